@@ -1,0 +1,42 @@
+"""Generates tests/golden/*.json from constants held in the reference SOURCE (run in the build
+container only; /root/reference does not exist on the GPU box). No reference code is copied: only
+format constants that pin the oracle are extracted.
+
+  python tests/golden/make_golden.py
+"""
+import json
+import os
+import re
+
+REF = "/root/reference/v2"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def expgolomb_tables():
+    src = open(os.path.join(REF, "entropy/ExpGolombCodec.go")).read()
+    body = src[src.index("_EXPG_VALUES"):]
+    body = body[: body.index("// ExpGolombEncoder")]
+    nums = [int(x) for x in re.findall(r"\b(\d+),", body)]
+    assert len(nums) == 512, len(nums)
+    return {"unsigned": nums[:256], "signed": nums[256:]}
+
+
+def main():
+    g = {
+        "source": "flanglet/kanzi-go v2 (bitstream v6)",
+        "expgolomb": expgolomb_tables(),
+        # BWT.go:48-62 doc-comment example
+        "bwt_mississippi": {"input": "mississippi", "bwt": "ipssmpissii", "primary_index": 5},
+        # Entropy_test.go:54-67 values; expected length = 1 + number of 7-bit groups above the first
+        "varint_values": [0, 1, 127, 128, 255, 16384, (1 << 21) - 1, 1 << 21, (1 << 28) - 1, 1 << 28, 0xFFFFFFFF],
+        # CompressedStream.go:42-54
+        "stream": {"magic": 0x4B414E5A, "version": 6, "hash_seed": 0x4B414E5A, "header_hash": 0x1E35A7BD,
+                   "header_seed_mul": 0x01030507},
+    }
+    with open(os.path.join(HERE, "reference_constants.json"), "w") as f:
+        json.dump(g, f, indent=1)
+    print("wrote reference_constants.json")
+
+
+if __name__ == "__main__":
+    main()
