@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py — encode+decode throughput of the MI355X-native Kanzi hot path (BASELINE.json metric).
+
+Workload (N=1): BASELINE.json configs[1] = `-t NONE -e HUFFMAN -b 4m` on S-silesia (211,957,760 synthetic bytes
+shaped like silesia.tar, bench_corpus.py). One step = compress the whole stream on the device (bit-exact .knz) and
+decompress it back, inputs resident in HBM. value = uncompressed MB (10^6 B) per second of a whole round trip;
+encode-only and decode-only rates are reported next to it.
+
+N>1: the blocks are sharded statically (contiguous ranges) over the ranks; every rank encodes/decodes its own
+blocks, the compressed segments are gathered to rank 0 over RCCL and assembled bit-granularly there. Total work is
+fixed => "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+CONFIGS = {
+    # name: (transform, entropy, block size, BASELINE.json config index)
+    "huffman": ("NONE", "HUFFMAN", 4 << 20, 1),
+}
+
+
+def load_pkg():
+    spec = importlib.util.spec_from_file_location("kanzi_go_amd", os.path.join(ROOT, "kanzi-go_amd", "__init__.py"),
+                                                  submodule_search_locations=[os.path.join(ROOT, "kanzi-go_amd")])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["kanzi_go_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cpu_baseline(data, transform, entropy, bs, budget_s=20.0):
+    """The oracle (C++ restatement of the kanzi-go CPU path, kind 'port') on the host cores, bounded sample."""
+    import oracle_lib as O
+    cores = os.cpu_count() or 1
+    sample = data
+    # probe on 32 MiB, then size the sample to ~budget_s of CPU work
+    probe = data[: min(len(data), 32 << 20)]
+    t0 = time.perf_counter()
+    c = O.compress(probe, transform, entropy, bs, 0, jobs=cores)
+    O.decompress(c, len(probe) + 64, jobs=cores)
+    dt = time.perf_counter() - t0
+    rate = len(probe) / dt
+    n = int(min(len(data), max(len(probe), rate * budget_s)))
+    n = max(bs, (n // bs) * bs)
+    sample = data[:n]
+    t0 = time.perf_counter()
+    c = O.compress(sample, transform, entropy, bs, 0, jobs=cores)
+    t1 = time.perf_counter()
+    back = O.decompress(c, len(sample) + 64, jobs=cores)
+    t2 = time.perf_counter()
+    assert back == sample.tobytes()
+    return {
+        "value": round(len(sample) / 1e6 / (t2 - t0), 2), "unit": "MB/s", "cores": cores, "kind": "port",
+        "encode_MBps": round(len(sample) / 1e6 / (t1 - t0), 2), "decode_MBps": round(len(sample) / 1e6 / (t2 - t1), 2),
+        "sample": f"first {len(sample)} bytes of S-silesia, {transform}/{entropy} -b {bs}, round trip, one block per thread",
+        "note": "C++ restatement of the kanzi-go CPU path (no Go toolchain in the image)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="huffman", choices=sorted(CONFIGS))
+    ap.add_argument("--size", type=int, default=0, help="override the corpus size (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import bench_corpus
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    K = load_pkg()
+    K.build_library()
+    transform, entropy, bs, cfg_idx = CONFIGS[args.config]
+
+    size = args.size or bench_corpus.SILESIA_SIZE
+    data = bench_corpus.s_silesia(size)
+    nblocks = (size + bs - 1) // bs
+    per = (nblocks + world - 1) // world
+    lo_b, hi_b = min(rank * per, nblocks), min((rank + 1) * per, nblocks)
+    lo, hi = lo_b * bs, min(hi_b * bs, size)
+    my = data[lo:hi]
+    n_my = len(my)
+
+    codec = K.Codec(transform, entropy, bs, device=local_rank)
+    d_src = torch.from_numpy(np.ascontiguousarray(my)).to(dev) if n_my else torch.zeros(16, dtype=torch.uint8, device=dev)
+    cap = per * bs + (per * bs) // 2 + (1 << 20)   # same on every rank (gather uses equal-sized buffers)
+    d_seg = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    d_back = torch.zeros(n_my + 4096, dtype=torch.uint8, device=dev)
+    d_stream = torch.zeros(size + size // 2 + (1 << 20), dtype=torch.uint8, device=dev) if rank == 0 and world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    stage = {"enc_entropy": 0.0, "enc_layout": 0.0, "enc_gather": 0.0, "dec_walk": 0.0, "dec_entropy": 0.0}
+    t_enc = t_dec = 0.0
+    result = {}
+
+    def one_step(timed):
+        nonlocal t_enc, t_dec
+        t0 = time.perf_counter()
+        if world == 1:
+            nb = codec.dev_compress(d_src.data_ptr(), n_my, d_seg.data_ptr(), cap, header_input_size=size, stream=stream)
+            result["stream_bytes"] = nb
+        else:
+            nbits = codec.dev_compress_blocks(d_src.data_ptr(), n_my, d_seg.data_ptr(), cap, stream=stream) if n_my else 0
+            result["seg_bits"] = nbits
+        tm = codec.last_timing()
+        if world > 1:
+            # gather of the compressed segments to rank 0 over RCCL/xGMI: sizes first, then padded payloads
+            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(sizes, torch.tensor([result["seg_bits"]], dtype=torch.int64, device=dev))
+            bits = [int(s.item()) for s in sizes]
+            maxb = (max(bits) + 7) // 8 + 8
+            maxb = (maxb + 15) & ~15
+            if rank == 0:
+                bufs = [torch.empty(maxb, dtype=torch.uint8, device=dev) for _ in range(world)]
+                dist.gather(d_seg[:maxb], bufs, dst=0)
+                nb = codec.dev_assemble(size, [b.data_ptr() for b in bufs], bits, d_stream.data_ptr(), d_stream.numel(), stream=stream)
+                result["stream_bytes"] = nb
+            else:
+                dist.gather(d_seg[:maxb], None, dst=0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if world == 1:
+            nd = codec.dev_decompress(d_seg.data_ptr(), result["stream_bytes"], d_back.data_ptr(), d_back.numel(), stream=stream)
+        else:
+            nd = codec.dev_decompress_blocks(d_seg.data_ptr(), result["seg_bits"], d_back.data_ptr(), d_back.numel(), stream=stream) if n_my else 0
+        td = codec.last_timing()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        assert nd == n_my, (nd, n_my)
+        if timed:
+            t_enc += t1 - t0
+            t_dec += t2 - t1
+            stage["enc_entropy"] += tm[1]; stage["enc_layout"] += tm[2]; stage["enc_gather"] += tm[3]
+            stage["dec_walk"] += td[0]; stage["dec_entropy"] += td[1]
+
+    for _ in range(args.warmup):
+        one_step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed, t_enc, t_dec], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, t_enc, t_dec = [float(x) for x in tt.tolist()]
+
+    ok_roundtrip = bool(torch.equal(d_back[:n_my], d_src[:n_my])) if n_my else True
+
+    if rank == 0:
+        K_ = max(args.steps, 1)
+        ms = elapsed / K_ * 1e3
+        C_bytes = result["stream_bytes"]
+        out = {
+            "metric": "encode+decode MB/s (round trip of the whole stream, uncompressed 10^6 B per second)",
+            "value": round(size / 1e6 / (elapsed / K_), 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{cfg_idx}]: -t {transform} -e {entropy} -b {bs >> 20}m on S-silesia "
+                                   f"({size} B, bench_corpus.py)", "blocks": nblocks, "block_size": bs,
+                       "parallelism": f"blocks sharded over {world} GPU(s)"},
+            "encode_MBps": round(size / 1e6 / (t_enc / K_), 2), "decode_MBps": round(size / 1e6 / (t_dec / K_), 2),
+            "compressed_bytes": int(C_bytes), "roundtrip_ok": ok_roundtrip,
+        }
+        # roofline of the dominant kernel, timed with HIP events on the launch stream inside the library
+        per_launch = {k: v / K_ for k, v in stage.items()}
+        n_local, c_local = n_my, (result.get("seg_bits", C_bytes * 8) + 7) // 8 if world > 1 else C_bytes
+        kern = {
+            "knz_huf_encode_kernel": (per_launch["enc_entropy"], n_local + c_local),
+            "knz_huf_decode_kernel": (per_launch["dec_entropy"] - 0.0, n_local + c_local),
+        }
+        dom = max(kern, key=lambda k: kern[k][0])
+        dur_ms, alg = kern[dom]
+        ach = alg / 1e9 / (dur_ms / 1e3) if dur_ms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                           "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(dur_ms, 4),
+                           "all_stage_ms": {k: round(v, 4) for k, v in per_launch.items()}}
+        if not args.no_verify and world == 1:
+            import oracle_lib as O
+            exp = O.compress(data, transform, entropy, bs, 0, jobs=os.cpu_count() or 1)
+            got = d_seg[:C_bytes].cpu().numpy().tobytes()
+            out["bit_exact_vs_oracle"] = bool(got == exp)
+        elif not args.no_verify:
+            import oracle_lib as O
+            exp = O.compress(data, transform, entropy, bs, 0, jobs=os.cpu_count() or 1)
+            got = d_stream[:C_bytes].cpu().numpy().tobytes()
+            out["bit_exact_vs_oracle"] = bool(got == exp)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(data, transform, entropy, bs)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

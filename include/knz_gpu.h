@@ -1,0 +1,137 @@
+/*
+ * knz_gpu.h — C ABI of the MI355X-native Kanzi block-compression hot path.
+ *
+ * Drop-in boundary for flanglet/kanzi-go (bitstream v6). Every entry point names the reference
+ * interface it replaces; the cgo stubs a kanzi-go maintainer would add are in INTEGRATION.md.
+ * Plain pointers and sizes only; the library never keeps a caller pointer after a call returns.
+ * Return value: 0 on success, otherwise a kanzi error code (v2/Definitions.go:25-46), except
+ * knz_transform_forward() which returns KNZ_SKIP when the transform declines (in kanzi-go a
+ * Forward error means "skip this transform", v2/transform/Sequence.go:86-91).
+ *
+ * The product library (libknz_gpu.so) contains gfx950 code only. There is no CPU fallback: with no
+ * usable GPU knz_open() fails with KNZ_ERR_CREATE_COMPRESSOR.
+ */
+#ifndef KNZ_GPU_H
+#define KNZ_GPU_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* v2/Definitions.go:25-46 */
+enum {
+    KNZ_OK = 0,
+    KNZ_ERR_MISSING_PARAM = 1, KNZ_ERR_BLOCK_SIZE = 2, KNZ_ERR_INVALID_CODEC = 3,
+    KNZ_ERR_CREATE_COMPRESSOR = 4, KNZ_ERR_CREATE_DECOMPRESSOR = 5, KNZ_ERR_READ_FILE = 11,
+    KNZ_ERR_WRITE_FILE = 12, KNZ_ERR_PROCESS_BLOCK = 13, KNZ_ERR_CREATE_CODEC = 14,
+    KNZ_ERR_INVALID_FILE = 15, KNZ_ERR_STREAM_VERSION = 16, KNZ_ERR_INVALID_PARAM = 18,
+    KNZ_ERR_CRC_CHECK = 19, KNZ_ERR_UNKNOWN = 127,
+    KNZ_SKIP = -1
+};
+
+/* transform ids, v2/transform/Factory.go:31-53 (6 bits each, first transform in bits 47..42) */
+enum { KNZ_T_NONE = 0, KNZ_T_BWT = 1, KNZ_T_LZ = 3, KNZ_T_ZRLT = 6, KNZ_T_MTFT = 7, KNZ_T_RANK = 8, KNZ_T_LZX = 16 };
+/* entropy ids, v2/entropy/EntropyCodecFactory.go:26-42 */
+enum { KNZ_E_NONE = 0, KNZ_E_HUFFMAN = 1, KNZ_E_FPAQ = 2, KNZ_E_ANS0 = 5, KNZ_E_ANS1 = 8 };
+
+/* Flat form of the ctx map handed to every kanzi-go factory (v2/io/CompressedStream.go:217-224,370-382). */
+typedef struct {
+    uint64_t transform;      /* packed as transform.GetType() returns it (Factory.go:289-328) */
+    uint32_t entropy;        /* entropy.GetType() value                                      */
+    uint32_t block_size;     /* ctx["blockSize"], multiple of 16, 1 KiB .. 1 GiB              */
+    uint32_t checksum_bits;  /* 0, 32 or 64 (Writer hasher32/hasher64)                        */
+    uint32_t bs_version;     /* ctx["bsVersion"]; only 6 is produced/accepted                 */
+    int32_t  device;         /* HIP device ordinal, -1 = current device                       */
+    uint32_t flags;          /* reserved, 0                                                   */
+} knz_cfg;
+
+/* One block of a batch: what one encodingTask/decodingTask owns (CompressedStream.go:189-214,1020-1045). */
+typedef struct {
+    const uint8_t* src;      /* encode: block bytes ; decode: block-local payload (mode byte first) */
+    uint32_t src_len;        /* bytes                                                          */
+    uint8_t* dst;            /* encode: block-local stream ; decode: decoded bytes              */
+    uint32_t dst_cap;
+    uint64_t out_bits;       /* encode: exact bit count (obs.Written() after Close, :912-914) ; decode: decoded bytes */
+    uint32_t post_len;       /* post-transform length (EVT_AFTER_TRANSFORM size)               */
+    uint8_t  skip_flags;     /* ByteTransformSequence.SkipFlags()                              */
+    uint8_t  mode;           /* block mode byte                                                */
+    uint16_t reserved;
+    uint64_t checksum;       /* XXHash32/64 of the original block when checksum_bits != 0       */
+    int32_t  status;         /* per-block kanzi error code (0 = ok)                            */
+    int32_t  reserved2;
+} knz_block;
+
+/* Handle = one GPU batch scheduler (device workspace + stream). One per io.Writer / io.Reader. */
+int knz_open(const knz_cfg* cfg, void** handle);
+int knz_close(void* handle);
+const char* knz_last_error(void* handle);
+
+/*
+ * Replaces the goroutine fan-out of Writer.processBlock (v2/io/CompressedStream.go:636-701): the n
+ * buffered blocks are encoded in one device batch. For every block the result equals
+ * encodingTask.encode up to obs.Close() (:729-914): dst holds mode byte .. entropy payload, out_bits the
+ * exact bit count. The Go host then performs the ordered emission (:951-976).
+ */
+int knz_encode_blocks(void* handle, knz_block* blocks, int n);
+
+/*
+ * Replaces the concurrent part of Reader.processBlock / decodingTask.decode after the payload has been
+ * read from the shared stream (:1875-2011). src = payload bytes (r = (read+7)>>3 of them).
+ */
+int knz_decode_blocks(void* handle, knz_block* blocks, int n);
+
+/*
+ * Whole-stream, device-resident form used by the bench and by multi-GPU sharding: d_src/d_dst are
+ * DEVICE pointers. Produces/consumes the complete .knz stream (header :429-519, blocks, end marker
+ * :593-594). hip_stream is a hipStream_t (NULL = the handle's own stream). out_bytes is a host pointer.
+ * header_input_size is ctx["fileSize"] written to the stream header (0 = unknown).
+ */
+int knz_dev_compress(void* handle, const void* d_src, uint64_t n, int64_t header_input_size,
+                     void* d_dst, uint64_t dst_cap, uint64_t* out_bytes, void* hip_stream);
+int knz_dev_decompress(void* handle, const void* d_src, uint64_t n_bytes,
+                       void* d_dst, uint64_t dst_cap, uint64_t* out_bytes, void* hip_stream);
+
+/*
+ * Multi-GPU block sharding: a rank encodes blocks [first_block, first_block+n_blocks) of a
+ * stream whose blocks are block_size bytes each; d_src points at this rank's first block. The result is a
+ * bit string (no stream header, no end marker): *out_bits bits, zero padded to a byte in d_dst.
+ * knz_dev_assemble() then concatenates the ranks' bit strings, in rank order, behind the stream header
+ * and appends the end marker (it is the device form of the ordered emission, :934-976).
+ */
+int knz_dev_compress_blocks(void* handle, const void* d_src, uint64_t n, void* d_dst, uint64_t dst_cap,
+                            uint64_t* out_bits, void* hip_stream);
+/* Decode side of the sharding: a rank decodes the framed blocks of its own segment (n_bits bits, no header). */
+int knz_dev_decompress_blocks(void* handle, const void* d_src, uint64_t n_bits, void* d_dst, uint64_t dst_cap,
+                              uint64_t* out_bytes, void* hip_stream);
+int knz_dev_assemble(void* handle, int64_t header_input_size, const void* const* d_segments,
+                     const uint64_t* segment_bits, int n_segments, void* d_dst, uint64_t dst_cap,
+                     uint64_t* out_bytes, void* hip_stream);
+
+/* Single kanzi.ByteTransform objects (v2/Definitions.go:78-91). type1 = one 6-bit transform id. Host pointers. */
+int knz_transform_forward(void* handle, uint64_t type1, const uint8_t* src, uint32_t n,
+                          uint8_t* dst, uint32_t cap, uint32_t* out_n);
+int knz_transform_inverse(void* handle, uint64_t type1, const uint8_t* src, uint32_t n,
+                          uint8_t* dst, uint32_t cap, uint32_t* out_n);
+/* ByteTransform.MaxEncodedLen for a packed sequence (Sequence.go:189-205) */
+uint32_t knz_max_encoded_len(uint64_t transform, uint32_t n);
+
+/* Single kanzi.EntropyEncoder / EntropyDecoder objects (v2/Definitions.go:154-179). Host pointers.
+ * encode: the shim then calls obs.WriteArray(bits, out_bits). decode: bits = the remaining payload. */
+int knz_entropy_encode(void* handle, uint32_t type, const uint8_t* src, uint32_t n,
+                       uint8_t* bits, uint64_t cap_bytes, uint64_t* out_bits);
+int knz_entropy_decode(void* handle, uint32_t type, const uint8_t* bits, uint64_t n_bytes,
+                       uint8_t* dst, uint32_t n, uint64_t* used_bits);
+
+/* Timing of the last device batch, measured with HIP events on the stream the kernels ran on.
+ * kernel_ms[] receives per-stage times, see KNZ_STAGE_*; returns the number of stages filled. */
+enum { KNZ_STAGE_TRANSFORM = 0, KNZ_STAGE_ENTROPY = 1, KNZ_STAGE_LAYOUT = 2, KNZ_STAGE_GATHER = 3, KNZ_STAGE_COUNT = 4 };
+int knz_last_timing(void* handle, float* stage_ms, int cap);
+
+/* 1 when a transform/entropy id has a device implementation in this build */
+int knz_supports(uint64_t transform, uint32_t entropy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KNZ_GPU_H */

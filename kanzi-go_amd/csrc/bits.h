@@ -1,0 +1,73 @@
+// Bit-string helpers shared by the gfx950 kernels.
+// kanzi bit streams are MSB-first (v2/bitstream/DefaultOutputBitStream.go:78-98): bit i of a stream is
+// bit (7 - i%8) of byte i/8. Kernels work on 32-bit "BE words": word w = bytes 4w..4w+3 read big-endian,
+// so stream bit 32w+k is bit (31-k) of the word; memory stores are byte-swapped 32-bit stores.
+#pragma once
+#include "wave.h"
+
+#define KNZ_HUF_CHUNK 16384          // _HUF_MAX_CHUNK_SIZE, HuffmanCodec.go:30
+#define KNZ_HUF_MAXLEN 12            // _HUF_MAX_SYMBOL_SIZE_V4, HuffmanCodec.go:31
+#define KNZ_UNITS_PER_CHUNK 5        // [header+varints][frag0][frag1][frag2][frag3+tail]
+#define KNZ_U0_BYTES 512             // scratch bytes reserved for unit 0
+#define KNZ_FRAG_BYTES 6160          // 4096 symbols * 12 bits = 6144 bytes, + tail 3 + pad
+#define KNZ_CHUNK_STRIDE (KNZ_U0_BYTES + 4 * KNZ_FRAG_BYTES)
+
+__device__ __forceinline__ uint32_t knz_bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+// BE word i of a byte buffer that is 4-byte aligned
+__device__ __forceinline__ uint32_t knz_load_be32(const uint8_t* base, int64_t word) {
+    return knz_bswap32(((const uint32_t*)base)[word]);
+}
+
+// 32 stream bits starting at bit position `bit` (bit may be negative or run past nbits: missing bits read 0)
+// of a 4-byte aligned MSB-first buffer holding nbits valid bits.
+__device__ __forceinline__ uint32_t knz_fetch32(const uint8_t* base, int64_t bit, int64_t nbits) {
+    int64_t q = bit >> 5;          // floor
+    int r = (int)(bit & 31);
+    int64_t nwords = (nbits + 31) >> 5;
+    uint32_t w0 = (q >= 0 && q < nwords) ? knz_load_be32(base, q) : 0u;
+    uint32_t w1 = (q + 1 >= 0 && q + 1 < nwords) ? knz_load_be32(base, q + 1) : 0u;
+    uint32_t v = r ? ((w0 << r) | (w1 >> (32 - r))) : w0;
+    // clear bits at or beyond nbits
+    int64_t valid = nbits - bit;   // number of leading bits of v that are inside the string (if bit >= 0)
+    if (valid <= 0) return 0u;
+    if (valid < 32) v &= ~(0xFFFFFFFFu >> valid);
+    return v;
+}
+
+// Serial MSB-first bit writer into a zeroed BE-word buffer (LDS or global). One thread only.
+struct KnzBitWriter {
+    uint32_t* words;
+    uint32_t pos;      // bits written
+    __device__ __forceinline__ void init(uint32_t* w) { words = w; pos = 0; }
+    __device__ __forceinline__ void put(uint32_t value, uint32_t count) { // count in [0..32]
+        if (count == 0) return;
+        if (count < 32) value &= (1u << count) - 1u;
+        uint32_t w = pos >> 5, off = pos & 31;
+        uint32_t room = 32 - off;
+        if (count <= room) {
+            words[w] |= value << (room - count);
+        } else {
+            uint32_t rem = count - room;
+            words[w] |= value >> rem;
+            words[w + 1] |= value << (32 - rem);
+        }
+        pos += count;
+    }
+};
+
+// EntropyUtils.go:264-275 WriteVarInt through a KnzBitWriter
+__device__ __forceinline__ void knz_put_varint(KnzBitWriter& bw, uint32_t value) {
+    while (value >= 128) { bw.put(0x80 | (value & 0x7F), 8); value >>= 7; }
+    bw.put(value, 8);
+}
+
+// Signed Exp-Golomb emit word (len<<9 | bits): closed form of ExpGolombCodec.go:45-62
+// (v as int8, n=|v|+1, L=floor(log2 n): (n<<1|sign) on 2L+2 bits; v == 0 is the single bit '1').
+__device__ __forceinline__ uint32_t knz_expg_signed(int v) {
+    if (v == 0) return (1u << 9) | 1u;
+    uint32_t sign = v < 0 ? 1u : 0u;
+    uint32_t n = (uint32_t)(v < 0 ? -v : v) + 1u;
+    uint32_t L = 31u - (uint32_t)__builtin_clz(n);
+    return ((2u * L + 2u) << 9) | ((n << 1) | sign);
+}

@@ -1,0 +1,357 @@
+// Decode side of the v6 stream for the Huffman path, gfx950.
+//   knz_dec_walk_stream_kernel  : Reader.processBlock's sequential part (v2/io/CompressedStream.go:1816-1852):
+//                                 reads (lw-3):5, written:lw of every block until the 0-length end marker.
+//   knz_dec_walk_blocks_kernel  : block header (:1878-1914) + the sequential location of every 16 KiB chunk of a
+//                                 Huffman payload (HuffmanDecoder.decodeV6 / readLengths / decodeChunkV6,
+//                                 v2/entropy/HuffmanCodec.go:758-805,620-657,807-830): chunks start where the
+//                                 previous one ended, fragment sizes are explicit varints.
+//   knz_huf_decode_kernel       : one wave64 per chunk: rebuild canonical codes + the 4096-entry table
+//                                 (buildDecodingTable :661-697) in LDS, then the 4 fragment bit strings are decoded
+//                                 by 4 lanes (decodeChunkV6 :832-969).
+#include "bits.h"
+
+// MSB-first reader over a 4-byte aligned global buffer, 64-bit window, aligned 32-bit refills.
+struct KnzStreamReader {
+    const uint32_t* words;
+    uint64_t nwords;      // readable words (reads beyond return 0)
+    uint64_t next;        // next word index to load
+    uint64_t win;         // left aligned
+    uint32_t navail;      // valid bits in win
+    __device__ __forceinline__ uint32_t ld(uint64_t i) const { return i < nwords ? knz_bswap32(words[i]) : 0u; }
+    __device__ __forceinline__ void init(const uint8_t* base, uint64_t nbytes, uint64_t bitpos) {
+        words = (const uint32_t*)base;
+        nwords = (nbytes + 3) >> 2;
+        uint64_t q = bitpos >> 5;
+        uint32_t off = (uint32_t)(bitpos & 31);
+        win = ((uint64_t)ld(q) << 32) | ld(q + 1);
+        win <<= off;
+        navail = 64 - off;
+        next = q + 2;
+    }
+    __device__ __forceinline__ void refill() {
+        if (navail <= 32) { win |= (uint64_t)ld(next++) << (32 - navail); navail += 32; }
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t n) { refill(); return (uint32_t)(win >> (64 - n)); } // 1..32
+    __device__ __forceinline__ void skip(uint32_t n) { refill(); win <<= n; navail -= n; }                 // 0..32
+    __device__ __forceinline__ uint32_t read(uint32_t n) { uint32_t v = peek(n); win <<= n; navail -= n; return v; }
+    __device__ __forceinline__ uint64_t tell() const { return (next << 5) - navail; }
+    __device__ __forceinline__ void seek(uint64_t bitpos) { init((const uint8_t*)words, nwords << 2, bitpos); }
+};
+
+// EntropyUtils.go:278-296
+__device__ __forceinline__ uint32_t knz_read_varint(KnzStreamReader& r) {
+    uint32_t res = 0, shift = 0;
+    for (int i = 0; i < 4; i++) {
+        uint32_t v = r.read(8);
+        res |= (v & 0x7F) << shift;
+        if (v < 128) return res;
+        shift += 7;
+    }
+    uint32_t v = r.read(8);
+    return res | ((v & 0x0F) << 28);
+}
+
+struct WalkStreamArgs {
+    const uint8_t* stream; uint64_t nbytes;
+    uint64_t first_bit;          // first block's framing
+    uint64_t seg_bits;           // != 0: a rank segment of exactly seg_bits bits without end marker (multi-GPU)
+    uint32_t max_blocks;
+    uint64_t* blk_bit;           // [max_blocks] bit position of the block-local stream
+    uint64_t* blk_bits;          // [max_blocks] its length in bits
+    uint32_t* result;            // [2] {nblocks, error code}
+};
+
+__global__ void knz_dec_walk_stream_kernel(WalkStreamArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    KnzStreamReader r;
+    r.init(a.stream, a.nbytes, a.first_bit);
+    const uint64_t limit = a.nbytes << 3;
+    uint32_t n = 0, err = 0;
+    for (;;) {
+        if (a.seg_bits && r.tell() >= a.first_bit + a.seg_bits) break;
+        if (r.tell() + 8 > limit) { err = KNZ_ERR_PROCESS_BLOCK; break; }     // bitstream EOS panic (:1778-1786)
+        uint32_t lr = r.read(5) + 3;
+        uint64_t read = 0;
+        if (lr > 32) { read = (uint64_t)r.read(lr - 32) << 32; read |= r.read(32); }
+        else read = r.read(lr);
+        if (read == 0) break;
+        if (read > ((uint64_t)1 << 34)) { err = KNZ_ERR_BLOCK_SIZE; break; }
+        uint64_t pos = r.tell();
+        if (pos + read > limit) { err = KNZ_ERR_PROCESS_BLOCK; break; }
+        if (n >= a.max_blocks) { err = KNZ_ERR_BLOCK_SIZE; break; }
+        a.blk_bit[n] = pos;
+        a.blk_bits[n] = read;
+        n++;
+        r.seek(pos + read);
+    }
+    a.result[0] = n;
+    a.result[1] = err;
+}
+
+struct WalkBlocksArgs {
+    const uint8_t* stream; uint64_t nbytes;
+    const uint64_t* blk_bit; const uint64_t* blk_bits;
+    uint32_t nblocks;
+    uint32_t block_size;          // stream block size (bounds preTransformLength, :1893-1903)
+    uint32_t checksum_bits;
+    uint32_t entropy;
+    uint32_t chunks_per_block;
+    uint32_t payload_only;        // 1: no block header, the entropy payload starts at blk_bit[b] and decodes to given_len bytes
+    uint32_t given_len;
+    // outputs
+    uint32_t* blk_pre_len;        // [nblocks] preTransformLength
+    uint8_t* blk_mode;            // [nblocks]
+    uint8_t* blk_skip;            // [nblocks]
+    uint64_t* blk_cksum;          // [nblocks]
+    uint64_t* chunk_bit;          // [nblocks*CPB] bit position of each chunk's first bit
+    int32_t* blk_status;          // [nblocks]
+    uint64_t* blk_end_bit;        // [nblocks] bit position just past the entropy payload
+};
+
+// Skips one signed Exp-Golomb code (ExpGolombCodec.go:159-190): '1' or L zeros, 1, L+1 bits.
+__device__ __forceinline__ void knz_skip_expg(KnzStreamReader& r) {
+    uint32_t w = r.peek(17);
+    if (w & 0x10000) { r.skip(1); return; }
+    if (w == 0) { r.skip(17); return; }                     // corrupt input; the walk fails its bounds check later
+    uint32_t z = (uint32_t)__builtin_clz(w << 15);         // leading zeros inside the 17-bit window
+    uint32_t lg = z & 7;                                    // the reference clamps log2 &= 7
+    // consumed: z zeros + the '1' + (lg+1) bits
+    r.skip(z + 1);
+    r.skip(lg + 1);
+}
+
+// one thread per block (serial walk); launched with 64-thread workgroups, one block per thread
+__global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs a) {
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.nblocks) return;
+    KnzStreamReader r;
+    const uint64_t start = a.blk_bit[b];
+    const uint64_t end = start + a.blk_bits[b];
+    // the block-local stream is its own bitstream in the reference (r = (read+7)>>3 bytes): reads past `end`
+    // rounded up to a byte are an EOS panic there; checked below per chunk
+    r.init(a.stream, a.nbytes, start);
+    int32_t status = 0;
+    uint32_t mode = 0, skipFlags = 0, preLen = a.given_len;
+    uint32_t entropy = a.entropy;
+    uint64_t ck = 0;
+    if (!a.payload_only) {
+        mode = r.read(8);
+        if (mode & 0x80) entropy = KNZ_E_NONE;
+        else if (mode & 0x10) skipFlags = r.read(8);
+        else skipFlags = ((mode << 4) | 0x0F) & 0xFF;
+        const uint32_t dataSize = 1 + ((mode >> 5) & 3);
+        preLen = r.read(8 * dataSize);
+        uint64_t maxLen = (uint64_t)a.block_size + a.block_size / 2;   // blockLength + blockLength/2 (:1893)
+        if (maxLen < 2048) maxLen = 2048;
+        if (maxLen > (1u << 30)) maxLen = 1u << 30;
+        if (preLen == 0 || preLen > maxLen) status = KNZ_ERR_BLOCK_SIZE;
+        if (a.checksum_bits == 32) ck = r.read(32);
+        else if (a.checksum_bits == 64) { ck = (uint64_t)r.read(32) << 32; ck |= r.read(32); }
+    }
+    a.blk_pre_len[b] = preLen;
+    a.blk_mode[b] = (uint8_t)mode;
+    a.blk_skip[b] = (uint8_t)skipFlags;
+    a.blk_cksum[b] = ck;
+    const uint64_t limit = start + (((a.blk_bits[b] + 7) >> 3) << 3);
+    const uint32_t cpb = a.chunks_per_block;
+    if (status == 0) {
+        const uint32_t nchunks = (preLen + KNZ_HUF_CHUNK - 1) / KNZ_HUF_CHUNK;
+        if (nchunks > cpb) status = KNZ_ERR_BLOCK_SIZE;
+        for (uint32_t k = 0; k < nchunks && status == 0; k++) {
+            const uint32_t sz = min((uint32_t)KNZ_HUF_CHUNK, preLen - k * KNZ_HUF_CHUNK);
+            a.chunk_bit[(size_t)b * cpb + k] = r.tell();
+            if (entropy == KNZ_E_NONE || sz < 32) {                    // raw bytes (HuffmanCodec.go:769-771)
+                r.seek(r.tell() + 8ull * sz);
+            } else {
+                // alphabet (EntropyUtils.go:71-119)
+                uint32_t count;
+                if (r.read(1) == 0) {
+                    if (r.read(1) == 1) { status = KNZ_ERR_PROCESS_BLOCK; break; }  // empty alphabet: Read returns short
+                    count = 256;
+                } else {
+                    uint32_t lastMask = r.read(5);
+                    count = 0;
+                    for (uint32_t m = 0; m <= lastMask; m++) count += (uint32_t)__popc(r.read(8));
+                    if (count == 0) { status = KNZ_ERR_PROCESS_BLOCK; break; }
+                }
+                for (uint32_t i = 0; i < count; i++) knz_skip_expg(r);
+                if (count > 1) {
+                    uint64_t fb = 0;
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t v = knz_read_varint(r);
+                        if ((int32_t)v < 0) status = KNZ_ERR_PROCESS_BLOCK;
+                        fb += v;
+                    }
+                    r.seek(r.tell() + fb + 8ull * (sz & 3));
+                }
+            }
+            if (r.tell() > limit) status = KNZ_ERR_PROCESS_BLOCK;       // ran past the block payload
+        }
+    }
+    a.blk_status[b] = status;
+    a.blk_end_bit[b] = r.tell();
+}
+
+struct HufDecArgs {
+    const uint8_t* stream; uint64_t nbytes;
+    const uint32_t* blk_pre_len;
+    const uint8_t* blk_mode;
+    const uint64_t* chunk_bit;
+    const uint64_t* blk_out_off;   // [nblocks] byte offset of the block's post-transform data in out
+    uint32_t chunks_per_block;
+    uint32_t entropy;
+    uint8_t* out;
+    int32_t* blk_status;
+};
+
+__global__ __launch_bounds__(64) void knz_huf_decode_kernel(HufDecArgs a) {
+    __shared__ uint16_t s_table[1 << KNZ_HUF_MAXLEN];
+    __shared__ uint8_t s_len[256];
+    __shared__ uint8_t s_alpha[256];
+    __shared__ uint16_t s_C[256];
+    __shared__ uint8_t s_symAt[256];
+    __shared__ uint32_t s_fragbits[4];
+    __shared__ uint64_t s_fragpos[4];
+    __shared__ int s_count, s_err;
+    __shared__ uint64_t s_tailpos;
+
+    const int lane = threadIdx.x;
+    const uint32_t cpb = a.chunks_per_block;
+    const uint32_t b = blockIdx.x / cpb, k = blockIdx.x % cpb;
+    const uint32_t preLen = a.blk_pre_len[b];
+    if (a.blk_status[b] != 0) return;
+    if ((uint64_t)k * KNZ_HUF_CHUNK >= preLen) return;
+    const uint32_t n = min((uint32_t)KNZ_HUF_CHUNK, preLen - k * KNZ_HUF_CHUNK);
+    uint8_t* dst = a.out + a.blk_out_off[b] + (size_t)k * KNZ_HUF_CHUNK;
+    const uint64_t cbit = a.chunk_bit[blockIdx.x];
+    uint32_t entropy = a.entropy;
+    if (a.blk_mode[b] & 0x80) entropy = KNZ_E_NONE;
+
+    if (entropy == KNZ_E_NONE || n < 32) {   // raw copy at an arbitrary bit offset
+        for (uint32_t i = lane * 4; i < n; i += 256) {
+            uint32_t w = knz_fetch32(a.stream, (int64_t)(cbit + 8ull * i), (int64_t)(a.nbytes << 3));
+            for (uint32_t j = 0; j < 4 && i + j < n; j++) dst[i + j] = (uint8_t)(w >> (24 - 8 * j));
+        }
+        return;
+    }
+
+    // ---- header: alphabet + code lengths (readLengths :620-657), serial on lane 0 ---------------------------------
+    for (int i = lane; i < 256; i += 64) s_len[i] = 0;
+    if (lane == 0) s_err = 0;
+    wave_sync();
+    if (lane == 0) {
+        KnzStreamReader r;
+        r.init(a.stream, a.nbytes, cbit);
+        int count = 0;
+        if (r.read(1) == 0) {
+            r.read(1);
+            count = 256;
+            for (int i = 0; i < 256; i++) s_alpha[i] = (uint8_t)i;
+        } else {
+            uint32_t lastMask = r.read(5);
+            for (uint32_t m = 0; m <= lastMask; m++) {
+                uint32_t mask = r.read(8);
+                for (int j = 0; j < 8; j++) if ((mask >> j) & 1) s_alpha[count++] = (uint8_t)(8 * m + j);
+            }
+        }
+        int curSize = 2;
+        for (int i = 0; i < count; i++) {
+            // signed Exp-Golomb (ExpGolombCodec.go:159-190)
+            int delta;
+            if (r.read(1) == 1) delta = 0;
+            else {
+                uint32_t lg = 1;
+                while (r.read(1) == 0) lg++;
+                lg &= 7;
+                uint32_t val = r.read(lg + 1);
+                uint32_t res = (val >> 1) + (1u << lg) - 1u;
+                if (val & 1) res = ~res + 1u;
+                delta = (int)(int8_t)(uint8_t)res;
+            }
+            curSize = (int)(int8_t)(curSize + delta);
+            if (curSize <= 0 || curSize > KNZ_HUF_MAXLEN) { s_err = KNZ_ERR_PROCESS_BLOCK; break; }
+            s_len[s_alpha[i]] = (uint8_t)curSize;
+        }
+        s_count = count;
+        if (count > 1 && s_err == 0) {
+            uint64_t fb[4];
+            for (int j = 0; j < 4; j++) { s_fragbits[j] = knz_read_varint(r); fb[j] = s_fragbits[j]; }
+            uint64_t p = r.tell();
+            for (int j = 0; j < 4; j++) { s_fragpos[j] = p; p += fb[j]; }
+            s_tailpos = p;
+        }
+    }
+    wave_sync();
+    if (s_err) { if (lane == 0) a.blk_status[b] = s_err; return; }
+    const int count = s_count;
+    if (count == 1) {                          // decodeV6 :778-786
+        const uint8_t v = s_alpha[0];
+        for (uint32_t i = lane; i < n; i += 64) dst[i] = v;
+        return;
+    }
+
+    // ---- canonical codes + decoding table ---------------------------------------------------------------------------
+    for (int i = lane; i < (1 << KNZ_HUF_MAXLEN) / 2; i += 64) ((uint32_t*)s_table)[i] = 0x00070007u;   // table[i] = 7 (:665-667)
+    for (int s = lane; s < 256; s += 64) {
+        const uint32_t ls = s_len[s];
+        if (ls == 0) continue;
+        uint32_t acc = 0, rank = 0;
+        for (int u = 0; u < 256; u++) {
+            const uint32_t lu = s_len[u];
+            const bool before = lu != 0 && (lu < ls || (lu == ls && u < s));
+            acc += before ? (1u << (KNZ_HUF_MAXLEN - lu)) : 0u;
+            rank += before ? 1u : 0u;
+        }
+        s_C[rank] = (uint16_t)min(acc, 0xFFFFu);
+        s_symAt[rank] = (uint8_t)s;
+    }
+    wave_sync();
+    bool bad = false;
+    for (int r = 0; r < count; r++) {
+        const uint32_t s = s_symAt[r];
+        const uint32_t len = s_len[s];
+        const uint32_t size = 1u << (KNZ_HUF_MAXLEN - len);
+        const uint32_t C = s_C[r];
+        if (C + size > (1u << KNZ_HUF_MAXLEN)) { bad = true; break; }      // buildDecodingTable returns false (:683-685)
+        const uint16_t val = (uint16_t)((s << 8) | len);
+        for (uint32_t e = lane; e < size; e += 64) s_table[C + e] = val;
+    }
+    wave_sync();
+    if (bad) { if (lane == 0) a.blk_status[b] = KNZ_ERR_PROCESS_BLOCK; return; }
+
+    // ---- fragments: lane j decodes fragment j (:832-969) --------------------------------------------------------------
+    const uint32_t F = n >> 2;
+    if (lane < 4) {
+        KnzStreamReader r;
+        r.init(a.stream, a.nbytes, s_fragpos[lane]);
+        uint8_t* d = dst + (size_t)lane * F;
+        for (uint32_t i = 0; i < F; i++) {
+            const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)];
+            r.skip(val & 0xFF);
+            d[i] = (uint8_t)(val >> 8);
+        }
+    }
+    if (lane == 4) {
+        for (uint32_t i = 4 * F; i < n; i++)
+            dst[i] = (uint8_t)(knz_fetch32(a.stream, (int64_t)(s_tailpos + 8ull * (i - 4 * F)), (int64_t)(a.nbytes << 3)) >> 24);
+    }
+}
+
+// -e NONE (NullEntropyCodec.go:43-62): chunk bytes become the units verbatim (4 x 4096 bytes in u1..u4)
+__global__ __launch_bounds__(256) void knz_raw_units_kernel(HufEncArgs a) {
+    const int tid = threadIdx.x;
+    const uint32_t cpb = a.chunks_per_block;
+    const uint32_t b = blockIdx.x / cpb, k = blockIdx.x % cpb;
+    const uint32_t postLen = a.blk_len[b];
+    uint32_t* ubits = a.unit_bits + (size_t)blockIdx.x * KNZ_UNITS_PER_CHUNK;
+    if ((uint64_t)k * KNZ_HUF_CHUNK >= postLen) { if (tid < KNZ_UNITS_PER_CHUNK) ubits[tid] = 0; return; }
+    const uint32_t n = min((uint32_t)KNZ_HUF_CHUNK, postLen - k * KNZ_HUF_CHUNK);
+    const uint8_t* src = a.data + a.blk_off[b] + (size_t)k * KNZ_HUF_CHUNK;
+    uint8_t* slot = a.scratch + (size_t)blockIdx.x * KNZ_CHUNK_STRIDE;
+    for (uint32_t i = tid; i < n; i += 256) slot[KNZ_U0_BYTES + (size_t)(i >> 12) * KNZ_FRAG_BYTES + (i & 4095)] = src[i];
+    if (tid < KNZ_UNITS_PER_CHUNK) {
+        uint32_t bits = 0;
+        if (tid >= 1) { uint32_t lo = (uint32_t)(tid - 1) * 4096u; bits = n > lo ? 8u * min(4096u, n - lo) : 0u; }
+        ubits[tid] = bits;
+    }
+}

@@ -1,0 +1,43 @@
+// Host-side internals of libknz_gpu: the GPU batch scheduler that Writer.processBlock / Reader.processBlock are
+// re-pointed at (v2/io/CompressedStream.go:621-710, 1614-1744). One Handle = one device workspace + one HIP stream.
+#pragma once
+#include "../../include/knz_gpu.h"
+#include "bits.h"
+#include <string>
+#include <vector>
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n);            // grows (never shrinks); contents are not preserved
+    void release();
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+struct Handle {
+    knz_cfg cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // workspace
+    DevBuf blk_off, blk_len, blk_src_len, blk_skip, blk_cksum, blk_status;
+    DevBuf unit_bits, scratch, chunk_rel, blk_written, blk_hdr, blk_dst_bit, total_bits;
+    DevBuf stage_in, stage_out;       // host-pointer entry points stage through these
+    DevBuf dec_tables;                // decoder per-chunk positions
+    void* pinned = nullptr;           // small pinned host area for results
+    hipEvent_t ev[KNZ_STAGE_COUNT + 1];
+    bool ev_valid = false;
+    float stage_ms[KNZ_STAGE_COUNT];
+};
+
+// ---- kernels (defined in the .hip files) -------------------------------------------------------------------------
+struct HufEncArgs;
+struct LayoutArgs;
+struct StreamArgs;
+struct GatherArgs;
+
+int knz_set_error(Handle* h, int code, const char* msg);
+
+// stream header (v2/io/CompressedStream.go:429-519): returns bit count, fills BE words
+uint32_t knz_build_stream_header(const knz_cfg& cfg, int64_t inputSize, uint32_t words[8]);

@@ -1,0 +1,71 @@
+// Wave64 primitives for gfx950 kernels (CDNA4: 64 lanes per wavefront, 4 SIMD-32 per CU).
+// Every cross-lane operation used by the kernels goes through this header so that the execution-model
+// emulator in tests/emu (test infrastructure, CPU container has no GPU) can stand in for the hardware.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KNZ_WAVE 64
+
+#ifndef KNZ_HIP_EMU
+// ------------------------------------------------------------------ device (gfx950)
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t wave_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+__device__ __forceinline__ uint64_t wave_shfl64(uint64_t v, int src) {
+    uint32_t lo = wave_shfl((uint32_t)v, src), hi = wave_shfl((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ uint32_t wave_bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+// LDS written by one lane, read by another lane of the SAME wave: make the DS writes land and stop
+// the compiler from moving accesses across (waves run their DS ops in order).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#else
+// ------------------------------------------------------------------ emulator (tests only)
+inline int lane_id() { return hipemu::lane(); }
+inline uint64_t wave_shfl64(uint64_t v, int src) {
+    uint64_t* s = hipemu::wave_slots();
+    s[hipemu::lane()] = v;
+    hipemu::wave_barrier();
+    uint64_t r = s[src & 63];
+    hipemu::wave_barrier();
+    return r;
+}
+inline uint32_t wave_shfl(uint32_t v, int src) { return (uint32_t)wave_shfl64(v, src); }
+inline uint64_t wave_ballot(bool p) {
+    uint64_t* s = hipemu::wave_slots();
+    s[hipemu::lane()] = p ? 1 : 0;
+    hipemu::wave_barrier();
+    uint64_t r = 0;
+    for (int i = 0; i < 64; i++) r |= (s[i] & 1) << i;
+    hipemu::wave_barrier();
+    return r;
+}
+inline uint32_t wave_bcast(uint32_t v, int src) { return wave_shfl(v, src); }
+inline void wave_sync() { hipemu::wave_barrier(); }
+#endif
+
+// inclusive prefix sum across the wave (log-step shuffles)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = wave_shfl(v, l - d);
+        if (l >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += wave_shfl(v, lane_id() ^ d);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_reduce_max(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { uint32_t t = wave_shfl(v, lane_id() ^ d); v = t > v ? t : v; }
+    return v;
+}

@@ -1,0 +1,99 @@
+// TEST INFRASTRUCTURE ONLY — see include/hip/hip_runtime.h in this directory.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <random>
+
+uint3_emu threadIdx, blockIdx;
+dim3 blockDim, gridDim;
+
+namespace hipemu {
+static const size_t STACK = 256 * 1024;
+struct Fiber { ucontext_t ctx; char* stack = nullptr; bool done = false; unsigned tid = 0; };
+static std::vector<Fiber> fibers;
+static ucontext_t schedCtx;
+static int cur = -1;
+static const std::function<void()>* bodyPtr = nullptr;
+static unsigned blkArrived, blkGen, blkAlive;
+static unsigned wvArrived[64], wvGen[64], wvAlive[64];
+static uint64_t wvSlots[64][64];
+static unsigned long progress = 0;
+
+static void trampoline() {
+    (*bodyPtr)();
+    Fiber& f = fibers[cur];
+    f.done = true;
+    progress++;
+    blkAlive--;
+    wvAlive[f.tid >> 6]--;
+    // a finished thread no longer takes part in barriers: release waiters if it was the last one missing
+    if (blkAlive && blkArrived == blkAlive) { blkArrived = 0; blkGen++; }
+    unsigned w = f.tid >> 6;
+    if (wvAlive[w] && wvArrived[w] == wvAlive[w]) { wvArrived[w] = 0; wvGen[w]++; }
+    swapcontext(&f.ctx, &schedCtx);
+}
+static inline void yield() { swapcontext(&fibers[cur].ctx, &schedCtx); }
+
+void block_barrier() {
+    unsigned g = blkGen;
+    progress++;
+    if (++blkArrived == blkAlive) { blkArrived = 0; blkGen++; return; }
+    while (blkGen == g) yield();
+}
+void wave_barrier() {
+    unsigned w = fibers[cur].tid >> 6;
+    unsigned g = wvGen[w];
+    progress++;
+    if (++wvArrived[w] == wvAlive[w]) { wvArrived[w] = 0; wvGen[w]++; return; }
+    while (wvGen[w] == g) yield();
+}
+uint64_t* wave_slots() { return wvSlots[fibers[cur].tid >> 6]; }
+int lane() { return (int)(fibers[cur].tid & 63); }
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+    unsigned nt = block.x * block.y * block.z;
+    if (nt == 0 || nt > 1024) { fprintf(stderr, "hipemu: bad block size %u\n", nt); abort(); }
+    const char* mode = getenv("KNZ_EMU_SCHED");
+    int sched = 0; // 0 fwd, 1 rev, 2 random
+    if (mode && !strcmp(mode, "rev")) sched = 1;
+    if (mode && !strcmp(mode, "rand")) sched = 2;
+    static std::mt19937 rng(12345);
+    if (fibers.size() < nt) fibers.resize(nt);
+    for (unsigned i = 0; i < nt; i++) if (!fibers[i].stack) fibers[i].stack = (char*)malloc(STACK);
+    bodyPtr = &body;
+    blockDim = block; gridDim = grid;
+    std::vector<unsigned> order(nt);
+    for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
+        blkArrived = 0; blkGen = 0; blkAlive = nt;
+        for (unsigned w = 0; w < 64; w++) { wvArrived[w] = 0; wvGen[w] = 0; wvAlive[w] = 0; }
+        for (unsigned i = 0; i < nt; i++) {
+            Fiber& f = fibers[i];
+            f.done = false; f.tid = i;
+            wvAlive[i >> 6]++;
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = &schedCtx;
+            makecontext(&f.ctx, (void (*)())trampoline, 0);
+            order[i] = i;
+        }
+        if (sched == 1) std::reverse(order.begin(), order.end());
+        unsigned remaining = nt;
+        unsigned long lastProgress = progress; int stalls = 0;
+        while (remaining) {
+            if (sched == 2) std::shuffle(order.begin(), order.end(), rng);
+            for (unsigned k = 0; k < nt; k++) {
+                unsigned i = order[k];
+                Fiber& f = fibers[i];
+                if (f.done) continue;
+                cur = (int)i;
+                unsigned lin = i;
+                threadIdx.x = lin % block.x; threadIdx.y = (lin / block.x) % block.y; threadIdx.z = lin / (block.x * block.y);
+                blockIdx.x = bx; blockIdx.y = by; blockIdx.z = bz;
+                swapcontext(&schedCtx, &f.ctx);
+                if (f.done) remaining--;
+            }
+            if (progress == lastProgress) { if (++stalls > 2) { fprintf(stderr, "hipemu: deadlock (divergent barrier / cross-lane op) in block %u\n", bx); abort(); } }
+            else { stalls = 0; lastProgress = progress; }
+        }
+    }
+    cur = -1;
+}
+} // namespace hipemu

@@ -1,0 +1,195 @@
+"""Parity cases shared by the emulator run (CPU container, `-m "not gpu"`) and the real MI355X run (`-m gpu`).
+Every case compares the HIP path (through the C ABI of include/knz_gpu.h) with the CPU oracle, bit for bit."""
+import numpy as np
+
+import knz
+import oracle_lib as O
+
+K = knz.package()
+
+
+class EmuBackend:
+    """TEST INFRASTRUCTURE: kernels compiled against tests/emu; 'device' memory is host memory."""
+    name = "emu"
+
+    def __init__(self):
+        self.lib = knz.emu_library()
+
+    def empty(self, n, align=16):
+        raw = np.zeros(n + align + 8, dtype=np.uint8)
+        off = (-raw.ctypes.data) % align
+        v = raw[off:off + n + 8]
+        return v.ctypes.data, (raw, v)
+
+    def to_dev(self, data, align=16):
+        ptr, keep = self.empty(len(data), align)
+        keep[1][: len(data)] = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        return ptr, keep
+
+    def to_host(self, keep, n):
+        return keep[1][:n].tobytes()
+
+    def sync(self):
+        pass
+
+
+class GpuBackend:
+    """The product path: libknz_gpu.so (gfx950) on cuda:0, device memory owned by torch."""
+    name = "gpu"
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        assert torch.cuda.is_available(), "GPU tests need a GPU"
+        self.lib = K.library_path()
+        self.dev = torch.device("cuda:0")
+
+    def empty(self, n, align=16):
+        t = self.torch.zeros(n + 16, dtype=self.torch.uint8, device=self.dev)  # torch allocations are 256-byte aligned
+        return t.data_ptr(), t
+
+    def to_dev(self, data, align=16):
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        t = self.torch.zeros(len(a) + 16, dtype=self.torch.uint8, device=self.dev)
+        if len(a):
+            t[: len(a)] = self.torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        return t.data_ptr(), t
+
+    def to_host(self, keep, n):
+        return keep[:n].cpu().numpy().tobytes()
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+
+def corpus(n, seed=3):
+    r = np.random.default_rng(seed)
+    words = [bytes(r.integers(97, 123, int(r.integers(2, 9)), dtype=np.uint8)) for _ in range(500)]
+    text = b" ".join(words[int(i)] for i in r.integers(0, 500, max(n // 4, 8)))
+    binary = (r.integers(0, 256, n // 4 + 1, dtype=np.uint8) & r.integers(0, 256, n // 4 + 1, dtype=np.uint8)).tobytes()
+    return (text + binary + bytes(n // 8) + text[::-1] + bytes(n))[:n]
+
+
+def fib_chunk(n=16384, k=24, seed=1):
+    """Fibonacci-like symbol counts: Huffman depth > 12 => exercises limitCodeLengths (HuffmanCodec.go:216-297)."""
+    f = [1, 1]
+    while len(f) < k:
+        f.append(f[-1] + f[-2])
+    f = np.array(f, dtype=np.float64)
+    f = np.maximum(1, np.floor(f / f.sum() * n)).astype(np.int64)
+    f[-1] += n - f.sum()
+    data = np.repeat(np.arange(k, dtype=np.uint8) * 7 + 3, f)
+    np.random.default_rng(seed).shuffle(data)
+    return data[:n].tobytes()
+
+
+def entropy_inputs():
+    rng = np.random.default_rng(0x4B414E5A)
+    yield "40x2", bytes([2] * 40)
+    yield "ascii16", bytes([0x3d, 0x4d, 0x54, 0x47, 0x5a, 0x36, 0x39, 0x26, 0x72, 0x6f, 0x6c, 0x65, 0x3d, 0x70, 0x72, 0x65])
+    yield "alt40", bytes(2 + (i & 1) for i in range(40))
+    yield "one", bytes([42])
+    yield "two", bytes([42, 42])
+    for ii in (7, 13, 19):
+        yield f"rand256_{ii}", bytes(int(64 + 4 * ii + rng.integers(0, 8 * ii + 1)) & 255 for _ in range(256))
+    yield "all256", bytes(range(256))
+    yield "1024x42", bytes([42] * 1024)
+    yield "AB512", b"AB" * 512
+    yield "rand4096", rng.integers(0, 256, 4096, dtype=np.uint8).tobytes()
+    v = bytearray(4096)
+    for i in range(1, 256):
+        v[i * 16] = i
+    yield "sparse4096", bytes(v)
+    for n in (31, 32, 33, 16383, 16384, 16385, 16384 + 31, 16384 + 32, 16384 * 3 + 5, 70001):
+        yield f"geom{n}", np.minimum(rng.geometric(0.2, n), 255).astype(np.uint8).tobytes()
+    yield "skew50000", (rng.integers(0, 4, 50000) * 17).astype(np.uint8).tobytes()
+    yield "fib24", fib_chunk(16384, 24)
+    yield "fib30", fib_chunk(16384, 30, 2) + fib_chunk(9000, 20, 3)
+    yield "text", corpus(100000)
+
+
+def check_entropy_encode(be, etype_name):
+    c = K.Codec("NONE", etype_name, 1 << 16, lib=be.lib)
+    enc = K.EntropyEncoder(c, etype_name)
+    dec = K.EntropyDecoder(c, etype_name)
+    et = O.entropy_type(etype_name)
+    for name, data in entropy_inputs():
+        gb, gbits = enc.write(data)
+        ob, obits = O.entropy_encode(et, data)
+        assert gbits == obits, (name, gbits, obits)
+        assert gb == ob, name
+        # the device decoder must accept the oracle's bits and vice versa (decoder restated independently)
+        dd, used = dec.read(ob, len(data))
+        assert dd == data, name
+        assert used == obits, (name, used, obits)
+        assert O.entropy_decode(et, gb, len(data))[0] == data
+    c.close()
+
+
+def check_stream(be, transform, entropy, block_size, n, seed=3):
+    data = corpus(n, seed)
+    c = K.Codec(transform, entropy, block_size, lib=be.lib)
+    src, ksrc = be.to_dev(data)
+    cap = n + n // 2 + 65536
+    dst, kdst = be.empty(cap)
+    nb = c.dev_compress(src, n, dst, cap)
+    got = be.to_host(kdst, nb)
+    exp = O.compress(data, transform, entropy, block_size)
+    assert len(got) == len(exp), (len(got), len(exp))
+    assert got == exp
+    # decode the oracle's stream on the device
+    sp, ks = be.to_dev(exp, 4)
+    out, kout = be.empty(n + 64)
+    nd = c.dev_decompress(sp, len(exp), out, n + 64)
+    assert nd == n
+    assert be.to_host(kout, nd) == data
+    c.close()
+    return len(exp)
+
+
+def check_block_batch(be, transform, entropy, block_size, nblocks, last_len):
+    """Writer.processBlock / Reader.processBlock batch hook through host buffers (knz_encode_blocks/knz_decode_blocks)."""
+    c = K.Codec(transform, entropy, block_size, lib=be.lib)
+    bb = K.BlockBatch(c)
+    blocks = [corpus(block_size, 10 + i) for i in range(nblocks - 1)] + [corpus(last_len, 99)]
+    res = bb.encode(blocks)
+    tt, et = O.transform_type(transform), O.entropy_type(entropy)
+    for blk, (bits, written, mode, post) in zip(blocks, res):
+        o = O.encode_block(blk, tt, et)
+        assert written == o["written"]
+        assert bits == o["bits"]
+        assert mode == o["mode"] and post == o["post_len"]
+    back = bb.decode([r[0] for r in res])
+    assert back == blocks
+    c.close()
+
+
+def check_assemble(be, entropy, block_size, n, ranks):
+    """Multi-GPU sharding: each 'rank' encodes a contiguous range of blocks, rank 0 assembles."""
+    data = corpus(n, 5)
+    nblocks = (n + block_size - 1) // block_size
+    per = (nblocks + ranks - 1) // ranks
+    c = K.Codec("NONE", entropy, block_size, lib=be.lib)
+    segs, bits, keep = [], [], []
+    for r in range(ranks):
+        lo, hi = min(r * per, nblocks) * block_size, min(min((r + 1) * per, nblocks) * block_size, n)
+        part = data[lo:hi]
+        cap = len(part) + len(part) // 2 + 65536
+        dst, kdst = be.empty(cap)
+        if part:
+            src, ksrc = be.to_dev(part)
+            keep.append(ksrc)
+            nb = c.dev_compress_blocks(src, len(part), dst, cap)
+            back, kback = be.empty(len(part) + 64)
+            assert c.dev_decompress_blocks(dst, nb, back, len(part) + 64) == len(part)   # each rank decodes its own segment
+            assert be.to_host(kback, len(part)) == part
+        else:
+            nb = 0
+        segs.append(dst)
+        bits.append(nb)
+        keep.append(kdst)
+    cap = n + n // 2 + 65536
+    out, kout = be.empty(cap)
+    total = c.dev_assemble(n, segs, bits, out, cap)
+    assert be.to_host(kout, total) == O.compress(data, "NONE", entropy, block_size)
+    c.close()
