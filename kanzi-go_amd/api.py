@@ -123,7 +123,7 @@ class Codec:
         self.h = C.c_void_p()
         rc = self.L.knz_open(C.byref(self.cfg), C.byref(self.h))
         if rc:
-            raise KnzError(rc, "knz_open failed (no usable GPU or invalid configuration)")
+            raise KnzError(rc, "knz_open failed: " + self.L.knz_last_error(None).decode() + " (no CPU fallback exists)")
 
     def close(self):
         if self.h:

@@ -120,10 +120,11 @@ __device__ __forceinline__ void knz_skip_expg(KnzStreamReader& r) {
     r.skip(lg + 1);
 }
 
-// one thread per block (serial walk); launched with 64-thread workgroups, one block per thread
+// One wave per block, the serial walk runs on lane 0 only: putting several blocks on the lanes of one wave makes
+// their data-dependent loops diverge and the wave then pays for the union of all paths.
 __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs a) {
-    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= a.nblocks) return;
+    const uint32_t b = blockIdx.x;
+    if (b >= a.nblocks || threadIdx.x != 0) return;
     KnzStreamReader r;
     const uint64_t start = a.blk_bit[b];
     const uint64_t end = start + a.blk_bits[b];

@@ -100,23 +100,30 @@ extern "C" uint32_t knz_max_encoded_len(uint64_t transform, uint32_t n) {
 }
 
 // ---- open / close --------------------------------------------------------------------------------------------------
+static thread_local std::string g_open_error;
+
 extern "C" int knz_open(const knz_cfg* cfg, void** handle) {
     if (!cfg || !handle) return KNZ_ERR_MISSING_PARAM;
     *handle = nullptr;
-    if (cfg->block_size < 1024 || cfg->block_size > (1u << 30) || (cfg->block_size & 15)) return KNZ_ERR_BLOCK_SIZE;
-    if (cfg->checksum_bits != 0 && cfg->checksum_bits != 32 && cfg->checksum_bits != 64) return KNZ_ERR_INVALID_PARAM;
-    if (cfg->bs_version != 0 && cfg->bs_version != 6) return KNZ_ERR_STREAM_VERSION;
+    g_open_error.clear();
+    if (cfg->block_size < 1024 || cfg->block_size > (1u << 30) || (cfg->block_size & 15)) { g_open_error = "invalid block size"; return KNZ_ERR_BLOCK_SIZE; }
+    if (cfg->checksum_bits != 0 && cfg->checksum_bits != 32 && cfg->checksum_bits != 64) { g_open_error = "invalid checksum size"; return KNZ_ERR_INVALID_PARAM; }
+    if (cfg->bs_version != 0 && cfg->bs_version != 6) { g_open_error = "only bitstream version 6"; return KNZ_ERR_STREAM_VERSION; }
     Handle* h = new Handle();
     h->cfg = *cfg;
     h->cfg.bs_version = 6;
     int dev = cfg->device;
-    if (dev >= 0) { if (hipSetDevice(dev) != hipSuccess) { delete h; return KNZ_ERR_CREATE_COMPRESSOR; } }
-    else if (hipGetDevice(&dev) != hipSuccess) { delete h; return KNZ_ERR_CREATE_COMPRESSOR; }
+    hipError_t e = hipSuccess;
+    if (dev < 0) { e = hipGetDevice(&dev); if (e != hipSuccess) dev = 0; }
+    e = hipSetDevice(dev);
+    if (e != hipSuccess) { g_open_error = std::string("hipSetDevice: ") + hipGetErrorString(e); delete h; return KNZ_ERR_CREATE_COMPRESSOR; }
     h->device = dev;
     void* probe = nullptr;
-    if (hipMalloc(&probe, 256) != hipSuccess) { delete h; return KNZ_ERR_CREATE_COMPRESSOR; } // no GPU: fail loudly
+    e = hipMalloc(&probe, 256);                      // no usable GPU: fail loudly, there is no CPU fallback
+    if (e != hipSuccess) { g_open_error = std::string("hipMalloc: ") + hipGetErrorString(e); delete h; return KNZ_ERR_CREATE_COMPRESSOR; }
     hipFree(probe);
-    if (hipHostMalloc(&h->pinned, 4096) != hipSuccess) { delete h; return KNZ_ERR_CREATE_COMPRESSOR; }
+    e = hipHostMalloc(&h->pinned, 4096);
+    if (e != hipSuccess) { g_open_error = std::string("hipHostMalloc: ") + hipGetErrorString(e); delete h; return KNZ_ERR_CREATE_COMPRESSOR; }
     for (int i = 0; i <= KNZ_STAGE_COUNT; i++) hipEventCreate(&h->ev[i]);
     for (int i = 0; i < KNZ_STAGE_COUNT; i++) h->stage_ms[i] = 0.f;
     *handle = h;
@@ -136,7 +143,7 @@ extern "C" int knz_close(void* handle) {
     return KNZ_OK;
 }
 
-extern "C" const char* knz_last_error(void* handle) { return handle ? ((Handle*)handle)->err.c_str() : ""; }
+extern "C" const char* knz_last_error(void* handle) { return handle ? ((Handle*)handle)->err.c_str() : g_open_error.c_str(); }
 
 extern "C" int knz_last_timing(void* handle, float* stage_ms, int cap) {
     Handle* h = (Handle*)handle;
