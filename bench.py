@@ -30,6 +30,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 CONFIGS = {
     # name: (transform, entropy, block size, BASELINE.json config index)
     "huffman": ("NONE", "HUFFMAN", 4 << 20, 1),
+    "ans0": ("NONE", "ANS0", 4 << 20, 2),       # entropy half of configs[2] (LZ front end: see DESIGN.md)
+    "bwt": ("BWT+RANK+ZRLT", "ANS1", 8 << 20, 3),
 }
 
 
@@ -118,7 +120,7 @@ def main():
     d_stream = torch.zeros(size + size // 2 + (1 << 20), dtype=torch.uint8, device=dev) if rank == 0 and world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
 
-    stage = {"enc_entropy": 0.0, "enc_layout": 0.0, "enc_gather": 0.0, "dec_walk": 0.0, "dec_entropy": 0.0}
+    stage = {"enc_transform": 0.0, "enc_entropy": 0.0, "enc_layout": 0.0, "enc_gather": 0.0, "dec_walk": 0.0, "dec_entropy": 0.0, "dec_transform": 0.0}
     t_enc = t_dec = 0.0
     result = {}
 
@@ -159,8 +161,8 @@ def main():
         if timed:
             t_enc += t1 - t0
             t_dec += t2 - t1
-            stage["enc_entropy"] += tm[1]; stage["enc_layout"] += tm[2]; stage["enc_gather"] += tm[3]
-            stage["dec_walk"] += td[0]; stage["dec_entropy"] += td[1]
+            stage["enc_transform"] += tm[0]; stage["enc_entropy"] += tm[1]; stage["enc_layout"] += tm[2]; stage["enc_gather"] += tm[3]
+            stage["dec_walk"] += td[0]; stage["dec_entropy"] += td[1]; stage["dec_transform"] += td[2]
 
     for _ in range(args.warmup):
         one_step(False)
@@ -200,8 +202,11 @@ def main():
         per_launch = {k: v / K_ for k, v in stage.items()}
         n_local, c_local = n_my, (result.get("seg_bits", C_bytes * 8) + 7) // 8 if world > 1 else C_bytes
         kern = {
-            "knz_huf_encode_kernel": (per_launch["enc_entropy"], n_local + c_local),
-            "knz_huf_decode_kernel": (per_launch["dec_entropy"] - 0.0, n_local + c_local),
+            {"HUFFMAN": "knz_huf_encode_kernel", "ANS0": "knz_ans0_stats+encode_kernels", "ANS1": "knz_ans1_hist+stats+merge+encode_kernels"}[entropy]: (per_launch["enc_entropy"], n_local + c_local),
+            {"HUFFMAN": "knz_huf_decode_kernel", "ANS0": "knz_ans0_decode_kernel", "ANS1": "knz_ans1_dec_tables+decode_kernels"}[entropy]: (per_launch["dec_entropy"], n_local + c_local),
+            "knz_dec_walk_blocks_kernel": (per_launch["dec_walk"], c_local),
+            "forward transforms (suffix sort + RANK + ZRLT stage kernels)": (per_launch["enc_transform"], 2 * n_local),
+            "inverse transforms (ZRLT^-1, RANK^-1, BWT^-1 chains)": (per_launch["dec_transform"], 2 * n_local),
         }
         dom = max(kern, key=lambda k: kern[k][0])
         dur_ms, alg = kern[dom]

@@ -190,7 +190,7 @@ class BlockBatch:
         keep = []
         for i, b in enumerate(blocks):
             a, _ = _u8(b)
-            cap = int(self.c.L.knz_max_encoded_len(self.c.cfg.transform, len(a))) * 12 // 8 + 1024
+            cap = int(self.c.L.knz_max_encoded_len(self.c.cfg.transform, len(a))) * 2 + 262144
             o = np.zeros(cap, dtype=np.uint8)
             keep.append((a, o))
             arr[i].src = a.ctypes.data
@@ -228,7 +228,7 @@ class EntropyEncoder:
 
     def write(self, block):
         a, p = _u8(block)
-        cap = len(a) * 12 // 8 + 8192
+        cap = len(a) * 2 + 262144
         out = np.zeros(cap, dtype=np.uint8)
         bits = C.c_uint64()
         self.c._chk(self.c.L.knz_entropy_encode(self.c.h, self.t, p, len(a), out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(bits)))

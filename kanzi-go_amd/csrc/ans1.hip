@@ -1,0 +1,472 @@
+// Static rANS order 1 of kanzi bitstream v6 on gfx950: 4 MiB chunks (min(16384<<8, 1<<27), ANSRangeCodec.go:98-100,153-155),
+// log range 11, 256 context tables, the chunk split into 4 quarters coded BACKWARDS in lock-step by the 4 states, each
+// quarter's first symbol coded in context 0 (ANSRangeCodec.go:353-388, rebuildStatistics :414-423).
+//
+//   knz_ans1_hist_kernel    16 workgroups per chunk, each owns 16 contexts in LDS and streams the chunk (L2/MALL resident)
+//   knz_ans1_stats_kernel   one wave per (chunk, context): NormalizeFrequencies to 2048, symbol parameters, header bits
+//   knz_ans1_merge_kernel   one workgroup per chunk: bit-granular concatenation of the 256 context headers (unit 0)
+//   knz_ans1_encode_kernel  one LANE per state; the symbol-table look-ups do not depend on the state, so they are issued
+//                           a group of 8 steps ahead of the dependent state arithmetic (hides the L2 latency of the 512 KiB
+//                           table); renormalisation words are placed with the ballot/popcount scheme of ans0.hip
+// Decode: knz_ans1_dec_tables_kernel (header parse, slot table {symbol,freq,slot-cum} 2 MiB per chunk) and
+// knz_ans1_decode_kernel (one lane per state, forward).
+#include "bits.h"
+
+#define KNZ_ANS1_CHUNK (4u << 20)
+#define KNZ_ANS1_LR 11
+#define KNZ_ANS1_SCALE 2048
+#define KNZ_ANS1_CTXHDR_BYTES 448                     // 3454 bits worst case per context header
+#define KNZ_ANS1_U0_CAP (256 * KNZ_ANS1_CTXHDR_BYTES + 64)
+#define KNZ_ANS1_U1_OFF KNZ_ANS1_U0_CAP
+#define KNZ_ANS1_PAY_OFF (KNZ_ANS1_U0_CAP + 64)
+#define KNZ_ANS1_PAY_CAP (((KNZ_ANS1_CHUNK / 8) * 11) + 64)   // a symbol costs at most log2(2048) = 11 bits
+#define KNZ_ANS1_SLOT (KNZ_ANS1_PAY_OFF + KNZ_ANS1_PAY_CAP + 64)
+
+struct Ans1Args {
+    const uint64_t* blk_off;       // absolute device address of each block's post-transform bytes
+    const uint32_t* blk_len;
+    uint32_t chunks_per_block;     // 4 MiB chunk slots per block
+    uint32_t nslots;
+    uint8_t* scratch;              // [nslots * KNZ_ANS1_SLOT]
+    uint32_t* unit_bits;           // [nslots * 5]
+    uint32_t* unit_src;            // [nslots * 5]
+    uint32_t* freqs;               // [nslots * 256 * 256] order-1 counts
+    uint2* tab;                    // [nslots * 65536] encoder symbol table
+    uint8_t* ctx_hdr;              // [nslots * 256 * KNZ_ANS1_CTXHDR_BYTES] per-context header bits (BE words)
+    uint32_t* ctx_bits;            // [nslots * 256]
+    int32_t* blk_status;
+};
+
+__device__ __forceinline__ bool knz_ans1_chunk(const Ans1Args& a, uint32_t slotId, uint32_t& b, uint32_t& n, const uint8_t*& src) {
+    b = slotId / a.chunks_per_block;
+    const uint32_t k = slotId % a.chunks_per_block;
+    const uint32_t postLen = a.blk_len[b];
+    if ((uint64_t)k * KNZ_ANS1_CHUNK >= postLen || postLen <= 32) return false;      // <= 32 bytes: raw (ANSRangeCodec.go:279-282)
+    n = min(KNZ_ANS1_CHUNK, postLen - k * KNZ_ANS1_CHUNK);
+    src = (const uint8_t*)a.blk_off[b] + (size_t)k * KNZ_ANS1_CHUNK;
+    return true;
+}
+
+// order-1 histogram with the quarter rule (Global.go:252-299 called per quarter, ANSRangeCodec.go:414-423)
+__global__ __launch_bounds__(256) void knz_ans1_hist_kernel(Ans1Args a) {
+    __shared__ uint32_t s_h[16][256];
+    const int tid = threadIdx.x;
+    const uint32_t slotId = blockIdx.x >> 4, grp = blockIdx.x & 15;
+    uint32_t b, n; const uint8_t* src;
+    if (!knz_ans1_chunk(a, slotId, b, n, src)) return;
+    for (int i = tid; i < 16 * 256; i += 256) (&s_h[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t quarter = n >> 2;
+    const uint32_t counted = quarter == 0 ? n : 4 * quarter;      // the (n & 3) tail is stored raw
+    for (uint32_t p = tid; p < counted; p += 256) {
+        const uint32_t sym = src[p];
+        const bool first = quarter == 0 ? (p == 0) : (p % quarter == 0);
+        const uint32_t ctx = first ? 0u : src[p - 1];
+        if ((ctx >> 4) == grp) atomicAdd(&s_h[ctx & 15][sym], 1u);
+    }
+    __syncthreads();
+    uint32_t* out = a.freqs + ((size_t)slotId * 256 + grp * 16) * 256;
+    for (int i = tid; i < 16 * 256; i += 256) out[i] = (&s_h[0][0])[i];
+}
+
+// one wave per (chunk, context)
+__global__ __launch_bounds__(64) void knz_ans1_stats_kernel(Ans1Args a) {
+    __shared__ int s_f[256];
+    __shared__ int s_alpha[256];
+    __shared__ uint32_t s_hdr[KNZ_ANS1_CTXHDR_BYTES / 4];
+    __shared__ int s_asize, s_panic;
+    __shared__ uint32_t s_bits;
+    const int lane = threadIdx.x;
+    const uint32_t slotId = blockIdx.x >> 8, ctx = blockIdx.x & 255;
+    uint32_t b, n; const uint8_t* src;
+    if (!knz_ans1_chunk(a, slotId, b, n, src)) return;
+    const uint32_t* fr = a.freqs + ((size_t)slotId * 256 + ctx) * 256;
+    uint32_t tot = 0;
+    for (int j = 0; j < 4; j++) { const uint32_t v = fr[lane * 4 + j]; s_f[lane * 4 + j] = (int)v; tot += v; }
+    tot = wave_reduce_add(tot);
+    for (int i = lane; i < KNZ_ANS1_CTXHDR_BYTES / 4; i += 64) s_hdr[i] = 0;
+    wave_sync();
+    if (lane == 0) {
+        int panic = 0;
+        s_asize = knz_normalize_freqs(s_f, 256, s_alpha, (int)tot, KNZ_ANS1_SCALE, &panic);   // updateFrequencies :185
+        s_panic = panic;
+    }
+    wave_sync();
+    const int asize = s_asize;
+    // encSymbol.reset for the 4 symbols of this lane (:446-468)
+    uint32_t f4[4], sum4 = 0;
+    for (int j = 0; j < 4; j++) { f4[j] = (uint32_t)s_f[lane * 4 + j]; sum4 += f4[j]; }
+    uint32_t cum = wave_scan_incl(sum4) - sum4;
+    uint2* tab = a.tab + ((size_t)slotId * 256 + ctx) * 256;
+    for (int j = 0; j < 4; j++) {
+        const uint32_t f = f4[j];
+        uint2 e; e.x = 0; e.y = 0;
+        if (f != 0 && asize > 0) {
+            const uint32_t frq = f < (KNZ_ANS1_SCALE - 1) ? f : (KNZ_ANS1_SCALE - 1);
+            uint32_t bias, invFreq, sh;
+            if (frq < 2) { invFreq = 0xFFFFFFFFu; sh = 0; bias = cum + (KNZ_ANS1_SCALE - 1); }
+            else {
+                uint32_t shift = 0;
+                while (frq > (1u << shift)) shift++;
+                invFreq = (uint32_t)(((((uint64_t)1) << (shift + 31)) + (uint64_t)(frq - 1)) / (uint64_t)frq);
+                sh = shift - 1;
+                bias = cum;
+            }
+            e.x = frq | (bias << 12) | (sh << 25);
+            e.y = invFreq;
+        }
+        tab[lane * 4 + j] = e;
+        cum += f;
+    }
+    if (lane == 0) {   // encodeHeader :216-270 for this context
+        KnzBitWriter bw;
+        bw.init(s_hdr);
+        if (asize == 256) { bw.put(0, 1); bw.put(0, 1); }
+        else if (asize == 0) { bw.put(0, 1); bw.put(1, 1); }
+        else {
+            bw.put(1, 1);
+            const int lastMask = s_alpha[asize - 1] >> 3;
+            bw.put((uint32_t)lastMask, 5);
+            for (int m = 0; m <= lastMask; m++) {
+                uint32_t mask = 0;
+                for (int bit = 0; bit < 8; bit++) mask |= (s_f[8 * m + bit] != 0 ? 1u : 0u) << bit;
+                bw.put(mask, 8);
+            }
+        }
+        if (asize > 1) {
+            const int chk = asize < 64 ? 6 : 8;
+            const uint32_t llr = 4;                    // smallest llr with 1<<llr > 11
+            for (int i = 1; i < asize; i += chk) {
+                int mx = s_f[s_alpha[i]] - 1;
+                const int endj = min(i + chk, asize);
+                for (int j = i + 1; j < endj; j++) { const int v = s_f[s_alpha[j]] - 1; if (v > mx) mx = v; }
+                uint32_t logMax = 0;
+                while ((1 << logMax) <= mx) logMax++;
+                bw.put(logMax, llr);
+                if (logMax == 0) continue;
+                for (int j = i; j < endj; j++) bw.put((uint32_t)(s_f[s_alpha[j]] - 1), logMax);
+            }
+        }
+        s_bits = bw.pos;
+    }
+    wave_sync();
+    if (s_panic && lane == 0) a.blk_status[b] = KNZ_ERR_PROCESS_BLOCK;
+    uint32_t* g = (uint32_t*)(a.ctx_hdr + ((size_t)slotId * 256 + ctx) * KNZ_ANS1_CTXHDR_BYTES);
+    const uint32_t hb = s_bits;
+    for (uint32_t i = lane; i < ((hb + 31) >> 5); i += 64) g[i] = knz_bswap32(s_hdr[i]);
+    if (lane == 0) a.ctx_bits[(size_t)slotId * 256 + ctx] = hb;
+}
+
+// unit 0 = (lr-8):3 then the 256 context headers back to back
+__global__ __launch_bounds__(256) void knz_ans1_merge_kernel(Ans1Args a) {
+    __shared__ uint32_t s_start[257];
+    __shared__ uint32_t s_wave[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t slotId = blockIdx.x;
+    uint32_t* ubits = a.unit_bits + (size_t)slotId * KNZ_UNITS_PER_CHUNK;
+    uint32_t* usrc = a.unit_src + (size_t)slotId * KNZ_UNITS_PER_CHUNK;
+    if (tid < KNZ_UNITS_PER_CHUNK) { ubits[tid] = 0; usrc[tid] = tid == 1 ? KNZ_ANS1_U1_OFF : (tid == 2 ? KNZ_ANS1_PAY_OFF : 0u); }
+    uint32_t b, n; const uint8_t* src;
+    uint8_t* slot = a.scratch + (size_t)slotId * KNZ_ANS1_SLOT;
+    const uint32_t bb = slotId / a.chunks_per_block, kk = slotId % a.chunks_per_block;
+    if (!knz_ans1_chunk(a, slotId, b, n, src)) {
+        // whole input <= 32 bytes: raw bytes as unit 0 of the block's first slot
+        const uint32_t postLen = a.blk_len[bb];
+        if (kk == 0 && postLen <= 32 && postLen > 0) {
+            const uint8_t* s = (const uint8_t*)a.blk_off[bb];
+            if (tid < (int)postLen) slot[tid] = s[tid];
+            if (tid == 0) ubits[0] = 8 * postLen;
+        }
+        return;
+    }
+    const uint32_t myBits = a.ctx_bits[(size_t)slotId * 256 + tid];
+    const uint32_t incl = wave_scan_incl(myBits);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t off = 3 + incl - myBits;
+    for (int w = 0; w < wave; w++) off += s_wave[w];
+    s_start[tid] = off;
+    if (tid == 255) s_start[256] = off + myBits;
+    __syncthreads();
+    const uint32_t total = s_start[256];
+    uint32_t* out = (uint32_t*)slot;
+    const uint8_t* hdrs = a.ctx_hdr + (size_t)slotId * 256 * KNZ_ANS1_CTXHDR_BYTES;
+    for (uint32_t w = tid; w < ((total + 31) >> 5); w += 256) {
+        const uint32_t wbit = w << 5;
+        uint32_t v = (w == 0) ? ((uint32_t)(KNZ_ANS1_LR - 8) << 29) : 0u;
+        // first context whose range ends after wbit
+        int lo = 0, hi = 256;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_start[mid + 1] > wbit) hi = mid; else lo = mid + 1; }
+        for (int c = lo; c < 256 && s_start[c] < wbit + 32; c++) {
+            const uint32_t nb = s_start[c + 1] - s_start[c];
+            if (nb == 0) continue;
+            v |= knz_fetch32_unit(hdrs + (size_t)c * KNZ_ANS1_CTXHDR_BYTES, 0, (int64_t)wbit - (int64_t)s_start[c], nb);
+        }
+        out[w] = knz_bswap32(v);
+    }
+    if (tid == 0) ubits[0] = total;
+}
+
+// one lane per state: lanes 4g..4g+3 own chunk g of the workgroup
+__global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a) {
+    const int lane = threadIdx.x;
+    const int c = lane & 3;
+    const uint32_t slotId = blockIdx.x * 16 + (lane >> 2);
+    uint32_t b = 0, n = 0; const uint8_t* src = nullptr;
+    bool live = slotId < a.nslots && knz_ans1_chunk(a, slotId, b, n, src);
+    if (live && a.blk_status[b] != 0) live = false;
+    const uint32_t end4 = n & ~3u;
+    const uint32_t q = end4 >> 2;
+    bool bad = false;
+    if (live && n > 1 && q == 0) { bad = true; live = false; }         // 2..3 byte chunk: Go indexes block[-1] and panics
+    const bool coded = live && n > 1;                                   // encodeChunk: `else if len(block) > 1` (:353)
+    const uint2* __restrict__ tab = a.tab + (size_t)(slotId < a.nslots ? slotId : 0) * 65536;
+    uint8_t* slot = a.scratch + (size_t)(slotId < a.nslots ? slotId : 0) * KNZ_ANS1_SLOT;
+    uint8_t* payEnd = slot + KNZ_ANS1_PAY_OFF + KNZ_ANS1_PAY_CAP;
+    const uint32_t steps = coded ? q : 0;                               // q-1 context steps + the final context-0 step
+    uint32_t maxSteps = steps;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = wave_shfl(maxSteps, lane ^ d); maxSteps = o > maxSteps ? o : maxSteps; }
+    // quarter c is coded from its last symbol down to its first: i = (c+1)*q-1 ... c*q (state 3 ends at end4-1)
+    const uint8_t* __restrict__ qbase = src + (size_t)c * q;           // symbols of my quarter: qbase[0..q)
+    uint32_t st = 1u << 15;
+    uint32_t cnt = 0;
+    const int gshift = (lane >> 2) << 2;
+    uint2 ecur[8], enext[8];
+    auto load_group = [&](uint32_t t0, uint2* e) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t t = t0 + j;
+            e[j].x = 0; e[j].y = 0;
+            if (t < steps) {
+                // step t codes symbol qbase[q-1-t] in context qbase[q-2-t] (context 0 for the quarter's first symbol)
+                const uint32_t sym = qbase[q - 1 - t];
+                const uint32_t ctx = (t + 1 < q) ? qbase[q - 2 - t] : 0u;
+                e[j] = tab[(ctx << 8) | sym];
+            }
+        }
+    };
+    load_group(0, ecur);
+    for (uint32_t t0 = 0; t0 < maxSteps; t0 += 8) {
+        load_group(t0 + 8, enext);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t t = t0 + j;
+            const bool act = t < steps;
+            const uint2 e = ecur[j];
+            const uint32_t x = (act && st >= ((e.x & 0xFFFu) << 20)) ? 1u : 0u;       // xMax = ((ANS_TOP>>11)<<16)*freq
+            const uint64_t bal = wave_ballot(x != 0);
+            const uint32_t gb = (uint32_t)(bal >> gshift) & 0xFu;
+            if (x) {
+                const uint32_t r = cnt + (uint32_t)__popc(gb & ((1u << c) - 1u));
+                uint8_t* p = payEnd - 2 * ((size_t)r + 1);
+                p[0] = (uint8_t)(st >> 8);
+                p[1] = (uint8_t)st;
+                st >>= 16;
+            }
+            cnt += (uint32_t)__popc(gb);
+            if (act) {
+                const uint32_t freq = e.x & 0xFFFu, bias = (e.x >> 12) & 0x1FFFu, sh = (e.x >> 25) & 0xFu;
+                const uint32_t qq = (uint32_t)(((uint64_t)st * e.y) >> (32 + sh));
+                st = st + bias + qq * ((uint32_t)KNZ_ANS1_SCALE - freq);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) ecur[j] = enext[j];
+    }
+    const uint32_t s1 = wave_shfl(st, (lane & ~3) + 1), s2 = wave_shfl(st, (lane & ~3) + 2), s3 = wave_shfl(st, (lane & ~3) + 3);
+    if (bad && c == 0) a.blk_status[b] = KNZ_ERR_PROCESS_BLOCK;
+    if (live && c == 0) {
+        const uint32_t tail = n & 3;
+        for (uint32_t i = 0; i < tail; i++) payEnd[i] = src[end4 + i];
+        const uint32_t nbytes = 2 * cnt + tail;
+        uint32_t w[8];
+        for (int i = 0; i < 8; i++) w[i] = 0;
+        KnzBitWriter bw;
+        bw.init(w);
+        knz_put_varint(bw, nbytes);
+        bw.put(st, 32); bw.put(s1, 32); bw.put(s2, 32); bw.put(s3, 32);
+        uint32_t* u1 = (uint32_t*)(slot + KNZ_ANS1_U1_OFF);
+        for (int i = 0; i < 8; i++) u1[i] = knz_bswap32(w[i]);
+        uint32_t* ubits = a.unit_bits + (size_t)slotId * KNZ_UNITS_PER_CHUNK;
+        uint32_t* usrc = a.unit_src + (size_t)slotId * KNZ_UNITS_PER_CHUNK;
+        ubits[1] = bw.pos;
+        ubits[2] = 8 * nbytes;
+        usrc[2] = (uint32_t)(KNZ_ANS1_PAY_OFF + KNZ_ANS1_PAY_CAP - 2 * cnt);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Decoder
+struct Ans1DecArgs {
+    const uint8_t* stream; uint64_t nbytes;
+    const uint32_t* blk_pre_len;
+    const uint8_t* blk_mode;
+    const uint64_t* chunk_bit;
+    const uint64_t* blk_out_off;   // absolute address of the block's output
+    uint32_t chunks_per_block;
+    uint32_t nslots;
+    uint32_t* dtab;                // [nslots * 256 * 2048] sym | freq<<8 | (slot-cum)<<20
+    uint32_t* info;                // [nslots * 8] {mode, st0..st3, lr}
+    uint64_t* paybit;              // [nslots]
+    int32_t* blk_status;
+};
+
+// Parses the chunk header at reader position r (decodeHeader :605-710). When freq16 != nullptr the frequencies of
+// context k are stored at freq16[k*256 + sym]; returns false on an invalid header. Used by the walker too.
+__device__ static bool knz_ans1_parse_header(KnzStreamReader& r, uint16_t* freq16, uint32_t& lrOut, int& totalAlpha) {
+    const uint32_t lr = 8 + r.read(3);
+    lrOut = lr;
+    if (lr > 16) return false;
+    uint32_t llr = 3;
+    while ((1u << llr) <= lr) llr++;
+    const uint32_t scale = 1u << lr;
+    totalAlpha = 0;
+    uint8_t alpha[256];
+    for (int k = 0; k < 256; k++) {
+        int count = 0;
+        if (r.read(1) == 0) {
+            if (r.read(1) == 1) count = 0;
+            else { count = 256; for (int i = 0; i < 256; i++) alpha[i] = (uint8_t)i; }
+        } else {
+            const uint32_t lastMask = r.read(5);
+            for (uint32_t mm = 0; mm <= lastMask; mm++) {
+                const uint32_t mask = r.read(8);
+                for (int j = 0; j < 8; j++) if ((mask >> j) & 1) alpha[count++] = (uint8_t)(8 * mm + j);
+            }
+        }
+        if (count == 0) continue;
+        uint16_t* f = freq16 ? freq16 + (size_t)k * 256 : nullptr;
+        const int chk = count < 64 ? 6 : 8;
+        uint32_t sum = 0;
+        for (int i = 1; i < count; i += chk) {
+            const uint32_t logMax = r.read(llr);
+            if ((1u << logMax) > scale) return false;
+            const int endj = min(i + chk, count);
+            for (int j = i; j < endj; j++) {
+                uint32_t fr = 1;
+                if (logMax > 0) { fr = 1 + r.read(logMax); if (fr >= scale) return false; }
+                if (f) f[alpha[j]] = (uint16_t)fr;
+                sum += fr;
+            }
+        }
+        if (scale <= sum) return false;
+        if (f) f[alpha[0]] = (uint16_t)(scale - sum);
+        totalAlpha += count;
+    }
+    return true;
+}
+
+// one workgroup per chunk: lane 0 parses the 256 context headers, then all threads fill the slot table
+__global__ __launch_bounds__(256) void knz_ans1_dec_tables_kernel(Ans1DecArgs a, uint16_t* freq16) {
+    __shared__ int s_mode;
+    __shared__ uint32_t s_lr;
+    const int tid = threadIdx.x;
+    const uint32_t slotId = blockIdx.x;
+    const uint32_t b = slotId / a.chunks_per_block, k = slotId % a.chunks_per_block;
+    uint32_t* info = a.info + (size_t)slotId * 8;
+    const uint32_t preLen = a.blk_pre_len[b];
+    if (tid == 0) info[0] = 0;
+    if (a.blk_status[b] != 0 || (uint64_t)k * KNZ_ANS1_CHUNK >= preLen) return;
+    if ((a.blk_mode[b] & 0x80) || preLen <= 32) { if (tid == 0) info[0] = 1; return; }   // raw
+    uint16_t* f16 = freq16 + (size_t)slotId * 65536;
+    for (int i = tid; i < 65536; i += 256) f16[i] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        KnzStreamReader r;
+        r.init(a.stream, a.nbytes, a.chunk_bit[slotId]);
+        uint32_t lr = 0; int total = 0;
+        int m = 3;
+        if (!knz_ans1_parse_header(r, f16, lr, total) || total == 0 || lr != KNZ_ANS1_LR) m = -1;   // encoder only produces lr 11
+        else {
+            const uint32_t sz = knz_read_varint(r);
+            if (sz >= (1u << 27)) m = -1;
+            for (int c = 0; c < 4; c++) info[1 + c] = r.read(32);
+            a.paybit[slotId] = r.tell();
+            if (r.tell() + 8ull * sz > (a.nbytes << 3) + 7) m = -1;
+        }
+        s_mode = m; s_lr = lr;
+        info[0] = (uint32_t)m; info[5] = lr;
+        if (m < 0) a.blk_status[b] = KNZ_ERR_PROCESS_BLOCK;
+    }
+    __syncthreads();
+    if (s_mode != 3) return;
+    // thread = context: cumulated frequencies and the slot table of that context
+    uint32_t* dt = a.dtab + ((size_t)slotId * 256 + tid) * KNZ_ANS1_SCALE;
+    const uint16_t* f = f16 + (size_t)tid * 256;
+    uint32_t cum = 0;
+    for (uint32_t s = 0; s < 256; s++) {
+        const uint32_t fr = f[s];
+        if (fr == 0) continue;
+        const uint32_t fclamp = fr < (KNZ_ANS1_SCALE - 1) ? fr : (KNZ_ANS1_SCALE - 1);        // decSymbol.reset :972-977
+        for (uint32_t j = 0; j < fr && cum + j < KNZ_ANS1_SCALE; j++) dt[cum + j] = s | (fclamp << 8) | (j << 20);
+        cum += fr;
+    }
+}
+
+__global__ __launch_bounds__(64) void knz_ans1_decode_kernel(Ans1DecArgs a) {
+    const int lane = threadIdx.x;
+    const int c = lane & 3;
+    const uint32_t slotId = blockIdx.x * 16 + (lane >> 2);
+    const uint64_t limit = a.nbytes << 3;
+    bool live = false;
+    uint32_t n = 0, b = 0, k = 0;
+    if (slotId < a.nslots) {
+        b = slotId / a.chunks_per_block; k = slotId % a.chunks_per_block;
+        const uint32_t preLen = a.blk_pre_len[b];
+        if (a.info[(size_t)slotId * 8] == 3 && a.blk_status[b] == 0) { live = true; n = min(KNZ_ANS1_CHUNK, preLen - k * KNZ_ANS1_CHUNK); }
+    }
+    uint8_t* dst = live ? (uint8_t*)a.blk_out_off[b] + (size_t)k * KNZ_ANS1_CHUNK : nullptr;
+    const uint32_t* __restrict__ dt = a.dtab + (size_t)(live ? slotId : 0) * 256 * KNZ_ANS1_SCALE;
+    const uint64_t paybit = live ? a.paybit[slotId] : 0;
+    uint32_t st = live ? a.info[(size_t)slotId * 8 + 1 + c] : 0;
+    const uint32_t end4 = n & ~3u;
+    const uint32_t q = end4 >> 2;
+    const uint32_t steps = live ? q : 0;
+    uint32_t maxSteps = steps;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = wave_shfl(maxSteps, lane ^ d); maxSteps = o > maxSteps ? o : maxSteps; }
+    uint8_t* qdst = dst + (size_t)c * q;
+    uint32_t ctx = 0, cnt = 0;
+    const int gshift = (lane >> 2) << 2;
+    for (uint32_t t = 0; t < maxSteps; t++) {
+        const bool act = t < steps;
+        uint32_t need = 0;
+        if (act) {
+            const uint32_t slot = st & (KNZ_ANS1_SCALE - 1);
+            const uint32_t e = dt[(ctx << KNZ_ANS1_LR) | slot];
+            const uint32_t sym = e & 0xFF;
+            qdst[t] = (uint8_t)sym;
+            st = ((e >> 8) & 0xFFF) * (st >> KNZ_ANS1_LR) + (e >> 20);          // freq*(st>>lr) + (slot - cumFreq)  (:846-858)
+            ctx = sym;
+            need = st < (1u << 15) ? 1u : 0u;
+        }
+        const uint64_t bal = wave_ballot(need != 0);
+        const uint32_t gb = (uint32_t)(bal >> gshift) & 0xFu;
+        if (need) {
+            const uint32_t r = cnt + (uint32_t)__popc(gb >> (c + 1));           // refill order st3, st2, st1, st0 (:918-949)
+            const uint32_t w = knz_fetch32(a.stream, (int64_t)(paybit + 16ull * r), (int64_t)limit) >> 16;
+            st = (st << 16) | w;
+        }
+        cnt += (uint32_t)__popc(gb);
+    }
+    if (live && c == 0) {
+        for (uint32_t i = end4; i < n; i++)
+            dst[i] = (uint8_t)(knz_fetch32(a.stream, (int64_t)(paybit + 16ull * cnt + 8ull * (i - end4)), (int64_t)limit) >> 24);
+    }
+}
+
+// raw chunks of an ANS1 block (copy blocks, <= 32 byte inputs)
+__global__ __launch_bounds__(256) void knz_ans1_raw_kernel(Ans1DecArgs a) {
+    const uint32_t slotId = blockIdx.x;
+    if (a.info[(size_t)slotId * 8] != 1) return;
+    const uint32_t b = slotId / a.chunks_per_block, k = slotId % a.chunks_per_block;
+    const uint32_t preLen = a.blk_pre_len[b];
+    const uint32_t n = min(KNZ_ANS1_CHUNK, preLen - k * KNZ_ANS1_CHUNK);
+    uint8_t* dst = (uint8_t*)a.blk_out_off[b] + (size_t)k * KNZ_ANS1_CHUNK;
+    const uint64_t cbit = a.chunk_bit[slotId];
+    for (uint32_t i = threadIdx.x * 4; i < n; i += 1024) {
+        const uint32_t w = knz_fetch32(a.stream, (int64_t)(cbit + 8ull * i), (int64_t)(a.nbytes << 3));
+        for (uint32_t j = 0; j < 4 && i + j < n; j++) dst[i + j] = (uint8_t)(w >> (24 - 8 * j));
+    }
+}

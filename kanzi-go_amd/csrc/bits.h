@@ -11,6 +11,12 @@
 #define KNZ_U0_BYTES 512             // scratch bytes reserved for unit 0
 #define KNZ_FRAG_BYTES 6160          // 4096 symbols * 12 bits = 6144 bytes, + tail 3 + pad
 #define KNZ_CHUNK_STRIDE (KNZ_U0_BYTES + 4 * KNZ_FRAG_BYTES)
+// rANS order 0 (16 KiB chunks): u0 header | u1 varint(size)+4 states | u2 renormalisation words (right aligned) + tail
+#define KNZ_ANS_CHUNK 16384           // _DEFAULT_ANS0_CHUNK_SIZE, ANSRangeCodec.go:33
+#define KNZ_ANS_U1_OFF 512
+#define KNZ_ANS_PAY_OFF 576
+#define KNZ_ANS_PAY_CAP 24704         // >= 16384 symbols * 12 bits / 8 + 16 (a symbol costs at most log2(4096) bits)
+#define KNZ_ANS_SLOT (KNZ_ANS_PAY_OFF + KNZ_ANS_PAY_CAP + 64)
 
 __device__ __forceinline__ uint32_t knz_bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
@@ -31,6 +37,22 @@ __device__ __forceinline__ uint32_t knz_fetch32(const uint8_t* base, int64_t bit
     // clear bits at or beyond nbits
     int64_t valid = nbits - bit;   // number of leading bits of v that are inside the string (if bit >= 0)
     if (valid <= 0) return 0u;
+    if (valid < 32) v &= ~(0xFFFFFFFFu >> valid);
+    return v;
+}
+
+// Same for a unit that starts at an arbitrary BYTE offset of a 4-byte aligned slot: `rel` is relative to the unit
+// start (may be negative), the unit holds nbits valid bits.
+__device__ __forceinline__ uint32_t knz_fetch32_unit(const uint8_t* slot, uint32_t unitByteOff, int64_t rel, int64_t nbits) {
+    if (rel >= nbits || rel <= -32) return 0u;
+    const int64_t abs = (int64_t)unitByteOff * 8 + rel;     // absolute bit inside the slot, may be < 0 only if rel < 0
+    const int64_t q = abs >> 5;
+    const int r = (int)(abs & 31);
+    const uint32_t w0 = q >= 0 ? knz_load_be32(slot, q) : 0u;
+    const uint32_t w1 = (q + 1) >= 0 ? knz_load_be32(slot, q + 1) : 0u;
+    uint32_t v = r ? ((w0 << r) | (w1 >> (32 - r))) : w0;
+    if (rel < 0) v &= 0xFFFFFFFFu >> (-rel);                // bits before the unit start
+    const int64_t valid = nbits - rel;                      // bits of v (from its MSB) that lie inside the unit
     if (valid < 32) v &= ~(0xFFFFFFFFu >> valid);
     return v;
 }
@@ -70,4 +92,26 @@ __device__ __forceinline__ uint32_t knz_expg_signed(int v) {
     uint32_t n = (uint32_t)(v < 0 ? -v : v) + 1u;
     uint32_t L = 31u - (uint32_t)__builtin_clz(n);
     return ((2u * L + 2u) << 9) | ((n << 1) | sign);
+}
+
+// Order-0 histogram of n bytes into 4 per-wave private LDS histograms (256 threads). Global.go:226-251.
+// Coalesced 16 B per lane when src is 16-byte aligned. Caller zeroes hist and synchronises before/after.
+__device__ __forceinline__ void knz_histogram_256t(const uint8_t* src, uint32_t n, uint32_t (*hist)[256], int tid) {
+    uint32_t* h = hist[tid >> 6];
+    const uint32_t nvec = n >> 4;
+    if ((((uintptr_t)src) & 15) == 0) {
+        const uint4* v = (const uint4*)src;
+        for (uint32_t i = tid; i < nvec; i += 256) {
+            uint4 x = v[i];
+            uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                atomicAdd(&h[w[j] & 255], 1u); atomicAdd(&h[(w[j] >> 8) & 255], 1u);
+                atomicAdd(&h[(w[j] >> 16) & 255], 1u); atomicAdd(&h[w[j] >> 24], 1u);
+            }
+        }
+        for (uint32_t i = (nvec << 4) + tid; i < n; i += 256) atomicAdd(&h[src[i]], 1u);
+    } else {
+        for (uint32_t i = tid; i < n; i += 256) atomicAdd(&h[src[i]], 1u);
+    }
 }

@@ -51,6 +51,8 @@ __device__ __forceinline__ uint32_t knz_read_varint(KnzStreamReader& r) {
     return res | ((v & 0x0F) << 28);
 }
 
+__device__ static bool knz_ans1_parse_header(KnzStreamReader& r, uint16_t* freq16, uint32_t& lrOut, int& totalAlpha);
+
 struct WalkStreamArgs {
     const uint8_t* stream; uint64_t nbytes;
     uint64_t first_bit;          // first block's framing
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs 
     uint64_t ck = 0;
     if (!a.payload_only) {
         mode = r.read(8);
-        if (mode & 0x80) entropy = KNZ_E_NONE;
+        if (mode & 0x80) { entropy = KNZ_E_NONE; skipFlags = 0xFF; }   // copy block: no transform runs (device convention)
         else if (mode & 0x10) skipFlags = r.read(8);
         else skipFlags = ((mode << 4) | 0x0F) & 0xFF;
         const uint32_t dataSize = 1 + ((mode >> 5) & 3);
@@ -156,13 +158,45 @@ __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs 
     const uint64_t limit = start + (((a.blk_bits[b] + 7) >> 3) << 3);
     const uint32_t cpb = a.chunks_per_block;
     if (status == 0) {
-        const uint32_t nchunks = (preLen + KNZ_HUF_CHUNK - 1) / KNZ_HUF_CHUNK;
+        const uint32_t chunkSize = entropy == KNZ_E_ANS1 ? (4u << 20) : (uint32_t)KNZ_HUF_CHUNK;
+        const uint32_t nchunks = (preLen + chunkSize - 1) / chunkSize;
         if (nchunks > cpb) status = KNZ_ERR_BLOCK_SIZE;
         for (uint32_t k = 0; k < nchunks && status == 0; k++) {
-            const uint32_t sz = min((uint32_t)KNZ_HUF_CHUNK, preLen - k * KNZ_HUF_CHUNK);
+            const uint32_t sz = min(chunkSize, preLen - k * chunkSize);
             a.chunk_bit[(size_t)b * cpb + k] = r.tell();
-            if (entropy == KNZ_E_NONE || sz < 32) {                    // raw bytes (HuffmanCodec.go:769-771)
-                r.seek(r.tell() + 8ull * sz);
+            if (entropy == KNZ_E_NONE || (entropy == KNZ_E_HUFFMAN && sz < 32) || ((entropy == KNZ_E_ANS0 || entropy == KNZ_E_ANS1) && preLen <= 32)) {
+                r.seek(r.tell() + 8ull * sz);                          // raw bytes (HuffmanCodec.go:769-771, ANSRangeCodec.go:720-723)
+            } else if (entropy == KNZ_E_ANS1) {
+                uint32_t lr; int total;
+                if (!knz_ans1_parse_header(r, nullptr, lr, total) || total == 0) { status = KNZ_ERR_PROCESS_BLOCK; break; }
+                const uint32_t szb = knz_read_varint(r);
+                if (szb >= (1u << 27)) status = KNZ_ERR_PROCESS_BLOCK;
+                r.seek(r.tell() + 128 + 8ull * szb);
+            } else if (entropy == KNZ_E_ANS0) {
+                // decodeHeader (ANSRangeCodec.go:605-710) far enough to find the end of the chunk
+                const uint32_t lr = 8 + r.read(3);
+                uint32_t llr = 3;
+                while ((1u << llr) <= lr) llr++;
+                uint32_t count;
+                if (r.read(1) == 0) count = r.read(1) == 1 ? 0 : 256;
+                else {
+                    uint32_t lastMask = r.read(5);
+                    count = 0;
+                    for (uint32_t m = 0; m <= lastMask; m++) count += (uint32_t)__popc(r.read(8));
+                }
+                if (count == 0) { status = KNZ_ERR_PROCESS_BLOCK; break; }
+                const uint32_t chk = count < 64 ? 6 : 8;
+                for (uint32_t i = 1; i < count; i += chk) {
+                    const uint32_t logMax = r.read(llr);
+                    const uint32_t endj = min(i + chk, count);
+                    if (logMax > 16) { status = KNZ_ERR_PROCESS_BLOCK; break; }
+                    r.seek(r.tell() + (uint64_t)(endj - i) * logMax);
+                }
+                if (count > 1 && status == 0) {
+                    const uint32_t szb = knz_read_varint(r);
+                    if (szb >= (1u << 27)) status = KNZ_ERR_PROCESS_BLOCK;
+                    r.seek(r.tell() + 128 + 8ull * szb);
+                }
             } else {
                 // alphabet (EntropyUtils.go:71-119)
                 uint32_t count;
@@ -345,6 +379,8 @@ __global__ __launch_bounds__(256) void knz_raw_units_kernel(HufEncArgs a) {
     const uint32_t b = blockIdx.x / cpb, k = blockIdx.x % cpb;
     const uint32_t postLen = a.blk_len[b];
     uint32_t* ubits = a.unit_bits + (size_t)blockIdx.x * KNZ_UNITS_PER_CHUNK;
+    if (tid < KNZ_UNITS_PER_CHUNK)
+        a.unit_src[(size_t)blockIdx.x * KNZ_UNITS_PER_CHUNK + tid] = tid == 0 ? 0u : (uint32_t)(KNZ_U0_BYTES + (tid - 1) * KNZ_FRAG_BYTES);
     if ((uint64_t)k * KNZ_HUF_CHUNK >= postLen) { if (tid < KNZ_UNITS_PER_CHUNK) ubits[tid] = 0; return; }
     const uint32_t n = min((uint32_t)KNZ_HUF_CHUNK, postLen - k * KNZ_HUF_CHUNK);
     const uint8_t* src = a.data + a.blk_off[b] + (size_t)k * KNZ_HUF_CHUNK;

@@ -178,6 +178,7 @@ struct HufEncArgs {
     uint32_t chunks_per_block;    // CPB: chunk slots reserved per block
     uint8_t* scratch;             // [(nblocks*CPB) * KNZ_CHUNK_STRIDE]
     uint32_t* unit_bits;          // [(nblocks*CPB) * 5]
+    uint32_t* unit_src;           // [(nblocks*CPB) * 5] byte offset of each unit inside its scratch slot
     int32_t* blk_status;          // [nblocks] set to ERR_PROCESS_BLOCK (13) where the Go code would panic
 };
 
@@ -201,6 +202,8 @@ __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
     const uint32_t b = blockIdx.x / cpb, k = blockIdx.x % cpb;
     const uint32_t postLen = a.blk_len[b];
     uint32_t* ubits = a.unit_bits + (size_t)blockIdx.x * KNZ_UNITS_PER_CHUNK;
+    if (tid < KNZ_UNITS_PER_CHUNK)
+        a.unit_src[(size_t)blockIdx.x * KNZ_UNITS_PER_CHUNK + tid] = tid == 0 ? 0u : (uint32_t)(KNZ_U0_BYTES + (tid - 1) * KNZ_FRAG_BYTES);
     if ((uint64_t)k * KNZ_HUF_CHUNK >= postLen) {
         if (tid < KNZ_UNITS_PER_CHUNK) ubits[tid] = 0;
         return;
@@ -225,26 +228,7 @@ __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
     }
 
     // ---- histogram (Global.go:226-251): coalesced 16 B per lane, per-wave private counters --------------------
-    {
-        uint32_t* h = s_hist[wave];
-        const uint32_t nvec = n >> 4;
-        const bool aligned = (((uintptr_t)src) & 15) == 0;
-        if (aligned) {
-            const uint4* v = (const uint4*)src;
-            for (uint32_t i = tid; i < nvec; i += 256) {
-                uint4 x = v[i];
-                uint32_t w[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    atomicAdd(&h[w[j] & 255], 1u); atomicAdd(&h[(w[j] >> 8) & 255], 1u);
-                    atomicAdd(&h[(w[j] >> 16) & 255], 1u); atomicAdd(&h[w[j] >> 24], 1u);
-                }
-            }
-            for (uint32_t i = (nvec << 4) + tid; i < n; i += 256) atomicAdd(&h[src[i]], 1u);
-        } else {
-            for (uint32_t i = tid; i < n; i += 256) atomicAdd(&h[src[i]], 1u);
-        }
-    }
+    knz_histogram_256t(src, n, s_hist, tid);
     __syncthreads();
     const uint32_t myFreq = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
     s_freq[tid] = myFreq;

@@ -3,6 +3,11 @@
 #include "knz_internal.h"
 #include "huffman_enc.hip"
 #include "huffman_dec.hip"
+#include "ans0.hip"
+#include "ans1.hip"
+#include "transforms.hip"
+#include "bwt.hip"
+#include "prims.h"
 #include "layout.hip"
 #include <algorithm>
 #include <cstdio>
@@ -73,8 +78,14 @@ uint32_t knz_build_stream_header(const knz_cfg& cfg, int64_t inputSize, uint32_t
 }
 
 // ---- capability table ----------------------------------------------------------------------------------------------
-static bool transform_on_device(uint64_t t) { return t == 0; }   // packed sequence: only NONE so far
-static bool entropy_on_device(uint32_t e) { return e == KNZ_E_HUFFMAN || e == KNZ_E_NONE; }
+static bool transform_on_device(uint64_t t) {                    // packed sequence
+    for (int s = 42; s >= 0; s -= 6) {
+        const uint32_t id = (uint32_t)((t >> s) & 63);
+        if (!(id == KNZ_T_NONE || id == KNZ_T_BWT || id == KNZ_T_RANK || id == KNZ_T_MTFT || id == KNZ_T_ZRLT)) return false;
+    }
+    return true;
+}
+static bool entropy_on_device(uint32_t e) { return e == KNZ_E_HUFFMAN || e == KNZ_E_NONE || e == KNZ_E_ANS0 || e == KNZ_E_ANS1; }
 
 extern "C" int knz_supports(uint64_t transform, uint32_t entropy) {
     return (transform_on_device(transform) && entropy_on_device(entropy)) ? 1 : 0;
@@ -133,7 +144,7 @@ extern "C" int knz_open(const knz_cfg* cfg, void** handle) {
 extern "C" int knz_close(void* handle) {
     Handle* h = (Handle*)handle;
     if (!h) return KNZ_OK;
-    DevBuf* bufs[] = {&h->blk_off, &h->blk_len, &h->blk_src_len, &h->blk_skip, &h->blk_cksum, &h->blk_status, &h->unit_bits,
+    DevBuf* bufs[] = {&h->blk_off, &h->blk_len, &h->blk_src_len, &h->blk_skip, &h->blk_cksum, &h->blk_status, &h->unit_bits, &h->unit_src, &h->ans_tab,
                       &h->scratch, &h->chunk_rel, &h->blk_written, &h->blk_hdr, &h->blk_dst_bit, &h->total_bits,
                       &h->stage_in, &h->stage_out, &h->dec_tables};
     for (DevBuf* b : bufs) b->release();
@@ -157,6 +168,8 @@ extern "C" int knz_last_timing(void* handle, float* stage_ms, int cap) {
     return n;
 }
 
+#include "knz_transforms.inc"
+
 // ---- encode batch ----------------------------------------------------------------------------------------------------
 // d_src: nblocks blocks, block b at b*block_size (last one shorter). Output either the framed .knz body/stream
 // (framed=1) or per-block local streams at out_stride bytes (framed=0).
@@ -179,47 +192,88 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     }
     const uint64_t bs = cfg.block_size;
     const uint32_t nblocks = (uint32_t)((eb.n + bs - 1) / bs);
-    const uint32_t chunkSize = KNZ_HUF_CHUNK;
+    const uint32_t chunkSize = cfg.entropy == KNZ_E_ANS1 ? KNZ_ANS1_CHUNK : KNZ_HUF_CHUNK;
     const uint32_t maxPost = knz_max_encoded_len(cfg.transform, (uint32_t)std::min<uint64_t>(bs, eb.n ? eb.n : 1));
     const uint32_t cpb = std::max<uint32_t>(1, (maxPost + chunkSize - 1) / chunkSize);
     const size_t nslots = (size_t)std::max<uint32_t>(nblocks, 1) * cpb;
+    const uint32_t slotStride = cfg.entropy == KNZ_E_ANS0 ? KNZ_ANS_SLOT : (cfg.entropy == KNZ_E_ANS1 ? KNZ_ANS1_SLOT : KNZ_CHUNK_STRIDE);
 
     if (h->blk_off.reserve(sizeof(uint64_t) * (nblocks + 1)) || h->blk_len.reserve(4 * (nblocks + 1)) ||
         h->blk_src_len.reserve(4 * (nblocks + 1)) || h->blk_skip.reserve(nblocks + 16) || h->blk_cksum.reserve(8 * (nblocks + 1)) ||
-        h->blk_status.reserve(4 * (nblocks + 1)) || h->unit_bits.reserve(4 * nslots * KNZ_UNITS_PER_CHUNK) ||
-        h->scratch.reserve(nslots * KNZ_CHUNK_STRIDE + 64) || h->chunk_rel.reserve(8 * nslots) ||
+        h->blk_status.reserve(4 * (nblocks + 1)) || h->unit_bits.reserve(4 * nslots * KNZ_UNITS_PER_CHUNK) || h->unit_src.reserve(4 * nslots * KNZ_UNITS_PER_CHUNK) ||
+        h->scratch.reserve(nslots * (size_t)slotStride + 64) || h->ans_tab.reserve(cfg.entropy == KNZ_E_ANS0 ? nslots * 2048 + nslots * 4 : 16) || h->chunk_rel.reserve(8 * nslots) ||
         h->blk_written.reserve(8 * (nblocks + 1)) || h->blk_hdr.reserve(4 * 6 * (nblocks + 1)) ||
         h->blk_dst_bit.reserve(8 * (nblocks + 1)) || h->total_bits.reserve(64))
         return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
 
-    // block tables (transform NONE: post-transform data is the input itself; skip flags 0x7F = slot 0 applied)
+    // block tables: absolute device addresses; blocks <= 15 bytes are copy blocks (CompressedStream.go:773-776)
+    XfBatch xb;
     {
         std::vector<uint64_t> off(nblocks);
         std::vector<uint32_t> len(nblocks);
-        std::vector<uint8_t> skip(nblocks, 0x7F);
-        for (uint32_t b = 0; b < nblocks; b++) { off[b] = (uint64_t)b * bs; len[b] = (uint32_t)std::min<uint64_t>(bs, eb.n - off[b]); }
+        std::vector<uint8_t> skip(nblocks), active(nblocks), side(nblocks, 0);
+        const bool noneOnly = cfg.transform == 0;
+        for (uint32_t b = 0; b < nblocks; b++) {
+            off[b] = (uint64_t)eb.d_src + (uint64_t)b * bs;
+            len[b] = (uint32_t)std::min<uint64_t>(bs, eb.n - (uint64_t)b * bs);
+            const bool copy = len[b] <= 15 && !eb.payload_only;
+            active[b] = (copy || noneOnly) ? 0 : 1;
+            skip[b] = (copy || noneOnly) ? 0x7F : 0xFF;       // NullTransform always applies: slot 0 cleared
+        }
         if (nblocks) {
-            HIP_OK(hipMemcpyAsync(h->blk_off.p, off.data(), 8 * nblocks, hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemcpyAsync(h->blk_len.p, len.data(), 4 * nblocks, hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemcpyAsync(h->blk_src_len.p, len.data(), 4 * nblocks, hipMemcpyHostToDevice, st));
+            const uint64_t stride = ((uint64_t)maxPost + 64 + 15) & ~(uint64_t)15;
+            if (!noneOnly && xf_alloc(h, xb, nblocks, stride)) return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
+            HIP_OK(hipMemcpyAsync(h->blk_off.p, off.data(), 8 * (size_t)nblocks, hipMemcpyHostToDevice, st));
+            HIP_OK(hipMemcpyAsync(h->blk_len.p, len.data(), 4 * (size_t)nblocks, hipMemcpyHostToDevice, st));
+            HIP_OK(hipMemcpyAsync(h->blk_src_len.p, len.data(), 4 * (size_t)nblocks, hipMemcpyHostToDevice, st));
             HIP_OK(hipMemcpyAsync(h->blk_skip.p, skip.data(), nblocks, hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemsetAsync(h->blk_status.p, 0, 4 * nblocks, st));
+            if (!noneOnly) {
+                HIP_OK(hipMemcpyAsync(xb.active, active.data(), nblocks, hipMemcpyHostToDevice, st));
+                HIP_OK(hipMemcpyAsync(xb.side, side.data(), nblocks, hipMemcpyHostToDevice, st));
+            }
+            HIP_OK(hipMemsetAsync(h->blk_status.p, 0, 4 * (size_t)nblocks, st));
             HIP_OK(hipStreamSynchronize(st)); // the host vectors go out of scope
         }
     }
     hipEventRecord(h->ev[0], st);
-    // (transform stage: nothing for NONE)
+    if (nblocks && cfg.transform != 0) {
+        xb.cur_ptr = h->blk_off.as<uint64_t>(); xb.cur_len = h->blk_len.as<uint32_t>(); xb.skip = h->blk_skip.as<uint8_t>();
+        xb.blk_status = h->blk_status.as<int32_t>();
+        int rc = forward_sequence(h, xb, cfg.transform, st);
+        if (rc) return rc;
+    }
     hipEventRecord(h->ev[1], st);
     if (nblocks) {
         if (cfg.entropy == KNZ_E_HUFFMAN || cfg.entropy == KNZ_E_NONE) {
-            // NONE entropy is only reachable here through blocks <= 15 bytes, which the Huffman kernel emits raw too;
-            // a real -e NONE stream goes through knz_raw_units_kernel
             HufEncArgs a;
-            a.data = eb.d_src; a.blk_off = h->blk_off.as<uint64_t>(); a.blk_len = h->blk_len.as<uint32_t>();
-            a.chunks_per_block = cpb; a.scratch = h->scratch.as<uint8_t>(); a.unit_bits = h->unit_bits.as<uint32_t>();
+            a.data = nullptr; a.blk_off = h->blk_off.as<uint64_t>(); a.blk_len = h->blk_len.as<uint32_t>();
+            a.chunks_per_block = cpb; a.scratch = h->scratch.as<uint8_t>(); a.unit_bits = h->unit_bits.as<uint32_t>(); a.unit_src = h->unit_src.as<uint32_t>();
             a.blk_status = h->blk_status.as<int32_t>();
             if (cfg.entropy == KNZ_E_HUFFMAN) hipLaunchKernelGGL(knz_huf_encode_kernel, dim3(nblocks * cpb), dim3(256), 0, st, a);
             else hipLaunchKernelGGL(knz_raw_units_kernel, dim3(nblocks * cpb), dim3(256), 0, st, a);
+        } else if (cfg.entropy == KNZ_E_ANS1) {
+            const uint32_t ns = nblocks * cpb;
+            if (h->a1_freqs.reserve((size_t)ns * 65536 * 4) || h->a1_tab.reserve((size_t)ns * 65536 * 8) ||
+                h->a1_ctxhdr.reserve((size_t)ns * 256 * KNZ_ANS1_CTXHDR_BYTES + 64) || h->a1_ctxbits.reserve((size_t)ns * 256 * 4))
+                return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
+            Ans1Args a;
+            a.blk_off = h->blk_off.as<uint64_t>(); a.blk_len = h->blk_len.as<uint32_t>(); a.chunks_per_block = cpb; a.nslots = ns;
+            a.scratch = h->scratch.as<uint8_t>(); a.unit_bits = h->unit_bits.as<uint32_t>(); a.unit_src = h->unit_src.as<uint32_t>();
+            a.freqs = h->a1_freqs.as<uint32_t>(); a.tab = h->a1_tab.as<uint2>(); a.ctx_hdr = h->a1_ctxhdr.as<uint8_t>();
+            a.ctx_bits = h->a1_ctxbits.as<uint32_t>(); a.blk_status = h->blk_status.as<int32_t>();
+            hipLaunchKernelGGL(knz_ans1_hist_kernel, dim3(ns * 16), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(knz_ans1_stats_kernel, dim3(ns * 256), dim3(64), 0, st, a);
+            hipLaunchKernelGGL(knz_ans1_merge_kernel, dim3(ns), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(knz_ans1_encode_kernel, dim3((ns + 15) / 16), dim3(64), 0, st, a);
+        } else if (cfg.entropy == KNZ_E_ANS0) {
+            Ans0Args a;
+            a.data = nullptr; a.blk_off = h->blk_off.as<uint64_t>(); a.blk_len = h->blk_len.as<uint32_t>();
+            a.chunks_per_block = cpb; a.scratch = h->scratch.as<uint8_t>(); a.unit_bits = h->unit_bits.as<uint32_t>(); a.unit_src = h->unit_src.as<uint32_t>();
+            a.tab = h->ans_tab.as<uint2>(); a.chunk_info = (uint32_t*)(h->ans_tab.as<uint8_t>() + nslots * 2048);
+            a.blk_status = h->blk_status.as<int32_t>();
+            const uint32_t ns = nblocks * cpb;
+            hipLaunchKernelGGL(knz_ans0_stats_kernel, dim3(ns), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(knz_ans0_encode_kernel, dim3((ns + KNZ_ANS0_CHUNKS_PER_WG - 1) / KNZ_ANS0_CHUNKS_PER_WG), dim3(128), 0, st, a, ns);
         }
     }
     hipEventRecord(h->ev[2], st);
@@ -248,12 +302,11 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
 
     GatherArgs ga;
     ga.chunks_per_block = cpb; ga.chunk_size = chunkSize; ga.blk_len = h->blk_len.as<uint32_t>(); ga.unit_bits = h->unit_bits.as<uint32_t>();
-    ga.scratch = h->scratch.as<uint8_t>(); ga.chunk_stride = KNZ_CHUNK_STRIDE;
-    ga.unit_off[0] = 0;
-    for (int j = 0; j < 4; j++) ga.unit_off[1 + j] = KNZ_U0_BYTES + j * KNZ_FRAG_BYTES;
+    ga.scratch = h->scratch.as<uint8_t>(); ga.chunk_stride = slotStride;
+    ga.unit_src = h->unit_src.as<uint32_t>();
     ga.chunk_rel = h->chunk_rel.as<uint64_t>(); ga.blk_dst_bit = h->blk_dst_bit.as<uint64_t>(); ga.dst_words = (uint32_t*)eb.d_dst;
     ga.total_bits = h->total_bits.as<uint64_t>();
-    if (nblocks) hipLaunchKernelGGL(knz_gather_kernel, dim3(nblocks * cpb), dim3(256), 0, st, ga);
+    if (nblocks) hipLaunchKernelGGL(knz_gather_kernel, dim3(nblocks * cpb, cfg.entropy == KNZ_E_ANS1 ? 64 : 1), dim3(256), 0, st, ga);
     hipEventRecord(h->ev[4], st);
     h->ev_valid = true;
 

@@ -219,7 +219,7 @@ struct GatherArgs {
     const uint32_t* unit_bits;
     const uint8_t* scratch;
     uint32_t chunk_stride;          // bytes per chunk slot
-    uint32_t unit_off[KNZ_UNITS_PER_CHUNK]; // byte offset of each unit inside a slot
+    const uint32_t* unit_src;       // [slots*5] byte offset of each unit inside its slot
     const uint64_t* chunk_rel;
     const uint64_t* blk_dst_bit;
     uint32_t* dst_words;
@@ -236,6 +236,10 @@ __global__ __launch_bounds__(256) void knz_gather_kernel(GatherArgs a) {
     if ((uint64_t)k * a.chunk_size >= a.blk_len[b]) return;
     const uint32_t* ub = a.unit_bits + (size_t)blockIdx.x * KNZ_UNITS_PER_CHUNK;
     const uint8_t* slot = a.scratch + (size_t)blockIdx.x * a.chunk_stride;
+    const uint32_t* usrc = a.unit_src + (size_t)blockIdx.x * KNZ_UNITS_PER_CHUNK;
+    uint32_t uoff[KNZ_UNITS_PER_CHUNK];
+#pragma unroll
+    for (int j = 0; j < KNZ_UNITS_PER_CHUNK; j++) uoff[j] = usrc[j];
     uint64_t ustart[KNZ_UNITS_PER_CHUNK + 1];
     ustart[0] = a.blk_dst_bit[b] + a.chunk_rel[blockIdx.x];
 #pragma unroll
@@ -243,14 +247,17 @@ __global__ __launch_bounds__(256) void knz_gather_kernel(GatherArgs a) {
     const uint64_t p0 = ustart[0], p1 = ustart[KNZ_UNITS_PER_CHUNK];
     if (p1 == p0) return;
     const uint64_t w0 = p0 >> 5, w1 = (p1 - 1) >> 5;
-    for (uint64_t w = w0 + tid; w <= w1; w += 256) {
+    // large chunks (rANS order 1: up to 5.8 MB) are split over gridDim.y workgroups
+    const uint64_t span = (w1 - w0 + gridDim.y) / gridDim.y;
+    const uint64_t wa = w0 + (uint64_t)blockIdx.y * span, wb = min(w1, wa + span - 1);
+    for (uint64_t w = wa + tid; w <= wb; w += 256) {
         const int64_t wbit = (int64_t)(w << 5);
         uint32_t v = 0;
 #pragma unroll
         for (int j = 0; j < KNZ_UNITS_PER_CHUNK; j++) {
             const int64_t us = (int64_t)ustart[j], ue = (int64_t)ustart[j + 1];
             if (ue <= wbit || us >= wbit + 32 || ue == us) continue;
-            v |= knz_fetch32(slot + a.unit_off[j], wbit - us, ue - us);
+            v |= knz_fetch32_unit(slot, uoff[j], wbit - us, ue - us);
         }
         const uint32_t sw = knz_bswap32(v);
         if (w == w0 || w == w1) atomicOr(&a.dst_words[w], sw);

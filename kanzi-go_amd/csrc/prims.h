@@ -1,0 +1,74 @@
+// Device-wide sort / scan / select primitives used by the suffix sort and the inverse BWT.
+// On the GPU these are rocPRIM's (ROCm's device-wide primitives library, header-only, compiled by hipcc for gfx950);
+// everything BWT-specific around them is hand-written in bwt.hip. Under the execution-model emulator (tests/emu,
+// CPU container, test infrastructure only) the same entry points are served by plain loops over host memory.
+#pragma once
+#include "knz_internal.h"
+
+#ifndef KNZ_HIP_EMU
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+static inline int knz_sort_pairs_u64(DevBuf& tmp, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
+                                     unsigned b0, unsigned b1, hipStream_t st) {
+    if (n == 0) return 0;
+    size_t bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, b0, b1, st) != hipSuccess) return -1;
+    if (tmp.reserve(bytes + 256)) return -1;
+    return rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, b0, b1, st) == hipSuccess ? 0 : -1;
+}
+static inline int knz_sort_pairs_u32(DevBuf& tmp, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
+                                     unsigned b0, unsigned b1, hipStream_t st) {
+    if (n == 0) return 0;
+    size_t bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, b0, b1, st) != hipSuccess) return -1;
+    if (tmp.reserve(bytes + 256)) return -1;
+    return rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, b0, b1, st) == hipSuccess ? 0 : -1;
+}
+static inline int knz_scan_max_u32(DevBuf& tmp, uint32_t* in, uint32_t* out, size_t n, hipStream_t st) {
+    if (n == 0) return 0;
+    size_t bytes = 0;
+    if (rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::maximum<uint32_t>(), st) != hipSuccess) return -1;
+    if (tmp.reserve(bytes + 256)) return -1;
+    return rocprim::inclusive_scan(tmp.p, bytes, in, out, n, rocprim::maximum<uint32_t>(), st) == hipSuccess ? 0 : -1;
+}
+// out_idx[k] = k-th index i in [0,n) with flags[i] != 0 ; *d_count = number selected
+static inline int knz_select_flagged(DevBuf& tmp, const uint8_t* flags, uint32_t* out_idx, uint32_t* d_count, size_t n, hipStream_t st) {
+    if (n == 0) return 0;
+    size_t bytes = 0;
+    rocprim::counting_iterator<uint32_t> it(0);
+    if (rocprim::select(nullptr, bytes, it, flags, out_idx, d_count, n, st) != hipSuccess) return -1;
+    if (tmp.reserve(bytes + 256)) return -1;
+    return rocprim::select(tmp.p, bytes, it, flags, out_idx, d_count, n, st) == hipSuccess ? 0 : -1;
+}
+#else
+#include <algorithm>
+#include <numeric>
+#include <vector>
+template <typename K>
+static inline int knz_sort_pairs_emu(K* kin, K* kout, uint32_t* vin, uint32_t* vout, size_t n, unsigned b0, unsigned b1) {
+    std::vector<size_t> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    const K mask = (b1 - b0) >= sizeof(K) * 8 ? ~(K)0 : ((((K)1) << (b1 - b0)) - 1);
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return ((kin[x] >> b0) & mask) < ((kin[y] >> b0) & mask); });
+    for (size_t i = 0; i < n; i++) { kout[i] = kin[idx[i]]; vout[i] = vin[idx[i]]; }
+    return 0;
+}
+static inline int knz_sort_pairs_u64(DevBuf&, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n, unsigned b0, unsigned b1, hipStream_t) {
+    return knz_sort_pairs_emu(kin, kout, vin, vout, n, b0, b1);
+}
+static inline int knz_sort_pairs_u32(DevBuf&, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout, size_t n, unsigned b0, unsigned b1, hipStream_t) {
+    return knz_sort_pairs_emu(kin, kout, vin, vout, n, b0, b1);
+}
+static inline int knz_scan_max_u32(DevBuf&, uint32_t* in, uint32_t* out, size_t n, hipStream_t) {
+    uint32_t m = 0;
+    for (size_t i = 0; i < n; i++) { m = in[i] > m ? in[i] : m; out[i] = m; }
+    return 0;
+}
+static inline int knz_select_flagged(DevBuf&, const uint8_t* flags, uint32_t* out_idx, uint32_t* d_count, size_t n, hipStream_t) {
+    uint32_t c = 0;
+    for (size_t i = 0; i < n; i++) if (flags[i]) out_idx[c++] = (uint32_t)i;
+    *d_count = c;
+    return 0;
+}
+#endif

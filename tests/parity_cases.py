@@ -130,7 +130,7 @@ def check_stream(be, transform, entropy, block_size, n, seed=3):
     data = corpus(n, seed)
     c = K.Codec(transform, entropy, block_size, lib=be.lib)
     src, ksrc = be.to_dev(data)
-    cap = n + n // 2 + 65536
+    cap = 2 * n + 262144 * (n // block_size + 2)
     dst, kdst = be.empty(cap)
     nb = c.dev_compress(src, n, dst, cap)
     got = be.to_host(kdst, nb)
@@ -192,4 +192,60 @@ def check_assemble(be, entropy, block_size, n, ranks):
     out, kout = be.empty(cap)
     total = c.dev_assemble(n, segs, bits, out, cap)
     assert be.to_host(kout, total) == O.compress(data, "NONE", entropy, block_size)
+    c.close()
+
+
+def transform_inputs(zrlt=False):
+    rng = np.random.default_rng(1234)
+    yield "A", b"A"
+    yield "AA", b"AA"
+    yield "AB", b"AB"
+    yield "all256", bytes(range(256))
+    yield "seq", bytes([0, 1, 2, 2, 2, 2, 7, 9, 9, 16, 16, 16, 1] + [3] * 19)
+    a = bytearray([8]) * 80000
+    a[0] = 1
+    yield "eights80k", bytes(a)
+    yield "short", bytes([0, 0, 1, 1, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3])
+    r = 5 if zrlt else 100
+    for i in range(3, 6):
+        v = rng.integers(0, r, 1 << (i + 6))
+        v[v >= 33] = 0
+        yield f"zeros{i}", v.astype(np.uint8).tobytes()
+    for k in range(6):
+        out = bytearray(20)
+        while len(out) < 1024:
+            ln = int(rng.integers(0, 120))
+            if ln % 3 == 0 or ln == 0:
+                ln = 1
+            out += bytes([int(rng.integers(0, 5 if zrlt else 256))]) * ln
+        yield f"runs{k}", bytes(out[:1024])
+    yield "mississippi", b"mississippi"
+    yield "ramp70000", bytes(i & 255 for i in range(70000))
+    yield "text", corpus(60000)
+    yield "zeros20000", bytes(20000)
+    yield "fefe", bytes([0xFE, 0xFF, 0, 0, 0xFF, 1, 0]) * 300 + bytes(900)
+    yield "rand30000", rng.integers(0, 256, 30000, dtype=np.uint8).tobytes()
+    yield "binary", (rng.integers(0, 256, 50000, dtype=np.uint8) & rng.integers(0, 256, 50000, dtype=np.uint8) & rng.integers(0, 256, 50000, dtype=np.uint8)).tobytes()
+
+
+_TID = {"BWT": 1, "ZRLT": 6, "MTFT": 7, "RANK": 8, "LZ": 3}
+
+
+def check_transform(be, tname):
+    """kanzi.ByteTransform objects through knz_transform_forward / knz_transform_inverse vs the oracle."""
+    c = K.Codec("NONE", "NONE", 1 << 20, lib=be.lib)
+    t = K.ByteTransform(c, tname)
+    tid = _TID[tname]
+    applied = 0
+    for name, data in transform_inputs(zrlt=(tname == "ZRLT")):
+        g = t.forward(data)
+        o = O.transform_forward(tid, data)
+        assert (g is None) == (o is None), (tname, name)
+        if o is None:
+            continue
+        assert g == o, (tname, name, len(g), len(o))
+        applied += 1
+        back = t.inverse(o, len(data) + max(512, len(data) >> 4))
+        assert back == data, (tname, name)
+    assert applied >= 8
     c.close()

@@ -15,7 +15,7 @@ def be():
 
 
 @pytest.mark.parametrize("sched", ["fwd", "rev"])
-@pytest.mark.parametrize("etype", ["HUFFMAN", "NONE"])
+@pytest.mark.parametrize("etype", ["HUFFMAN", "NONE", "ANS0", "ANS1"])
 def test_entropy_objects_bit_exact(be, etype, sched, monkeypatch):
     monkeypatch.setenv("KNZ_EMU_SCHED", sched)   # thread order inside a workgroup: catches missing barriers
     P.check_entropy_encode(be, etype)
@@ -25,6 +25,12 @@ def test_entropy_objects_bit_exact(be, etype, sched, monkeypatch):
     ("NONE", "HUFFMAN", 1 << 16, 300000), ("NONE", "HUFFMAN", 1 << 16, 1 << 16), ("NONE", "HUFFMAN", 1 << 16, (1 << 16) + 5),
     ("NONE", "HUFFMAN", 1024, 1000), ("NONE", "HUFFMAN", 1024, 10), ("NONE", "HUFFMAN", 1 << 20, 70000),
     ("NONE", "HUFFMAN", 4096, 4096 * 3 + 15), ("NONE", "NONE", 1 << 16, 200003), ("NONE", "HUFFMAN", 1 << 20, (1 << 20) + 17),
+    ("NONE", "ANS0", 1 << 16, 300000), ("NONE", "ANS0", 1024, 1000), ("NONE", "ANS0", 1024, 10), ("NONE", "ANS0", 1 << 16, (1 << 16) + 33),
+    ("NONE", "ANS0", 1 << 20, (1 << 20) + 17), ("NONE", "ANS0", 4096, 4096 * 2 + 3),
+    ("NONE", "ANS1", 1 << 16, 300000), ("NONE", "ANS1", 1024, 1000), ("NONE", "ANS1", 1024, 10),
+    ("BWT", "HUFFMAN", 1 << 16, 200000), ("BWT+RANK+ZRLT", "ANS0", 1 << 16, 200000), ("BWT+RANK+ZRLT", "ANS1", 1 << 16, 300000),
+    ("BWT+MTFT+ZRLT", "ANS0", 1 << 15, 100003), ("RANK", "HUFFMAN", 1 << 16, 100000), ("ZRLT", "NONE", 1 << 16, 150000),
+    ("BWT+RANK+ZRLT", "ANS1", 1024, 1000), ("BWT+RANK+ZRLT", "ANS1", 1024, 12),
 ])
 def test_stream_bit_exact(be, cfg):
     P.check_stream(be, *cfg)
@@ -39,8 +45,20 @@ def test_block_batch_hook(be):
     P.check_block_batch(be, "NONE", "HUFFMAN", 1 << 16, 3, 12345)
     P.check_block_batch(be, "NONE", "HUFFMAN", 1 << 16, 1, 9)      # copy block (<= 15 bytes)
     P.check_block_batch(be, "NONE", "NONE", 4096, 2, 4096)
+    P.check_block_batch(be, "NONE", "ANS0", 1 << 16, 3, 33)
 
 
 @pytest.mark.parametrize("ranks", [1, 2, 3, 8])
 def test_multi_gpu_assemble(be, ranks):
     P.check_assemble(be, "HUFFMAN", 1 << 16, 5 * (1 << 16) + 777, ranks)
+    P.check_assemble(be, "ANS0", 1 << 16, 3 * (1 << 16) + 5, ranks)
+
+
+@pytest.mark.parametrize("tname", ["ZRLT", "RANK", "MTFT", "BWT"])
+def test_transform_objects_bit_exact(be, tname):
+    P.check_transform(be, tname)
+
+
+def test_block_batch_hook_transforms(be):
+    P.check_block_batch(be, "BWT+RANK+ZRLT", "ANS1", 1 << 16, 3, 4321)
+    P.check_block_batch(be, "BWT+RANK+ZRLT", "ANS0", 1 << 16, 2, 9)

@@ -15,7 +15,7 @@ def be():
     return P.GpuBackend()
 
 
-@pytest.mark.parametrize("etype", ["HUFFMAN", "NONE"])
+@pytest.mark.parametrize("etype", ["HUFFMAN", "NONE", "ANS0", "ANS1"])
 def test_entropy_objects_bit_exact(be, etype):
     P.check_entropy_encode(be, etype)
 
@@ -24,6 +24,12 @@ def test_entropy_objects_bit_exact(be, etype):
     ("NONE", "HUFFMAN", 1 << 16, 300000), ("NONE", "HUFFMAN", 1 << 16, (1 << 16) + 5), ("NONE", "HUFFMAN", 1024, 1000),
     ("NONE", "HUFFMAN", 1024, 10), ("NONE", "HUFFMAN", 4096, 4096 * 3 + 15), ("NONE", "NONE", 1 << 16, 200003),
     ("NONE", "HUFFMAN", 1 << 20, 5 * (1 << 20) + 17), ("NONE", "HUFFMAN", 4 << 20, 3 * (4 << 20) + 12345),
+    ("NONE", "ANS0", 1 << 16, 300000), ("NONE", "ANS0", 1024, 1000), ("NONE", "ANS0", 1024, 10),
+    ("NONE", "ANS0", 1 << 20, 5 * (1 << 20) + 17), ("NONE", "ANS0", 4 << 20, 3 * (4 << 20) + 12345),
+    ("NONE", "ANS1", 1 << 16, 300000), ("NONE", "ANS1", 1024, 1000), ("NONE", "ANS1", 8 << 20, (8 << 20) + 12345),
+    ("BWT", "HUFFMAN", 1 << 16, 200000), ("BWT+RANK+ZRLT", "ANS0", 1 << 16, 200000), ("BWT+RANK+ZRLT", "ANS1", 1 << 16, 300000),
+    ("BWT+MTFT+ZRLT", "ANS0", 1 << 15, 100003), ("RANK", "HUFFMAN", 1 << 16, 100000), ("ZRLT", "NONE", 1 << 16, 150000),
+    ("BWT+RANK+ZRLT", "ANS1", 1024, 1000), ("BWT+RANK+ZRLT", "ANS1", 1024, 12), ("BWT+RANK+ZRLT", "ANS1", 1 << 20, 3 * (1 << 20) + 5),
 ])
 def test_stream_bit_exact(be, cfg):
     P.check_stream(be, *cfg)
@@ -33,6 +39,7 @@ def test_block_batch_hook(be):
     P.check_block_batch(be, "NONE", "HUFFMAN", 1 << 16, 3, 12345)
     P.check_block_batch(be, "NONE", "HUFFMAN", 1 << 16, 1, 9)
     P.check_block_batch(be, "NONE", "HUFFMAN", 4 << 20, 2, 1 << 20)
+    P.check_block_batch(be, "NONE", "ANS0", 1 << 20, 3, 33)
 
 
 @pytest.mark.parametrize("ranks", [1, 2, 8])
@@ -78,3 +85,40 @@ def test_stress_inputs(be):
         be_c.close()
     data = bytes(5 * (1 << 20))
     P.check_stream(be, "NONE", "HUFFMAN", 1 << 20, len(data))
+
+
+@pytest.mark.parametrize("tname", ["ZRLT", "RANK", "MTFT", "BWT"])
+def test_transform_objects_bit_exact(be, tname):
+    P.check_transform(be, tname)
+
+
+def test_block_batch_hook_transforms(be):
+    P.check_block_batch(be, "BWT+RANK+ZRLT", "ANS1", 1 << 16, 3, 4321)
+
+
+def test_config4_8m_blocks(be):
+    """BASELINE.json configs[3] block size (8 MiB): two blocks of S-silesia-shaped data, bit-exact vs the oracle (the
+    oracle's SA-IS needs a few seconds per block) and decoded back on the device; plus the BWT_test.go 8 MiB ramp
+    round trip (crosses the 4 MiB mergeTPSI/biPSIv2 switch of the reference inverse)."""
+    import bench_corpus
+    import torch
+    data = bench_corpus.s_silesia(12 << 20).tobytes()[: (8 << 20) + 3333333]
+    P_len = P.check_stream  # noqa
+    import oracle_lib as O
+    c = P.K.Codec("BWT+RANK+ZRLT", "ANS1", 8 << 20, lib=be.lib)
+    src, ks = be.to_dev(data)
+    cap = 2 * len(data) + (1 << 20)
+    dst, kd = be.empty(cap)
+    nb = c.dev_compress(src, len(data), dst, cap)
+    got = be.to_host(kd, nb)
+    exp = O.compress(data, "BWT+RANK+ZRLT", "ANS1", 8 << 20, 0, jobs=2)
+    assert got == exp
+    out, ko = be.empty(len(data) + 64)
+    assert c.dev_decompress(dst, nb, out, len(data) + 64) == len(data)
+    assert be.to_host(ko, len(data)) == data
+    ramp = bench_corpus.s_ramp(8 << 20).tobytes()
+    src, ks = be.to_dev(ramp)
+    nb = c.dev_compress(src, len(ramp), dst, cap)
+    assert c.dev_decompress(dst, nb, out, len(ramp) + 64) == len(ramp)
+    assert be.to_host(ko, len(ramp)) == ramp
+    c.close()
