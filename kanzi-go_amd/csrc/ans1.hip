@@ -21,6 +21,7 @@
 #define KNZ_ANS1_PAY_OFF (KNZ_ANS1_U0_CAP + 64)
 #define KNZ_ANS1_PAY_CAP (((KNZ_ANS1_CHUNK / 8) * 11) + 64)   // a symbol costs at most log2(2048) = 11 bits
 #define KNZ_ANS1_SLOT (KNZ_ANS1_PAY_OFF + KNZ_ANS1_PAY_CAP + 64)
+#define KNZ_ANS1_RING 1024                            // 16-bit words per chunk ring (power of two)
 
 struct Ans1Args {
     const uint64_t* blk_off;       // absolute device address of each block's post-transform bytes
@@ -246,6 +247,11 @@ __global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a) {
             }
         }
     };
+    // Renormalisation words are staged in an LDS ring per chunk and flushed in bursts: on gfx950 stores and loads share
+    // the in-order vmcnt counter, a global store inside the dependent loop would stall every following table load.
+    __shared__ uint16_t s_ring[16][KNZ_ANS1_RING];
+    uint16_t* ring = s_ring[lane >> 2];
+    uint32_t flushed = 0;                                                // words already copied to the slot
     load_group(0, ecur);
     for (uint32_t t0 = 0; t0 < maxSteps; t0 += 8) {
         load_group(t0 + 8, enext);
@@ -259,9 +265,7 @@ __global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a) {
             const uint32_t gb = (uint32_t)(bal >> gshift) & 0xFu;
             if (x) {
                 const uint32_t r = cnt + (uint32_t)__popc(gb & ((1u << c) - 1u));
-                uint8_t* p = payEnd - 2 * ((size_t)r + 1);
-                p[0] = (uint8_t)(st >> 8);
-                p[1] = (uint8_t)st;
+                ring[r & (KNZ_ANS1_RING - 1)] = (uint16_t)st;                             // word r of the descending stream
                 st >>= 16;
             }
             cnt += (uint32_t)__popc(gb);
@@ -273,6 +277,19 @@ __global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a) {
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) ecur[j] = enext[j];
+        // flush when any chunk of the wave could overflow its ring within the next group (32 words)
+        const bool last = t0 + 8 >= maxSteps;
+        if (wave_ballot(cnt - flushed > KNZ_ANS1_RING - 64) != 0 || last) {
+            wave_sync();
+            for (uint32_t r = flushed + (uint32_t)c; r < cnt; r += 4) {                   // the 4 lanes of a chunk share the copy
+                const uint16_t wv = ring[r & (KNZ_ANS1_RING - 1)];
+                uint8_t* p = payEnd - 2 * ((size_t)r + 1);
+                p[0] = (uint8_t)(wv >> 8);
+                p[1] = (uint8_t)wv;
+            }
+            flushed = cnt;
+            wave_sync();
+        }
     }
     const uint32_t s1 = wave_shfl(st, (lane & ~3) + 1), s2 = wave_shfl(st, (lane & ~3) + 2), s3 = wave_shfl(st, (lane & ~3) + 3);
     if (bad && c == 0) a.blk_status[b] = KNZ_ERR_PROCESS_BLOCK;
@@ -429,6 +446,10 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_kernel(Ans1DecArgs a) {
     uint8_t* qdst = dst + (size_t)c * q;
     uint32_t ctx = 0, cnt = 0;
     const int gshift = (lane >> 2) << 2;
+    // decoded bytes are staged per lane in LDS (row stride 132 B: conflict free) and written out every 128 steps, so that
+    // no global store sits between two dependent table loads (stores and loads share the in-order vmcnt counter)
+    __shared__ uint8_t s_obuf[64][132];
+    uint8_t* orow = s_obuf[lane];
     for (uint32_t t = 0; t < maxSteps; t++) {
         const bool act = t < steps;
         uint32_t need = 0;
@@ -436,7 +457,7 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_kernel(Ans1DecArgs a) {
             const uint32_t slot = st & (KNZ_ANS1_SCALE - 1);
             const uint32_t e = dt[(ctx << KNZ_ANS1_LR) | slot];
             const uint32_t sym = e & 0xFF;
-            qdst[t] = (uint8_t)sym;
+            orow[t & 127] = (uint8_t)sym;
             st = ((e >> 8) & 0xFFF) * (st >> KNZ_ANS1_LR) + (e >> 20);          // freq*(st>>lr) + (slot - cumFreq)  (:846-858)
             ctx = sym;
             need = st < (1u << 15) ? 1u : 0u;
@@ -449,6 +470,13 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_kernel(Ans1DecArgs a) {
             st = (st << 16) | w;
         }
         cnt += (uint32_t)__popc(gb);
+        if ((t & 127) == 127 || t + 1 == maxSteps) {
+            const uint32_t base = t & ~127u;
+            if (base < steps) {
+                const uint32_t m = min(128u, steps - base);
+                for (uint32_t i = 0; i < m; i++) qdst[base + i] = orow[i];
+            }
+        }
     }
     if (live && c == 0) {
         for (uint32_t i = end4; i < n; i++)

@@ -65,6 +65,72 @@ __device__ __forceinline__ int knz_sbrt_q(uint32_t mode, int i, int p) {
     return ((i & m1) + (p & m2)) >> s;
 }
 
+// The SBRT list (256 symbols ordered by rank) lives in REGISTERS, 4 consecutive ranks per lane: symbol, q and p of the
+// symbol at rank 4*lane+k. One list update (SBRT.go:155-172) is then a handful of wave-wide compares, ballots and a
+// one-position shift across lanes, at a cost that does not depend on how far the symbol moves (the scalar loop of the
+// reference costs two dependent LDS reads per position moved).
+struct SbrtWave {
+    uint32_t s[4];
+    int q[4], p[4];
+
+    __device__ __forceinline__ void load(const uint8_t* r2s, const int* qBySym, const int* pBySym, int lane) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t c = r2s[4 * lane + k]; s[k] = c; q[k] = qBySym[c]; p[k] = pBySym[c]; }
+    }
+    // rank of symbol c (forward direction)
+    __device__ __forceinline__ uint32_t find(uint32_t c) const {
+        uint32_t r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint64_t m = wave_ballot(s[k] == c); if (m) r = 4u * (uint32_t)(__ffsll((unsigned long long)m) - 1) + (uint32_t)k; }
+        return r;
+    }
+    // symbol at rank r (inverse direction)
+    __device__ __forceinline__ uint32_t at(uint32_t r) const {
+        const uint32_t L = r >> 2, k = r & 3;
+        const uint32_t a0 = wave_readlane(s[0], L), a1 = wave_readlane(s[1], L), a2 = wave_readlane(s[2], L), a3 = wave_readlane(s[3], L);
+        return k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : a3));
+    }
+    // access of the symbol c sitting at rank r at time i
+    __device__ __forceinline__ void update(uint32_t mode, int i, uint32_t c, uint32_t r, int lane) {
+        const uint32_t L = r >> 2, k = r & 3;
+        const int p0 = (int)wave_readlane((uint32_t)p[0], L), p1 = (int)wave_readlane((uint32_t)p[1], L);
+        const int p2 = (int)wave_readlane((uint32_t)p[2], L), p3 = (int)wave_readlane((uint32_t)p[3], L);
+        const int pc = k == 0 ? p0 : (k == 1 ? p1 : (k == 2 ? p2 : p3));
+        const int qc = knz_sbrt_q(mode, i, pc);
+        // j = 1 + highest rank x < r with q[x] > qc (the symbol stops below it, :163-168)
+        int j = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const uint32_t x = 4u * (uint32_t)lane + (uint32_t)kk;
+            const uint64_t m = wave_ballot(x < r && q[kk] > qc);
+            if (m) { const int cand = 4 * (63 - __clzll((long long)m)) + kk + 1; j = cand > j ? cand : j; }
+        }
+        if ((uint32_t)j == r) {                                   // stays in place (always the case at rank 0)
+            if ((uint32_t)lane == L) {
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) if ((uint32_t)kk == k) { q[kk] = qc; p[kk] = i; }
+            }
+            return;
+        }
+        // ranks j..r-1 move down by one, c is inserted at rank j
+        const uint32_t sPrev = wave_shfl(s[3], lane - 1);
+        const int qPrev = (int)wave_shfl((uint32_t)q[3], lane - 1);
+        const int pPrev = (int)wave_shfl((uint32_t)p[3], lane - 1);
+#pragma unroll
+        for (int kk = 3; kk >= 0; kk--) {
+            const uint32_t x = 4u * (uint32_t)lane + (uint32_t)kk;
+            const bool moved = x > (uint32_t)j && x <= r;
+            const bool ins = x == (uint32_t)j;
+            const uint32_t sFrom = kk > 0 ? s[kk > 0 ? kk - 1 : 0] : sPrev;
+            const int qFrom = kk > 0 ? q[kk > 0 ? kk - 1 : 0] : qPrev;
+            const int pFrom = kk > 0 ? p[kk > 0 ? kk - 1 : 0] : pPrev;
+            s[kk] = ins ? c : (moved ? sFrom : s[kk]);
+            q[kk] = ins ? qc : (moved ? qFrom : q[kk]);
+            p[kk] = ins ? i : (moved ? pFrom : p[kk]);
+        }
+    }
+};
+
 // 1) last two positions of every symbol inside the segment (block-local positions, -1 if none)
 __global__ __launch_bounds__(64) void knz_sbrt_seg_last2_kernel(XfArgs a) {
     __shared__ int s_last[256], s_prev[256];
@@ -106,7 +172,8 @@ __global__ __launch_bounds__(256) void knz_sbrt_carry_kernel(XfArgs a) {
 
 // 3) replay of the list update inside each segment from the reconstructed state (SBRT.go:155-172)
 __global__ __launch_bounds__(64) void knz_sbrt_apply_kernel(XfArgs a) {
-    __shared__ uint8_t s_in[KNZ_SEG], s_out[KNZ_SEG];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[KNZ_SEG];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[KNZ_SEG];
     __shared__ uint8_t s_s2r[256], s_r2s[256];
     __shared__ int s_p[256], s_q[256], s_t[256];
     const int lane = threadIdx.x;
@@ -142,23 +209,21 @@ __global__ __launch_bounds__(64) void knz_sbrt_apply_kernel(XfArgs a) {
         s_r2s[r] = (uint8_t)d;
     }
     wave_sync();
-    if (lane == 0) {
-        for (uint32_t k = 0; k < cnt; k++) {
-            const int i = (int)(lo + k);
-            const uint8_t c = s_in[k];
-            int r = s_s2r[c];
-            s_out[k] = (uint8_t)r;
-            const int qc = knz_sbrt_q(a.mode, i, s_p[c]);
-            s_p[c] = i;
-            s_q[c] = qc;
-            while (r > 0 && s_q[s_r2s[r - 1]] <= qc) {
-                const uint8_t t = s_r2s[r - 1];
-                s_r2s[r] = t; s_s2r[t] = (uint8_t)r;
-                r--;
+    SbrtWave w;
+    w.load(s_r2s, s_q, s_p, lane);
+    for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
+        const uint32_t four = *(const uint32_t*)(s_in + k0);                 // 4 symbols, uniform LDS read
+        uint32_t outw = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (k0 + u < cnt) {
+                const uint32_t c = (four >> (8 * u)) & 0xFF;
+                const uint32_t r = w.find(c);
+                outw |= r << (8 * u);
+                w.update(a.mode, (int)(lo + k0 + u), c, r, lane);
             }
-            s_r2s[r] = c;
-            s_s2r[c] = (uint8_t)r;
         }
+        if (lane == 0) *(uint32_t*)(s_out + k0) = outw;
     }
     wave_sync();
     for (uint32_t i = lane; i < cnt; i += 64) dst[lo + i] = s_out[i];
@@ -166,9 +231,8 @@ __global__ __launch_bounds__(64) void knz_sbrt_apply_kernel(XfArgs a) {
 
 // SBRT inverse: one chain per block (SBRT.go:204-223), tiles staged through LDS
 __global__ __launch_bounds__(64) void knz_sbrt_inverse_kernel(XfArgs a) {
-    __shared__ uint8_t s_in[4096], s_out[4096];
-    __shared__ uint8_t s_r2s[256];
-    __shared__ int s_p[256], s_q[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[4096];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[4096];
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (!a.active[b]) return;
@@ -177,24 +241,27 @@ __global__ __launch_bounds__(64) void knz_sbrt_inverse_kernel(XfArgs a) {
     if (n > a.out_cap) return;
     const uint8_t* src = (const uint8_t*)a.in_ptr[b];
     uint8_t* dst = (uint8_t*)a.out_ptr[b];
-    for (int d = lane; d < 256; d += 64) { s_r2s[d] = (uint8_t)d; s_p[d] = 0; s_q[d] = 0; }
+    SbrtWave w;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { w.s[k] = 4u * (uint32_t)lane + (uint32_t)k; w.q[k] = 0; w.p[k] = 0; }
     for (uint32_t base = 0; base < n; base += 4096) {
         const uint32_t cnt = min(4096u, n - base);
         wave_sync();
         for (uint32_t i = lane; i < cnt; i += 64) s_in[i] = src[base + i];
         wave_sync();
-        if (lane == 0) {
-            for (uint32_t k = 0; k < cnt; k++) {
-                const int i = (int)(base + k);
-                int r = s_in[k];
-                const uint8_t c = s_r2s[r];
-                s_out[k] = c;
-                const int qc = knz_sbrt_q(a.mode, i, s_p[c]);
-                s_p[c] = i;
-                s_q[c] = qc;
-                while (r > 0 && s_q[s_r2s[r - 1]] <= qc) { s_r2s[r] = s_r2s[r - 1]; r--; }
-                s_r2s[r] = c;
+        for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
+            const uint32_t four = *(const uint32_t*)(s_in + k0);
+            uint32_t outw = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (k0 + u < cnt) {
+                    const uint32_t r = (four >> (8 * u)) & 0xFF;
+                    const uint32_t c = w.at(r);
+                    outw |= c << (8 * u);
+                    w.update(a.mode, (int)(base + k0 + u), c, r, lane);
+                }
             }
+            if (lane == 0) *(uint32_t*)(s_out + k0) = outw;
         }
         wave_sync();
         for (uint32_t i = lane; i < cnt; i += 64) dst[base + i] = s_out[i];
@@ -342,98 +409,144 @@ __global__ __launch_bounds__(64) void knz_zrlt_offsets_kernel(XfArgs a) {
     a.ok[b] = (fits && a.out_cap >= n) ? 1 : 0;
 }
 
-// ZRLT inverse (ZRLT.go:142-225): one chain per block. Input and output are staged through LDS tiles; lane 0 runs the
-// byte automaton, all lanes refill / flush.
-__global__ __launch_bounds__(64) void knz_zrlt_inverse_kernel(XfArgs a) {
-    __shared__ uint8_t s_in[4096], s_out[4096];
-    __shared__ uint32_t s_state[8];   // 0: inPos(consumed in tile) 1: outFill 2: pendingZeros 3: runLength acc 4: phase 5: err 6: done
-    const int lane = threadIdx.x;
-    const uint32_t b = blockIdx.x;
+// ZRLT inverse (ZRLT.go:142-225), segment-parallel like the forward direction. Every input byte is classified
+// (payload of a 0xFF escape / digit of a zero run / escape / literal); a run of digit bytes d1..dL decodes to
+// ((1<<L)|d1..dL) - 1 zeros, accounted at its last digit; literals and payloads produce one byte. Output offsets come
+// from a per-segment + per-block scan, the destination is zero-filled and only non-zero bytes are scattered.
+// class: 0 literal, 1 digit, 2 escape (0xFF), 3 payload
+__device__ __forceinline__ int knz_zi_class(const uint8_t* src, uint32_t i) {
+    uint32_t c = 0;
+    while (c < i && c < 4096 && src[i - 1 - c] == 0xFF) c++;     // valid streams: 0 or 1 (an escape's payload is 0 or 1)
+    if (c & 1) return 3;
+    const uint8_t v = src[i];
+    return v <= 1 ? 1 : (v == 0xFF ? 2 : 0);
+}
+// bytes produced by the element ending at i ; lastND = index of the last non-digit byte before i (-1 if none)
+__device__ __forceinline__ uint32_t knz_zi_size(const uint8_t* src, uint32_t n, uint32_t i, int cls, int lastND, int* err) {
+    if (cls == 0 || cls == 3) return 1;
+    if (cls == 2) return 0;
+    if (i + 1 < n && knz_zi_class(src, i + 1) == 1) return 0;       // not the last digit of its run
+    const uint32_t L = (uint32_t)((int)i - lastND);
+    if (L > 31) { *err = 1; return 0; }
+    uint32_t v = 1;
+    for (uint32_t j = 0; j < L; j++) v = (v << 1) | src[i - L + 1 + j];
+    return v - 1;
+}
+
+// 1) per segment: block-local index of the last NON-digit byte (-1 if none)
+__global__ __launch_bounds__(256) void knz_zrlti_seg_lastnd_kernel(XfArgs a) {
+    __shared__ int s_max;
+    const int tid = threadIdx.x;
+    const uint32_t b = blockIdx.x / a.segs_per_block, s = blockIdx.x % a.segs_per_block;
     if (!a.active[b]) return;
-    const uint32_t srcEnd = a.in_len[b];
-    const uint32_t dstEnd = a.out_cap;
+    const uint32_t n = a.in_len[b];
+    const uint32_t lo = s * KNZ_SEG;
+    if (lo >= n) return;
+    const uint32_t hi = min(n, lo + KNZ_SEG);
+    const uint8_t* src = (const uint8_t*)a.in_ptr[b];
+    if (tid == 0) s_max = -1;
+    __syncthreads();
+    int m = -1;
+    for (uint32_t i = lo + tid; i < hi; i += 256) if (knz_zi_class(src, i) != 1) m = (int)i;
+    if (m >= 0) atomicMax(&s_max, m);
+    __syncthreads();
+    if (tid == 0) a.seg_a[blockIdx.x] = s_max;
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void knz_zrlti_seg_kernel(XfArgs a) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_carry;
+    __shared__ int s_lastnd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t b = blockIdx.x / a.segs_per_block, s = blockIdx.x % a.segs_per_block;
+    if (!a.active[b]) return;
+    if (SCATTER && a.ok[b] != 1) return;
+    const uint32_t n = a.in_len[b];
+    const uint32_t lo = s * KNZ_SEG;
+    if (lo >= n) return;
+    const uint32_t hi = min(n, lo + KNZ_SEG);
     const uint8_t* src = (const uint8_t*)a.in_ptr[b];
     uint8_t* dst = (uint8_t*)a.out_ptr[b];
-    // phases of the automaton: 0 = at element start, 1 = inside a run of digit bytes, 2 = after 0xFF escape
-    uint32_t srcBase = 0, dstBase = 0;     // uniform across lanes
-    if (lane == 0) { for (int i = 0; i < 8; i++) s_state[i] = 0; }
-    wave_sync();
-    uint32_t tileCnt = 0, inPos = 0;
-    bool needRefill = true;
-    for (;;) {
-        if (needRefill) {
-            srcBase += inPos;
-            inPos = 0;
-            tileCnt = min(4096u, srcEnd - srcBase);
-            for (uint32_t i = lane; i < tileCnt; i += 64) s_in[i] = src[srcBase + i];
-            wave_sync();
+    if (tid == 0) { s_carry = SCATTER ? (uint32_t)a.seg_b[blockIdx.x] : 0u; s_lastnd = a.seg_a[blockIdx.x]; }
+    __syncthreads();
+    int err = 0;
+    for (uint32_t base = lo; base < hi; base += 256 * 32) {
+        const uint32_t p0 = base + (uint32_t)tid * 32;
+        int myMax = -1;
+        for (uint32_t j = 0; j < 32 && p0 + j < hi; j++) if (knz_zi_class(src, p0 + j) != 1) myMax = (int)(p0 + j);
+        int m = myMax;
+        for (int d = 1; d < 64; d <<= 1) { int t = (int)wave_shfl((uint32_t)m, lane - d); if (lane >= d && t > m) m = t; }
+        __syncthreads();
+        if (lane == 63) s_wave[wave] = (uint32_t)m;
+        __syncthreads();
+        int before = s_lastnd;
+        for (int w = 0; w < wave; w++) { int t = (int)s_wave[w]; if (t > before) before = t; }
+        int exclusive = (int)wave_shfl((uint32_t)m, lane - 1);
+        if (lane == 0) exclusive = -1;
+        if (exclusive > before) before = exclusive;
+        int passMax = (int)s_wave[0];
+        for (int w = 1; w < 4; w++) if ((int)s_wave[w] > passMax) passMax = (int)s_wave[w];
+        uint32_t sz = 0;
+        int lnd = before;
+        for (uint32_t j = 0; j < 32 && p0 + j < hi; j++) {
+            const int cls = knz_zi_class(src, p0 + j);
+            sz += knz_zi_size(src, n, p0 + j, cls, lnd, &err);
+            if (cls != 1) lnd = (int)(p0 + j);
         }
-        if (lane == 0) {
-            uint32_t ip = inPos, of = 0, pend = s_state[2], run = s_state[3], phase = s_state[4], err = 0, done = 0;
-            const uint32_t outRoom = 4096;
-            for (;;) {
-                if (pend > 0) {                                  // zeros still owed by the last run
-                    while (pend > 0 && of < outRoom) { s_out[of++] = 0; pend--; }
-                    if (pend > 0) break;                         // flush needed
-                }
-                if (ip >= tileCnt) {                             // input tile exhausted
-                    if (srcBase + ip >= srcEnd) {                // end of input (ZRLT.go:171-173,206-222)
-                        if (phase == 1) {                        // the stream ends inside a run: goto End with runLength
-                            uint32_t r = run - 1;                // End: runLength-- (trailing zeros)
-                            if ((uint64_t)r > (uint64_t)dstEnd - (dstBase + of)) err = 1;
-                            else { pend = r; phase = 0; run = 0; if (pend > 0) continue; }
-                        } else if (phase == 2) {
-                            err = 0;                             // 0xFF at the very end: loop breaks with srcIdx == srcEnd
-                        }
-                        done = 1;
-                    }
-                    break;
-                }
-                const uint8_t v = s_in[ip];
-                if (phase == 2) {                                // escaped value
-                    if (dstBase + of >= dstEnd) { err = 1; done = 1; break; }
-                    if (of >= outRoom) break;
-                    s_out[of++] = (uint8_t)(0xFE + v);
-                    ip++; phase = 0;
-                    continue;
-                }
-                if (v <= 1) {                                    // digit byte of a run (:163-174)
-                    if (phase == 0) { run = 1; phase = 1; }
-                    run += run + v;
-                    ip++;
-                    continue;
-                }
-                if (phase == 1) {                                // run finished by a non-digit: emit runLength-1 zeros
-                    const uint32_t r = run - 1;
-                    if ((uint64_t)r >= (uint64_t)dstEnd - (dstBase + of)) { err = 1; done = 1; break; }   // :178-180
-                    pend = r; phase = 0; run = 0;
-                    continue;
-                }
-                if (dstBase + of >= dstEnd) { err = 1; done = 1; break; }
-                if (of >= outRoom) break;
-                if (v == 0xFF) { ip++; phase = 2; continue; }
-                s_out[of++] = (uint8_t)(v - 1);
-                ip++;
+        const uint32_t incl = wave_scan_incl(sz);
+        __syncthreads();
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t off = s_carry + incl - sz;
+        for (int w = 0; w < wave; w++) off += s_wave[w];
+        const uint32_t passTotal = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (SCATTER) {
+            lnd = before;
+            for (uint32_t j = 0; j < 32 && p0 + j < hi; j++) {
+                const uint32_t i = p0 + j;
+                const int cls = knz_zi_class(src, i);
+                const uint32_t e = knz_zi_size(src, n, i, cls, lnd, &err);
+                if (cls == 0) dst[off] = (uint8_t)(src[i] - 1);
+                else if (cls == 3) dst[off] = (uint8_t)(0xFE + src[i]);
+                off += e;
+                if (cls != 1) lnd = (int)i;
             }
-            s_state[0] = ip; s_state[1] = of; s_state[2] = pend; s_state[3] = run; s_state[4] = phase; s_state[5] = err; s_state[6] = done;
         }
-        wave_sync();
-        inPos = s_state[0];
-        const uint32_t of = s_state[1];
-        const uint32_t done = s_state[6], err = s_state[5];
-        for (uint32_t i = lane; i < of; i += 64) if (dstBase + i < dstEnd) dst[dstBase + i] = s_out[i];
-        dstBase += of;
-        wave_sync();
-        if (done || err) {
-            if (lane == 0) {
-                // an escape byte left dangling or unread input is an error (:218-220)
-                const bool leftover = (srcBase + inPos) < srcEnd;
-                a.out_len[b] = dstBase;
-                a.ok[b] = (err || leftover) ? -KNZ_ERR_PROCESS_BLOCK : 1;
-            }
-            return;
-        }
-        needRefill = inPos >= tileCnt;
+        __syncthreads();
+        if (tid == 0) { s_carry += passTotal; if (passMax > s_lastnd) s_lastnd = passMax; }
+        __syncthreads();
+    }
+    if (!SCATTER && tid == 0) a.seg_b[blockIdx.x] = (int32_t)s_carry;
+    if (!SCATTER && err) a.ok[b] = -KNZ_ERR_PROCESS_BLOCK;
+}
+
+// per block: exclusive scan of the segment sizes; the decoded size must fit the destination (ZRLT.go:178-180,211-216)
+__global__ __launch_bounds__(64) void knz_zrlti_offsets_kernel(XfArgs a) {
+    const uint32_t b = blockIdx.x;
+    if (!a.active[b] || threadIdx.x != 0) return;
+    const uint32_t n = a.in_len[b];
+    const uint32_t nseg = (n + KNZ_SEG - 1) / KNZ_SEG;
+    uint64_t off = 0;
+    for (uint32_t s = 0; s < nseg; s++) {
+        int32_t* p = a.seg_b + (size_t)b * a.segs_per_block + s;
+        const uint32_t v = (uint32_t)*p;
+        *p = (int32_t)off;
+        off += v;
+    }
+    a.out_len[b] = (uint32_t)min(off, (uint64_t)0xFFFFFFFFu);
+    if (a.ok[b] == 0) a.ok[b] = off <= a.out_cap ? 1 : -KNZ_ERR_PROCESS_BLOCK;
+}
+
+// zero fill of the decoded range (only non-zero bytes are scattered afterwards)
+__global__ __launch_bounds__(256) void knz_zrlti_zero_kernel(XfArgs a) {
+    const uint32_t b = blockIdx.y;
+    if (!a.active[b] || a.ok[b] != 1) return;
+    const uint32_t n = a.out_len[b];
+    uint8_t* dst = (uint8_t*)a.out_ptr[b];
+    for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; i < n; i += (uint64_t)gridDim.x * 256 * 16) {
+        if (i + 16 <= n && (((uintptr_t)(dst + i)) & 15) == 0) { uint4 z; z.x = z.y = z.z = z.w = 0; *(uint4*)(dst + i) = z; }
+        else for (uint64_t j = i; j < n && j < i + 16; j++) dst[j] = 0;
     }
 }
 

@@ -17,6 +17,10 @@ __device__ __forceinline__ uint64_t wave_shfl64(uint64_t v, int src) {
 }
 __device__ __forceinline__ uint64_t wave_ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ uint32_t wave_bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+// value of lane `src` (src must be wave-uniform): v_readlane_b32 into an SGPR, no LDS crossbar
+__device__ __forceinline__ uint32_t wave_readlane(uint32_t v, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)src));
+}
 // LDS written by one lane, read by another lane of the SAME wave: make the DS writes land and stop
 // the compiler from moving accesses across (waves run their DS ops in order).
 __device__ __forceinline__ void wave_sync() {
@@ -46,6 +50,7 @@ inline uint64_t wave_ballot(bool p) {
     return r;
 }
 inline uint32_t wave_bcast(uint32_t v, int src) { return wave_shfl(v, src); }
+inline uint32_t wave_readlane(uint32_t v, uint32_t src) { return wave_shfl(v, (int)src); }
 inline void wave_sync() { hipemu::wave_barrier(); }
 #endif
 

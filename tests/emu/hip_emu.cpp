@@ -8,9 +8,34 @@ dim3 blockDim, gridDim;
 
 namespace hipemu {
 static const size_t STACK = 256 * 1024;
-struct Fiber { ucontext_t ctx; char* stack = nullptr; bool done = false; unsigned tid = 0; };
+// Minimal x86-64 SysV context switch (callee-saved registers + stack pointer). glibc's swapcontext() makes a
+// sigprocmask system call per switch, which dominates kernels that use many cross-lane operations.
+extern "C" void knz_emu_switch(void** save_sp, void* new_sp);
+asm(R"(
+.text
+.globl knz_emu_switch
+.type knz_emu_switch,@function
+knz_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size knz_emu_switch,.-knz_emu_switch
+)");
+struct Fiber { void* sp = nullptr; char* stack = nullptr; bool done = false; unsigned tid = 0; };
 static std::vector<Fiber> fibers;
-static ucontext_t schedCtx;
+static void* schedSp = nullptr;
 static int cur = -1;
 static const std::function<void()>* bodyPtr = nullptr;
 static unsigned blkArrived, blkGen, blkAlive;
@@ -29,9 +54,10 @@ static void trampoline() {
     if (blkAlive && blkArrived == blkAlive) { blkArrived = 0; blkGen++; }
     unsigned w = f.tid >> 6;
     if (wvAlive[w] && wvArrived[w] == wvAlive[w]) { wvArrived[w] = 0; wvGen[w]++; }
-    swapcontext(&f.ctx, &schedCtx);
+    knz_emu_switch(&f.sp, schedSp);
+    abort();   // a finished fiber is never resumed
 }
-static inline void yield() { swapcontext(&fibers[cur].ctx, &schedCtx); }
+static inline void yield() { knz_emu_switch(&fibers[cur].sp, schedSp); }
 
 void block_barrier() {
     unsigned g = blkGen;
@@ -69,9 +95,13 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
             Fiber& f = fibers[i];
             f.done = false; f.tid = i;
             wvAlive[i >> 6]++;
-            getcontext(&f.ctx);
-            f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = &schedCtx;
-            makecontext(&f.ctx, (void (*)())trampoline, 0);
+            // initial frame: 6 callee-saved registers, then the entry point as the address `ret` jumps to
+            uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
+            void** spp = (void**)(top - 64);
+            for (int r = 0; r < 6; r++) spp[r] = nullptr;
+            spp[6] = (void*)trampoline;
+            spp[7] = nullptr;
+            f.sp = (void*)spp;
             order[i] = i;
         }
         if (sched == 1) std::reverse(order.begin(), order.end());
@@ -87,7 +117,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                 unsigned lin = i;
                 threadIdx.x = lin % block.x; threadIdx.y = (lin / block.x) % block.y; threadIdx.z = lin / (block.x * block.y);
                 blockIdx.x = bx; blockIdx.y = by; blockIdx.z = bz;
-                swapcontext(&schedCtx, &f.ctx);
+                knz_emu_switch(&schedSp, f.sp);
                 if (f.done) remaining--;
             }
             if (progress == lastProgress) { if (++stalls > 2) { fprintf(stderr, "hipemu: deadlock (divergent barrier / cross-lane op) in block %u\n", bx); abort(); } }

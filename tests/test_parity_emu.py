@@ -28,8 +28,8 @@ def test_entropy_objects_bit_exact(be, etype, sched, monkeypatch):
     ("NONE", "ANS0", 1 << 16, 300000), ("NONE", "ANS0", 1024, 1000), ("NONE", "ANS0", 1024, 10), ("NONE", "ANS0", 1 << 16, (1 << 16) + 33),
     ("NONE", "ANS0", 1 << 20, (1 << 20) + 17), ("NONE", "ANS0", 4096, 4096 * 2 + 3),
     ("NONE", "ANS1", 1 << 16, 300000), ("NONE", "ANS1", 1024, 1000), ("NONE", "ANS1", 1024, 10),
-    ("BWT", "HUFFMAN", 1 << 16, 200000), ("BWT+RANK+ZRLT", "ANS0", 1 << 16, 200000), ("BWT+RANK+ZRLT", "ANS1", 1 << 16, 300000),
-    ("BWT+MTFT+ZRLT", "ANS0", 1 << 15, 100003), ("RANK", "HUFFMAN", 1 << 16, 100000), ("ZRLT", "NONE", 1 << 16, 150000),
+    ("BWT", "HUFFMAN", 1 << 16, 200000), ("BWT+RANK+ZRLT", "ANS0", 1 << 14, 40000), ("BWT+RANK+ZRLT", "ANS1", 1 << 14, 50000),
+    ("BWT+MTFT+ZRLT", "ANS0", 1 << 14, 20003), ("RANK", "HUFFMAN", 1 << 14, 20000), ("ZRLT", "NONE", 1 << 16, 150000),
     ("BWT+RANK+ZRLT", "ANS1", 1024, 1000), ("BWT+RANK+ZRLT", "ANS1", 1024, 12),
 ])
 def test_stream_bit_exact(be, cfg):
@@ -56,9 +56,10 @@ def test_multi_gpu_assemble(be, ranks):
 
 @pytest.mark.parametrize("tname", ["ZRLT", "RANK", "MTFT", "BWT"])
 def test_transform_objects_bit_exact(be, tname):
-    P.check_transform(be, tname)
+    # the register-resident SBRT list uses ~12 cross-lane operations per byte: keep the emulated inputs small
+    P.check_transform(be, tname, max_len=4096 if tname in ("RANK", "MTFT") else 1 << 30)
 
 
 def test_block_batch_hook_transforms(be):
-    P.check_block_batch(be, "BWT+RANK+ZRLT", "ANS1", 1 << 16, 3, 4321)
-    P.check_block_batch(be, "BWT+RANK+ZRLT", "ANS0", 1 << 16, 2, 9)
+    P.check_block_batch(be, "BWT+RANK+ZRLT", "ANS1", 1 << 13, 3, 4321)
+    P.check_block_batch(be, "BWT+RANK+ZRLT", "ANS0", 1 << 13, 2, 9)
