@@ -233,28 +233,41 @@ __global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a) {
     uint32_t st = 1u << 15;
     uint32_t cnt = 0;
     const int gshift = (lane >> 2) << 2;
+    // Three-stage software pipeline per lane: symbol bytes of group g+2 are loaded while the table entries of group g+1
+    // (whose addresses need the bytes loaded one iteration earlier) are in flight and group g runs the dependent state
+    // arithmetic. Neither the table nor the data fits L2 for 16 chunks per wave: both latencies must be hidden.
     uint2 ecur[8], enext[8];
-    auto load_group = [&](uint32_t t0, uint2* e) {
+    uint32_t bnext[9], bnext2[9];                                     // bytes q-1-t0 .. q-9-t0 of a group (index 8 = context of step 7)
+    auto load_bytes = [&](uint32_t t0, uint32_t* bytes) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            const uint32_t t = t0 + j;
+            bytes[j] = (t < q && t <= steps) ? (uint32_t)qbase[q - 1 - t] : 0u;    // t == q: the context of the quarter's first symbol is 0
+        }
+    };
+    auto load_entries = [&](uint32_t t0, const uint32_t* bytes, uint2* e) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t t = t0 + j;
             e[j].x = 0; e[j].y = 0;
             if (t < steps) {
                 // step t codes symbol qbase[q-1-t] in context qbase[q-2-t] (context 0 for the quarter's first symbol)
-                const uint32_t sym = qbase[q - 1 - t];
-                const uint32_t ctx = (t + 1 < q) ? qbase[q - 2 - t] : 0u;
-                e[j] = tab[(ctx << 8) | sym];
+                const uint32_t ctx = (t + 1 < q) ? bytes[j + 1] : 0u;
+                e[j] = tab[(ctx << 8) | bytes[j]];
             }
         }
     };
+    load_bytes(0, bnext);
+    load_entries(0, bnext, ecur);
+    load_bytes(8, bnext);
     // Renormalisation words are staged in an LDS ring per chunk and flushed in bursts: on gfx950 stores and loads share
     // the in-order vmcnt counter, a global store inside the dependent loop would stall every following table load.
     __shared__ uint16_t s_ring[16][KNZ_ANS1_RING];
     uint16_t* ring = s_ring[lane >> 2];
     uint32_t flushed = 0;                                                // words already copied to the slot
-    load_group(0, ecur);
     for (uint32_t t0 = 0; t0 < maxSteps; t0 += 8) {
-        load_group(t0 + 8, enext);
+        load_bytes(t0 + 16, bnext2);
+        load_entries(t0 + 8, bnext, enext);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t t = t0 + j;
@@ -277,6 +290,8 @@ __global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a) {
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) ecur[j] = enext[j];
+#pragma unroll
+        for (int j = 0; j < 9; j++) bnext[j] = bnext2[j];
         // flush when any chunk of the wave could overflow its ring within the next group (32 words)
         const bool last = t0 + 8 >= maxSteps;
         if (wave_ballot(cnt - flushed > KNZ_ANS1_RING - 64) != 0 || last) {
@@ -331,7 +346,8 @@ struct Ans1DecArgs {
 
 // Parses the chunk header at reader position r (decodeHeader :605-710). When freq16 != nullptr the frequencies of
 // context k are stored at freq16[k*256 + sym]; returns false on an invalid header. Used by the walker too.
-__device__ static bool knz_ans1_parse_header(KnzStreamReader& r, uint16_t* freq16, uint32_t& lrOut, int& totalAlpha) {
+template <typename R>
+__device__ static bool knz_ans1_parse_header(R& r, uint16_t* freq16, uint32_t& lrOut, int& totalAlpha) {
     const uint32_t lr = 8 + r.read(3);
     lrOut = lr;
     if (lr > 16) return false;
@@ -344,12 +360,13 @@ __device__ static bool knz_ans1_parse_header(KnzStreamReader& r, uint16_t* freq1
         int count = 0;
         if (r.read(1) == 0) {
             if (r.read(1) == 1) count = 0;
-            else { count = 256; for (int i = 0; i < 256; i++) alpha[i] = (uint8_t)i; }
+            else { count = 256; if (freq16) for (int i = 0; i < 256; i++) alpha[i] = (uint8_t)i; }
         } else {
             const uint32_t lastMask = r.read(5);
             for (uint32_t mm = 0; mm <= lastMask; mm++) {
                 const uint32_t mask = r.read(8);
-                for (int j = 0; j < 8; j++) if ((mask >> j) & 1) alpha[count++] = (uint8_t)(8 * mm + j);
+                if (freq16) { for (int j = 0; j < 8; j++) if ((mask >> j) & 1) alpha[count++] = (uint8_t)(8 * mm + j); }
+                else count += __popc(mask);                    // position walk only: the symbols themselves are not needed
             }
         }
         if (count == 0) continue;

@@ -17,6 +17,7 @@ struct KnzStreamReader {
     uint64_t next;        // next word index to load
     uint64_t win;         // left aligned
     uint32_t navail;      // valid bits in win
+    uint32_t pre;         // word `next`, loaded one refill ahead so that its latency overlaps the decoding of ~32 bits
     __device__ __forceinline__ uint32_t ld(uint64_t i) const { return i < nwords ? knz_bswap32(words[i]) : 0u; }
     __device__ __forceinline__ void init(const uint8_t* base, uint64_t nbytes, uint64_t bitpos) {
         words = (const uint32_t*)base;
@@ -27,9 +28,10 @@ struct KnzStreamReader {
         win <<= off;
         navail = 64 - off;
         next = q + 2;
+        pre = ld(next);
     }
     __device__ __forceinline__ void refill() {
-        if (navail <= 32) { win |= (uint64_t)ld(next++) << (32 - navail); navail += 32; }
+        if (navail <= 32) { win |= (uint64_t)pre << (32 - navail); navail += 32; next++; pre = ld(next); }
     }
     __device__ __forceinline__ uint32_t peek(uint32_t n) { refill(); return (uint32_t)(win >> (64 - n)); } // 1..32
     __device__ __forceinline__ void skip(uint32_t n) { refill(); win <<= n; navail -= n; }                 // 0..32
@@ -38,8 +40,55 @@ struct KnzStreamReader {
     __device__ __forceinline__ void seek(uint64_t bitpos) { init((const uint8_t*)words, nwords << 2, bitpos); }
 };
 
+// Same interface, but the stream words are staged 128 at a time into two registers per lane (two coalesced loads by the
+// whole wave) and fetched with v_readlane: a serial header walk then never waits on a dependent global load, and since
+// every value is wave-uniform the compiler keeps the parse on the scalar unit. ALL 64 lanes must call it uniformly.
+struct KnzWaveReader {
+    const uint32_t* words;
+    uint64_t nwords;
+    uint64_t base;        // word index held by lane 0 of w0
+    uint32_t w0, w1;      // lane l: words base+l and base+64+l (byte-swapped on use)
+    uint64_t next;
+    uint64_t win;
+    uint32_t navail;
+    __device__ __forceinline__ void stage(uint64_t b) {
+        const uint64_t l = (uint64_t)lane_id();
+        base = b;
+        w0 = (b + l < nwords) ? words[b + l] : 0u;
+        w1 = (b + 64 + l < nwords) ? words[b + 64 + l] : 0u;
+    }
+    __device__ __forceinline__ uint32_t ld(uint64_t i) {
+        if (i < base || i >= base + 128) stage(i);
+        const uint32_t k = (uint32_t)(i - base);
+        const uint32_t v = k < 64 ? wave_readlane(w0, k) : wave_readlane(w1, k - 64);
+        return knz_bswap32(v);
+    }
+    __device__ __forceinline__ void init(const uint8_t* b, uint64_t nbytes, uint64_t bitpos) {
+        words = (const uint32_t*)b;
+        nwords = (nbytes + 3) >> 2;
+        stage(bitpos >> 5);
+        seek(bitpos);
+    }
+    __device__ __forceinline__ void seek(uint64_t bitpos) {
+        const uint64_t q = bitpos >> 5;
+        const uint32_t off = (uint32_t)(bitpos & 31);
+        win = ((uint64_t)ld(q) << 32) | ld(q + 1);
+        win <<= off;
+        navail = 64 - off;
+        next = q + 2;
+    }
+    __device__ __forceinline__ void refill() {
+        if (navail <= 32) { win |= (uint64_t)ld(next++) << (32 - navail); navail += 32; }
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t n) { refill(); return (uint32_t)(win >> (64 - n)); }
+    __device__ __forceinline__ void skip(uint32_t n) { refill(); win <<= n; navail -= n; }
+    __device__ __forceinline__ uint32_t read(uint32_t n) { uint32_t v = peek(n); win <<= n; navail -= n; return v; }
+    __device__ __forceinline__ uint64_t tell() const { return (next << 5) - navail; }
+};
+
 // EntropyUtils.go:278-296
-__device__ __forceinline__ uint32_t knz_read_varint(KnzStreamReader& r) {
+template <typename R>
+__device__ __forceinline__ uint32_t knz_read_varint(R& r) {
     uint32_t res = 0, shift = 0;
     for (int i = 0; i < 4; i++) {
         uint32_t v = r.read(8);
@@ -51,7 +100,8 @@ __device__ __forceinline__ uint32_t knz_read_varint(KnzStreamReader& r) {
     return res | ((v & 0x0F) << 28);
 }
 
-__device__ static bool knz_ans1_parse_header(KnzStreamReader& r, uint16_t* freq16, uint32_t& lrOut, int& totalAlpha);
+template <typename R>
+__device__ static bool knz_ans1_parse_header(R& r, uint16_t* freq16, uint32_t& lrOut, int& totalAlpha);
 
 struct WalkStreamArgs {
     const uint8_t* stream; uint64_t nbytes;
@@ -111,7 +161,8 @@ struct WalkBlocksArgs {
 };
 
 // Skips one signed Exp-Golomb code (ExpGolombCodec.go:159-190): '1' or L zeros, 1, L+1 bits.
-__device__ __forceinline__ void knz_skip_expg(KnzStreamReader& r) {
+template <typename R>
+__device__ __forceinline__ void knz_skip_expg(R& r) {
     uint32_t w = r.peek(17);
     if (w & 0x10000) { r.skip(1); return; }
     if (w == 0) { r.skip(17); return; }                     // corrupt input; the walk fails its bounds check later
@@ -122,12 +173,33 @@ __device__ __forceinline__ void knz_skip_expg(KnzStreamReader& r) {
     r.skip(lg + 1);
 }
 
+// 12-bit look-ahead table for skipping SEVERAL signed Exp-Golomb codes at once: entry = (codes << 4) | bits for the
+// complete codes found in the window (code-length deltas are mostly 0 = '1' or +-1 = 4 bits, so a window usually holds
+// 3-8 codes). codes == 0: the first code does not fit in 12 bits -> single-code path.
+__device__ __forceinline__ uint32_t knz_expg_lut_entry(uint32_t w) {
+    uint32_t pos = 0, codes = 0;
+    while (pos < 12) {
+        if ((w >> (11 - pos)) & 1) { codes++; pos++; continue; }
+        uint32_t z = 0;
+        while (pos + z < 12 && !((w >> (11 - pos - z)) & 1)) z++;
+        if (pos + z >= 12) break;                       // terminator outside the window
+        const uint32_t total = z + 1 + (z & 7) + 1;
+        if (pos + total > 12) break;
+        codes++; pos += total;
+    }
+    return (codes << 4) | pos;
+}
+
 // One wave per block, the serial walk runs on lane 0 only: putting several blocks on the lanes of one wave makes
 // their data-dependent loops diverge and the wave then pays for the union of all paths.
 __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs a) {
+    __shared__ uint8_t s_lut[4096];
+    for (uint32_t i = threadIdx.x; i < 4096; i += 64) s_lut[i] = (uint8_t)knz_expg_lut_entry(i);
+    wave_sync();
     const uint32_t b = blockIdx.x;
-    if (b >= a.nblocks || threadIdx.x != 0) return;
-    KnzStreamReader r;
+    if (b >= a.nblocks) return;
+    const bool writer = threadIdx.x == 0;            // every lane runs the (uniform) parse, lane 0 stores the results
+    KnzWaveReader r;
     const uint64_t start = a.blk_bit[b];
     const uint64_t end = start + a.blk_bits[b];
     // the block-local stream is its own bitstream in the reference (r = (read+7)>>3 bytes): reads past `end`
@@ -151,10 +223,12 @@ __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs 
         if (a.checksum_bits == 32) ck = r.read(32);
         else if (a.checksum_bits == 64) { ck = (uint64_t)r.read(32) << 32; ck |= r.read(32); }
     }
-    a.blk_pre_len[b] = preLen;
-    a.blk_mode[b] = (uint8_t)mode;
-    a.blk_skip[b] = (uint8_t)skipFlags;
-    a.blk_cksum[b] = ck;
+    if (writer) {
+        a.blk_pre_len[b] = preLen;
+        a.blk_mode[b] = (uint8_t)mode;
+        a.blk_skip[b] = (uint8_t)skipFlags;
+        a.blk_cksum[b] = ck;
+    }
     const uint64_t limit = start + (((a.blk_bits[b] + 7) >> 3) << 3);
     const uint32_t cpb = a.chunks_per_block;
     if (status == 0) {
@@ -163,7 +237,7 @@ __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs 
         if (nchunks > cpb) status = KNZ_ERR_BLOCK_SIZE;
         for (uint32_t k = 0; k < nchunks && status == 0; k++) {
             const uint32_t sz = min(chunkSize, preLen - k * chunkSize);
-            a.chunk_bit[(size_t)b * cpb + k] = r.tell();
+            if (writer) a.chunk_bit[(size_t)b * cpb + k] = r.tell();
             if (entropy == KNZ_E_NONE || (entropy == KNZ_E_HUFFMAN && sz < 32) || ((entropy == KNZ_E_ANS0 || entropy == KNZ_E_ANS1) && preLen <= 32)) {
                 r.seek(r.tell() + 8ull * sz);                          // raw bytes (HuffmanCodec.go:769-771, ANSRangeCodec.go:720-723)
             } else if (entropy == KNZ_E_ANS1) {
@@ -209,7 +283,12 @@ __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs 
                     for (uint32_t m = 0; m <= lastMask; m++) count += (uint32_t)__popc(r.read(8));
                     if (count == 0) { status = KNZ_ERR_PROCESS_BLOCK; break; }
                 }
-                for (uint32_t i = 0; i < count; i++) knz_skip_expg(r);
+                for (uint32_t i = 0; i < count;) {
+                    const uint32_t e = s_lut[r.peek(12)];
+                    const uint32_t nc = e >> 4;
+                    if (nc == 0 || i + nc > count) { knz_skip_expg(r); i++; }
+                    else { r.skip(e & 15); i += nc; }
+                }
                 if (count > 1) {
                     uint64_t fb = 0;
                     for (int j = 0; j < 4; j++) {
@@ -223,8 +302,10 @@ __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs 
             if (r.tell() > limit) status = KNZ_ERR_PROCESS_BLOCK;       // ran past the block payload
         }
     }
-    a.blk_status[b] = status;
-    a.blk_end_bit[b] = r.tell();
+    if (writer) {
+        a.blk_status[b] = status;
+        a.blk_end_bit[b] = r.tell();
+    }
 }
 
 struct HufDecArgs {
@@ -360,10 +441,25 @@ __global__ __launch_bounds__(64) void knz_huf_decode_kernel(HufDecArgs a) {
         KnzStreamReader r;
         r.init(a.stream, a.nbytes, s_fragpos[lane]);
         uint8_t* d = dst + (size_t)lane * F;
-        for (uint32_t i = 0; i < F; i++) {
-            const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)];
-            r.skip(val & 0xFF);
-            d[i] = (uint8_t)(val >> 8);
+        if ((((uintptr_t)d) & 3) == 0) {            // full chunks: fragments start 4096 bytes apart -> 32-bit stores
+            uint32_t i = 0;
+            for (; i + 4 <= F; i += 4) {
+                uint32_t out = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)];
+                    r.skip(val & 0xFF);
+                    out |= (val >> 8) << (8 * u);
+                }
+                *(uint32_t*)(d + i) = out;
+            }
+            for (; i < F; i++) { const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)]; r.skip(val & 0xFF); d[i] = (uint8_t)(val >> 8); }
+        } else {
+            for (uint32_t i = 0; i < F; i++) {
+                const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)];
+                r.skip(val & 0xFF);
+                d[i] = (uint8_t)(val >> 8);
+            }
         }
     }
     if (lane == 4) {
