@@ -101,6 +101,7 @@ def main():
 
     K = load_pkg()
     K.build_library()
+    from kanzi_go_amd import dist as kd
     transform, entropy, bs, cfg_idx = CONFIGS[args.config]
 
     size = args.size or bench_corpus.SILESIA_SIZE
@@ -131,23 +132,12 @@ def main():
             nb = codec.dev_compress(d_src.data_ptr(), n_my, d_seg.data_ptr(), cap, header_input_size=size, stream=stream)
             result["stream_bytes"] = nb
         else:
-            nbits = codec.dev_compress_blocks(d_src.data_ptr(), n_my, d_seg.data_ptr(), cap, stream=stream) if n_my else 0
+            # every rank encodes its blocks; gather of the segments to rank 0 over RCCL/xGMI; bit-granular assembly there
+            nb, nbits = kd.sharded_compress(codec, d_src, n_my, d_seg, size, d_stream if rank == 0 else d_seg, stream=stream)
             result["seg_bits"] = nbits
-        tm = codec.last_timing()
-        if world > 1:
-            # gather of the compressed segments to rank 0 over RCCL/xGMI: sizes first, then padded payloads
-            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-            dist.all_gather(sizes, torch.tensor([result["seg_bits"]], dtype=torch.int64, device=dev))
-            bits = [int(s.item()) for s in sizes]
-            maxb = (max(bits) + 7) // 8 + 8
-            maxb = (maxb + 15) & ~15
             if rank == 0:
-                bufs = [torch.empty(maxb, dtype=torch.uint8, device=dev) for _ in range(world)]
-                dist.gather(d_seg[:maxb], bufs, dst=0)
-                nb = codec.dev_assemble(size, [b.data_ptr() for b in bufs], bits, d_stream.data_ptr(), d_stream.numel(), stream=stream)
                 result["stream_bytes"] = nb
-            else:
-                dist.gather(d_seg[:maxb], None, dst=0)
+        tm = codec.last_timing()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         if world == 1:

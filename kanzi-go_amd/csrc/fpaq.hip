@@ -1,0 +1,177 @@
+// FPAQ (adaptive order-0 binary arithmetic coder) of kanzi bitstream v6 on gfx950.
+// Replaces FPAQEncoder.encodeBit / Write / flush / Dispose and FPAQDecoder.decodeBitV2 / read / Read
+// (v2/entropy/FPAQCodec.go:100-196, 308-420). The coder state (low, high, 4 x 256 adaptive probabilities) runs through the
+// whole block, across the 4 MiB sub-chunks: ONE serial chain per block is all the format offers, so the device runs one
+// lane per block (blocks in parallel) and keeps everything that chain touches in LDS / registers:
+//   * input tiles are staged cooperatively by the wave, the 8 probability reads of a byte are issued up front
+//     (the encoder knows the tree path in advance), the 32-bit flush words go to the scratch slot with plain stores;
+//   * per 4 MiB sub-chunk the kernel leaves 3 units: varint(bytes) | bytes | (low | 0xFFFFFF):56 (:162-168,:195).
+#include "bits.h"
+
+#define KNZ_FPAQ_CHUNK (4u << 20)
+#define KNZ_FPAQ_PAY_OFF 64
+#define KNZ_FPAQ_PAY_CAP (KNZ_FPAQ_CHUNK + (KNZ_FPAQ_CHUNK >> 3))     // the reference buffer: chunk + chunk/8 (:141-143)
+#define KNZ_FPAQ_U2_OFF (KNZ_FPAQ_PAY_OFF + KNZ_FPAQ_PAY_CAP + 64)
+#define KNZ_FPAQ_SLOT (KNZ_FPAQ_U2_OFF + 64)
+
+struct FpaqArgs {
+    const uint64_t* blk_off; const uint32_t* blk_len; const uint32_t* blk_src_len;
+    uint32_t chunks_per_block;
+    uint8_t* scratch; uint32_t* unit_bits; uint32_t* unit_src;
+    int32_t* blk_status;
+};
+
+__global__ __launch_bounds__(64) void knz_fpaq_encode_kernel(FpaqArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[4096];
+    __shared__ int s_p[4][256];
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    const uint32_t n = a.blk_len[b];
+    const uint8_t* src = (const uint8_t*)a.blk_off[b];
+    const uint32_t cpb = a.chunks_per_block;
+    for (uint32_t k = lane; k < cpb * KNZ_UNITS_PER_CHUNK; k += 64) {
+        const uint32_t j = k % KNZ_UNITS_PER_CHUNK;
+        a.unit_bits[(size_t)b * cpb * KNZ_UNITS_PER_CHUNK + k] = 0;
+        a.unit_src[(size_t)b * cpb * KNZ_UNITS_PER_CHUNK + k] = j == 1 ? KNZ_FPAQ_PAY_OFF : (j == 2 ? KNZ_FPAQ_U2_OFF : 0u);
+    }
+    if (a.blk_src_len[b] <= 15) {                                          // copy block: NONE/NONE, raw bytes (CompressedStream.go:773-776)
+        wave_sync();
+        uint8_t* slot = a.scratch + (size_t)b * cpb * KNZ_FPAQ_SLOT;
+        if ((uint32_t)lane < n) slot[KNZ_FPAQ_PAY_OFF + lane] = src[lane];
+        if (lane == 0) a.unit_bits[(size_t)b * cpb * KNZ_UNITS_PER_CHUNK + 1] = 8 * n;
+        return;
+    }
+    for (int i = lane; i < 1024; i += 64) (&s_p[0][0])[i] = 1 << 15;      // PSCALE >> 1
+    uint64_t low = 0, high = 0x00FFFFFFFFFFFFFFull;
+    int tbl = 0;                                                           // p = probs[0] at the start of every sub-chunk (:147)
+    bool failed = false;
+    const uint32_t nsub = (n + KNZ_FPAQ_CHUNK - 1) / KNZ_FPAQ_CHUNK;
+    for (uint32_t k = 0; k < nsub; k++) {
+        const uint32_t start = k * KNZ_FPAQ_CHUNK;
+        const uint32_t len = min(KNZ_FPAQ_CHUNK, n - start);
+        uint8_t* slot = a.scratch + ((size_t)b * cpb + k) * KNZ_FPAQ_SLOT;
+        uint32_t* pay = (uint32_t*)(slot + KNZ_FPAQ_PAY_OFF);
+        uint32_t index = 0;                                                // flush words written
+        tbl = 0;
+        for (uint32_t base = 0; base < len; base += 4096) {
+            const uint32_t cnt = min(4096u, len - base);
+            wave_sync();
+            for (uint32_t i = lane; i < cnt; i += 64) s_in[i] = src[start + base + i];
+            wave_sync();
+            if (lane == 0 && !failed) {
+                for (uint32_t i = 0; i < cnt; i++) {
+                    const uint32_t val = s_in[i];
+                    const uint32_t bits = val + 256;
+                    int* p = s_p[tbl];
+                    // tree path is known: node indexes 1, bits>>7, ..., bits>>1 (:150-159)
+                    int idx[8], pr[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) { idx[j] = j == 0 ? 1 : (int)(bits >> (8 - j)); pr[j] = p[idx[j]]; }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint64_t split = (((high - low) >> 8) * (uint64_t)(uint32_t)pr[j]) >> 8;     // :103
+                        if (((val >> (7 - j)) & 1) == 0) { low += split + 1; pr[j] -= pr[j] >> 6; }
+                        else { high = low + split; pr[j] -= (pr[j] - 65536 + 64) >> 6; }
+                        if ((low ^ high) < (1ull << 24)) {                                                  // flush (:174-179)
+                            if (4 * (index + 1) > KNZ_FPAQ_PAY_CAP) { failed = true; break; }               // Go slice-bound panic
+                            pay[index++] = knz_bswap32((uint32_t)(high >> 24));
+                            low <<= 32;
+                            high = (high << 32) | 0xFFFFFFFFull;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) p[idx[j]] = pr[j];
+                    tbl = (int)(val >> 6);
+                    if (failed) break;
+                }
+            }
+        }
+        if (lane == 0) {
+            uint32_t w[2] = {0, 0};
+            KnzBitWriter bw; bw.init(w);
+            knz_put_varint(bw, 4 * index);
+            ((uint32_t*)slot)[0] = knz_bswap32(w[0]); ((uint32_t*)slot)[1] = knz_bswap32(w[1]);
+            const uint64_t f = (low | 0xFFFFFFull) & 0x00FFFFFFFFFFFFFFull;               // WriteBits(low | MASK_0_24, 56)
+            uint32_t* u2 = (uint32_t*)(slot + KNZ_FPAQ_U2_OFF);
+            u2[0] = knz_bswap32((uint32_t)(f >> 24));
+            u2[1] = knz_bswap32((uint32_t)(f << 8));
+            uint32_t* ub = a.unit_bits + ((size_t)b * cpb + k) * KNZ_UNITS_PER_CHUNK;
+            ub[0] = bw.pos; ub[1] = 32 * index; ub[2] = 56;
+        }
+    }
+    if (lane == 0 && failed) a.blk_status[b] = KNZ_ERR_PROCESS_BLOCK;
+}
+
+struct FpaqDecArgs {
+    const uint8_t* stream; uint64_t nbytes;
+    const uint32_t* blk_pre_len; const uint8_t* blk_mode;
+    const uint64_t* chunk_bit;        // first sub-chunk of each block is enough: the chain walks the rest
+    const uint64_t* blk_out_off;
+    uint32_t chunks_per_block;
+    int32_t* blk_status;
+};
+
+__global__ __launch_bounds__(64) void knz_fpaq_decode_kernel(FpaqDecArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[4096];
+    __shared__ int s_p[4][256];
+    __shared__ int s_err;
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (a.blk_status[b] != 0) return;
+    const uint32_t n = a.blk_pre_len[b];
+    uint8_t* dst = (uint8_t*)a.blk_out_off[b];
+    const uint64_t limit = a.nbytes << 3;
+    if (a.blk_mode[b] & 0x80) {                                            // copy block: raw bytes
+        const uint64_t cbit = a.chunk_bit[(size_t)b * a.chunks_per_block];
+        for (uint32_t i = lane; i < n; i += 64) dst[i] = (uint8_t)(knz_fetch32(a.stream, (int64_t)(cbit + 8ull * i), (int64_t)limit) >> 24);
+        return;
+    }
+    for (int i = lane; i < 1024; i += 64) (&s_p[0][0])[i] = 1 << 15;
+    if (lane == 0) s_err = 0;
+    wave_sync();
+    KnzStreamReader r;
+    r.init(a.stream, a.nbytes, a.chunk_bit[(size_t)b * a.chunks_per_block]);
+    uint64_t low = 0, high = 0x00FFFFFFFFFFFFFFull, current = 0;
+    const uint32_t nsub = (n + KNZ_FPAQ_CHUNK - 1) / KNZ_FPAQ_CHUNK;
+    for (uint32_t k = 0; k < nsub; k++) {
+        const uint32_t start = k * KNZ_FPAQ_CHUNK;
+        const uint32_t len = min(KNZ_FPAQ_CHUNK, n - start);
+        uint32_t wordsLeft = 0;
+        int tbl = 0;
+        if (lane == 0) {
+            const uint32_t szBytes = knz_read_varint(r);                               // Read :357-377
+            if ((int32_t)szBytes < 0 || (uint64_t)szBytes >= 2ull * n || r.tell() + 56 + 8ull * szBytes > limit + 7) s_err = KNZ_ERR_PROCESS_BLOCK;
+            current = ((uint64_t)r.read(24) << 32) | r.read(32);
+            wordsLeft = (szBytes + 3) >> 2;
+        }
+        for (uint32_t base = 0; base < len; base += 4096) {
+            const uint32_t cnt = min(4096u, len - base);
+            wave_sync();
+            if (lane == 0 && s_err == 0) {
+                for (uint32_t i = 0; i < cnt; i++) {
+                    int* p = s_p[tbl];
+                    uint32_t ctx = 1;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {                                       // decodeBitV2 :308-334
+                        int pv = p[ctx];
+                        const uint64_t split = ((((high - low) >> 8) * (uint64_t)(uint32_t)pv) >> 8) + low;
+                        if (split >= current) { high = split; pv -= (pv - 65536 + 64) >> 6; p[ctx] = pv; ctx = 2 * ctx + 1; }
+                        else { low = split + 1; pv -= pv >> 6; p[ctx] = pv; ctx = 2 * ctx; }
+                        if ((low ^ high) < (1ull << 24)) {                              // read :336-342
+                            low = (low << 32) & 0x00FFFFFFFFFFFFFFull;
+                            high = ((high << 32) | 0xFFFFFFFFull) & 0x00FFFFFFFFFFFFFFull;
+                            uint32_t wv = 0;
+                            if (wordsLeft > 0) { wv = r.read(32); wordsLeft--; }        // past the payload the reference reads its zero guard
+                            current = ((current << 32) | wv) & 0x00FFFFFFFFFFFFFFull;
+                        }
+                    }
+                    s_out[i] = (uint8_t)ctx;
+                    tbl = (int)((ctx & 0xFF) >> 6);
+                }
+            }
+            wave_sync();
+            if (s_err == 0) for (uint32_t i = lane; i < cnt; i += 64) dst[start + base + i] = s_out[i];
+        }
+    }
+    if (lane == 0 && s_err) a.blk_status[b] = s_err;
+}

@@ -173,18 +173,20 @@ __device__ __forceinline__ void knz_skip_expg(R& r) {
     r.skip(lg + 1);
 }
 
-// 12-bit look-ahead table for skipping SEVERAL signed Exp-Golomb codes at once: entry = (codes << 4) | bits for the
-// complete codes found in the window (code-length deltas are mostly 0 = '1' or +-1 = 4 bits, so a window usually holds
-// 3-8 codes). codes == 0: the first code does not fit in 12 bits -> single-code path.
+// 8-bit look-ahead table for skipping SEVERAL signed Exp-Golomb codes at once: entry = (codes << 4) | bits for the
+// complete codes found in the window (code-length deltas are mostly 0 = '1' or +-1 = 4 bits). The 256 one-byte entries
+// live in ONE register across the wave (lane l holds entries 4l..4l+3) and are fetched with v_readlane, so the walk has
+// no memory access at all per step. codes == 0: the first code does not fit in 8 bits -> single-code path.
+#define KNZ_EXPG_WIN 8
 __device__ __forceinline__ uint32_t knz_expg_lut_entry(uint32_t w) {
     uint32_t pos = 0, codes = 0;
-    while (pos < 12) {
-        if ((w >> (11 - pos)) & 1) { codes++; pos++; continue; }
+    while (pos < KNZ_EXPG_WIN) {
+        if ((w >> (KNZ_EXPG_WIN - 1 - pos)) & 1) { codes++; pos++; continue; }
         uint32_t z = 0;
-        while (pos + z < 12 && !((w >> (11 - pos - z)) & 1)) z++;
-        if (pos + z >= 12) break;                       // terminator outside the window
+        while (pos + z < KNZ_EXPG_WIN && !((w >> (KNZ_EXPG_WIN - 1 - pos - z)) & 1)) z++;
+        if (pos + z >= KNZ_EXPG_WIN) break;              // terminator outside the window
         const uint32_t total = z + 1 + (z & 7) + 1;
-        if (pos + total > 12) break;
+        if (pos + total > KNZ_EXPG_WIN) break;
         codes++; pos += total;
     }
     return (codes << 4) | pos;
@@ -193,9 +195,8 @@ __device__ __forceinline__ uint32_t knz_expg_lut_entry(uint32_t w) {
 // One wave per block, the serial walk runs on lane 0 only: putting several blocks on the lanes of one wave makes
 // their data-dependent loops diverge and the wave then pays for the union of all paths.
 __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs a) {
-    __shared__ uint8_t s_lut[4096];
-    for (uint32_t i = threadIdx.x; i < 4096; i += 64) s_lut[i] = (uint8_t)knz_expg_lut_entry(i);
-    wave_sync();
+    uint32_t lutReg = 0;
+    for (uint32_t j = 0; j < 4; j++) lutReg |= knz_expg_lut_entry(4u * threadIdx.x + j) << (8 * j);
     const uint32_t b = blockIdx.x;
     if (b >= a.nblocks) return;
     const bool writer = threadIdx.x == 0;            // every lane runs the (uniform) parse, lane 0 stores the results
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs 
     const uint64_t limit = start + (((a.blk_bits[b] + 7) >> 3) << 3);
     const uint32_t cpb = a.chunks_per_block;
     if (status == 0) {
-        const uint32_t chunkSize = entropy == KNZ_E_ANS1 ? (4u << 20) : (uint32_t)KNZ_HUF_CHUNK;
+        const uint32_t chunkSize = (a.entropy == KNZ_E_ANS1 || a.entropy == KNZ_E_FPAQ) ? (4u << 20) : (uint32_t)KNZ_HUF_CHUNK;
         const uint32_t nchunks = (preLen + chunkSize - 1) / chunkSize;
         if (nchunks > cpb) status = KNZ_ERR_BLOCK_SIZE;
         for (uint32_t k = 0; k < nchunks && status == 0; k++) {
@@ -240,6 +241,10 @@ __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs 
             if (writer) a.chunk_bit[(size_t)b * cpb + k] = r.tell();
             if (entropy == KNZ_E_NONE || (entropy == KNZ_E_HUFFMAN && sz < 32) || ((entropy == KNZ_E_ANS0 || entropy == KNZ_E_ANS1) && preLen <= 32)) {
                 r.seek(r.tell() + 8ull * sz);                          // raw bytes (HuffmanCodec.go:769-771, ANSRangeCodec.go:720-723)
+            } else if (entropy == KNZ_E_FPAQ) {                       // FPAQDecoder.Read :357-377
+                const uint32_t szb = knz_read_varint(r);
+                if ((int32_t)szb < 0 || (uint64_t)szb >= 2ull * preLen) status = KNZ_ERR_PROCESS_BLOCK;
+                r.seek(r.tell() + 56 + 8ull * szb);
             } else if (entropy == KNZ_E_ANS1) {
                 uint32_t lr; int total;
                 if (!knz_ans1_parse_header(r, nullptr, lr, total) || total == 0) { status = KNZ_ERR_PROCESS_BLOCK; break; }
@@ -280,11 +285,16 @@ __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs 
                 } else {
                     uint32_t lastMask = r.read(5);
                     count = 0;
-                    for (uint32_t m = 0; m <= lastMask; m++) count += (uint32_t)__popc(r.read(8));
+                    for (uint32_t bitsLeft = 8 * (lastMask + 1); bitsLeft > 0;) {
+                        const uint32_t take = bitsLeft > 32 ? 32 : bitsLeft;
+                        count += (uint32_t)__popc(r.read(take));
+                        bitsLeft -= take;
+                    }
                     if (count == 0) { status = KNZ_ERR_PROCESS_BLOCK; break; }
                 }
                 for (uint32_t i = 0; i < count;) {
-                    const uint32_t e = s_lut[r.peek(12)];
+                    const uint32_t w8 = r.peek(KNZ_EXPG_WIN);
+                    const uint32_t e = (wave_readlane(lutReg, w8 >> 2) >> (8 * (w8 & 3))) & 0xFF;
                     const uint32_t nc = e >> 4;
                     if (nc == 0 || i + nc > count) { knz_skip_expg(r); i++; }
                     else { r.skip(e & 15); i += nc; }

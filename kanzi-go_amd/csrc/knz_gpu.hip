@@ -5,6 +5,7 @@
 #include "huffman_dec.hip"
 #include "ans0.hip"
 #include "ans1.hip"
+#include "fpaq.hip"
 #include "transforms.hip"
 #include "bwt.hip"
 #include "prims.h"
@@ -85,7 +86,7 @@ static bool transform_on_device(uint64_t t) {                    // packed seque
     }
     return true;
 }
-static bool entropy_on_device(uint32_t e) { return e == KNZ_E_HUFFMAN || e == KNZ_E_NONE || e == KNZ_E_ANS0 || e == KNZ_E_ANS1; }
+static bool entropy_on_device(uint32_t e) { return e == KNZ_E_HUFFMAN || e == KNZ_E_NONE || e == KNZ_E_ANS0 || e == KNZ_E_ANS1 || e == KNZ_E_FPAQ; }
 
 extern "C" int knz_supports(uint64_t transform, uint32_t entropy) {
     return (transform_on_device(transform) && entropy_on_device(entropy)) ? 1 : 0;
@@ -192,11 +193,11 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     }
     const uint64_t bs = cfg.block_size;
     const uint32_t nblocks = (uint32_t)((eb.n + bs - 1) / bs);
-    const uint32_t chunkSize = cfg.entropy == KNZ_E_ANS1 ? KNZ_ANS1_CHUNK : KNZ_HUF_CHUNK;
+    const uint32_t chunkSize = (cfg.entropy == KNZ_E_ANS1 || cfg.entropy == KNZ_E_FPAQ) ? KNZ_ANS1_CHUNK : KNZ_HUF_CHUNK;
     const uint32_t maxPost = knz_max_encoded_len(cfg.transform, (uint32_t)std::min<uint64_t>(bs, eb.n ? eb.n : 1));
     const uint32_t cpb = std::max<uint32_t>(1, (maxPost + chunkSize - 1) / chunkSize);
     const size_t nslots = (size_t)std::max<uint32_t>(nblocks, 1) * cpb;
-    const uint32_t slotStride = cfg.entropy == KNZ_E_ANS0 ? KNZ_ANS_SLOT : (cfg.entropy == KNZ_E_ANS1 ? KNZ_ANS1_SLOT : KNZ_CHUNK_STRIDE);
+    const uint32_t slotStride = cfg.entropy == KNZ_E_ANS0 ? KNZ_ANS_SLOT : (cfg.entropy == KNZ_E_ANS1 ? KNZ_ANS1_SLOT : (cfg.entropy == KNZ_E_FPAQ ? KNZ_FPAQ_SLOT : KNZ_CHUNK_STRIDE));
 
     if (h->blk_off.reserve(sizeof(uint64_t) * (nblocks + 1)) || h->blk_len.reserve(4 * (nblocks + 1)) ||
         h->blk_src_len.reserve(4 * (nblocks + 1)) || h->blk_skip.reserve(nblocks + 16) || h->blk_cksum.reserve(8 * (nblocks + 1)) ||
@@ -225,7 +226,9 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             if (!noneOnly && xf_alloc(h, xb, nblocks, stride)) return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
             HIP_OK(hipMemcpyAsync(h->blk_off.p, off.data(), 8 * (size_t)nblocks, hipMemcpyHostToDevice, st));
             HIP_OK(hipMemcpyAsync(h->blk_len.p, len.data(), 4 * (size_t)nblocks, hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemcpyAsync(h->blk_src_len.p, len.data(), 4 * (size_t)nblocks, hipMemcpyHostToDevice, st));
+            std::vector<uint32_t> srclen(len);
+            if (eb.payload_only) for (auto& v : srclen) v = std::max<uint32_t>(v, 16);   // a bare EntropyEncoder has no copy-block rule
+            HIP_OK(hipMemcpyAsync(h->blk_src_len.p, srclen.data(), 4 * (size_t)nblocks, hipMemcpyHostToDevice, st));
             HIP_OK(hipMemcpyAsync(h->blk_skip.p, skip.data(), nblocks, hipMemcpyHostToDevice, st));
             if (!noneOnly) {
                 HIP_OK(hipMemcpyAsync(xb.active, active.data(), nblocks, hipMemcpyHostToDevice, st));
@@ -251,6 +254,12 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             a.blk_status = h->blk_status.as<int32_t>();
             if (cfg.entropy == KNZ_E_HUFFMAN) hipLaunchKernelGGL(knz_huf_encode_kernel, dim3(nblocks * cpb), dim3(256), 0, st, a);
             else hipLaunchKernelGGL(knz_raw_units_kernel, dim3(nblocks * cpb), dim3(256), 0, st, a);
+        } else if (cfg.entropy == KNZ_E_FPAQ) {
+            FpaqArgs a;
+            a.blk_off = h->blk_off.as<uint64_t>(); a.blk_len = h->blk_len.as<uint32_t>(); a.blk_src_len = h->blk_src_len.as<uint32_t>();
+            a.chunks_per_block = cpb; a.scratch = h->scratch.as<uint8_t>(); a.unit_bits = h->unit_bits.as<uint32_t>();
+            a.unit_src = h->unit_src.as<uint32_t>(); a.blk_status = h->blk_status.as<int32_t>();
+            hipLaunchKernelGGL(knz_fpaq_encode_kernel, dim3(nblocks), dim3(64), 0, st, a);
         } else if (cfg.entropy == KNZ_E_ANS1) {
             const uint32_t ns = nblocks * cpb;
             if (h->a1_freqs.reserve((size_t)ns * 65536 * 4) || h->a1_tab.reserve((size_t)ns * 65536 * 8) ||
@@ -306,7 +315,7 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     ga.unit_src = h->unit_src.as<uint32_t>();
     ga.chunk_rel = h->chunk_rel.as<uint64_t>(); ga.blk_dst_bit = h->blk_dst_bit.as<uint64_t>(); ga.dst_words = (uint32_t*)eb.d_dst;
     ga.total_bits = h->total_bits.as<uint64_t>();
-    if (nblocks) hipLaunchKernelGGL(knz_gather_kernel, dim3(nblocks * cpb, cfg.entropy == KNZ_E_ANS1 ? 64 : 1), dim3(256), 0, st, ga);
+    if (nblocks) hipLaunchKernelGGL(knz_gather_kernel, dim3(nblocks * cpb, (cfg.entropy == KNZ_E_ANS1 || cfg.entropy == KNZ_E_FPAQ) ? 64 : 1), dim3(256), 0, st, ga);
     hipEventRecord(h->ev[4], st);
     h->ev_valid = true;
 

@@ -1,0 +1,66 @@
+"""N > 1 path on CPU: world_size 2, gloo, kernels on the emulator (tests/emu). Each rank encodes its contiguous block
+range, segments are gathered to rank 0 and assembled bit-granularly; the result must equal the oracle's stream and
+every rank must decode its own segment back."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+import knz, parity_cases as P, oracle_lib as O
+K = knz.package()
+from kanzi_go_amd import dist as kd
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=int(sys.argv[4]))
+rank, world = dist.get_rank(), dist.get_world_size()
+entropy, bs, n = sys.argv[5], int(sys.argv[6]), int(sys.argv[7])
+data = P.corpus(n, 5)
+nblocks = (n + bs - 1) // bs
+lo_b, hi_b = kd.block_range(nblocks, rank, world)
+lo, hi = lo_b * bs, min(hi_b * bs, n)
+part = data[lo:hi]
+codec = K.Codec("NONE", entropy, bs, lib=knz.emu_library())
+per = (nblocks + world - 1) // world
+cap = 2 * per * bs + (1 << 18)
+raw = torch.zeros(len(part) + 64, dtype=torch.uint8)
+off = (-raw.data_ptr()) % 16
+src = raw[off:off + max(len(part), 1)]
+if part:
+    src[: len(part)] = torch.from_numpy(np.frombuffer(part, dtype=np.uint8).copy())
+seg = torch.zeros(cap + 16, dtype=torch.uint8)
+seg = seg[(-seg.data_ptr()) % 16:][:cap]
+out = torch.zeros(2 * n + (1 << 18) + 16, dtype=torch.uint8)
+out = out[(-out.data_ptr()) % 16:]
+nbytes, nbits = kd.sharded_compress(codec, src, len(part), seg, n, out)
+if rank == 0:
+    got = out[:nbytes].numpy().tobytes()
+    assert got == O.compress(data, "NONE", entropy, bs), "assembled stream differs from the oracle"
+back = torch.zeros(len(part) + 64, dtype=torch.uint8)
+if part:
+    assert codec.dev_decompress_blocks(seg.data_ptr(), nbits, back.data_ptr(), back.numel()) == len(part)
+    assert back[: len(part)].numpy().tobytes() == part
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+@pytest.mark.parametrize("cfg", [("HUFFMAN", 1 << 16, 5 * (1 << 16) + 777, 2), ("ANS0", 1 << 16, 2 * (1 << 16) + 5, 2), ("HUFFMAN", 1 << 16, 1000, 2)])
+def test_two_ranks_gloo(cfg, tmp_path):
+    entropy, bs, n, world = cfg
+    import knz
+    knz.emu_library()                                    # build once, before the ranks race for it
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = str(29500 + (os.getpid() % 2000))
+    procs = [subprocess.Popen([sys.executable, str(script), HERE, port, str(r), str(world), entropy, str(bs), str(n)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o

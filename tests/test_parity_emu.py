@@ -15,7 +15,7 @@ def be():
 
 
 @pytest.mark.parametrize("sched", ["fwd", "rev"])
-@pytest.mark.parametrize("etype", ["HUFFMAN", "NONE", "ANS0", "ANS1"])
+@pytest.mark.parametrize("etype", ["HUFFMAN", "NONE", "ANS0", "ANS1", "FPAQ"])
 def test_entropy_objects_bit_exact(be, etype, sched, monkeypatch):
     monkeypatch.setenv("KNZ_EMU_SCHED", sched)   # thread order inside a workgroup: catches missing barriers
     P.check_entropy_encode(be, etype)
@@ -31,6 +31,7 @@ def test_entropy_objects_bit_exact(be, etype, sched, monkeypatch):
     ("BWT", "HUFFMAN", 1 << 16, 200000), ("BWT+RANK+ZRLT", "ANS0", 1 << 14, 40000), ("BWT+RANK+ZRLT", "ANS1", 1 << 14, 50000),
     ("BWT+MTFT+ZRLT", "ANS0", 1 << 14, 20003), ("RANK", "HUFFMAN", 1 << 14, 20000), ("ZRLT", "NONE", 1 << 16, 150000),
     ("BWT+RANK+ZRLT", "ANS1", 1024, 1000), ("BWT+RANK+ZRLT", "ANS1", 1024, 12),
+    ("NONE", "FPAQ", 1 << 16, 300000), ("NONE", "FPAQ", 1024, 1000), ("NONE", "FPAQ", 1024, 10), ("BWT+RANK+ZRLT", "FPAQ", 1 << 13, 20000),
 ])
 def test_stream_bit_exact(be, cfg):
     P.check_stream(be, *cfg)

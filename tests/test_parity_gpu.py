@@ -15,7 +15,7 @@ def be():
     return P.GpuBackend()
 
 
-@pytest.mark.parametrize("etype", ["HUFFMAN", "NONE", "ANS0", "ANS1"])
+@pytest.mark.parametrize("etype", ["HUFFMAN", "NONE", "ANS0", "ANS1", "FPAQ"])
 def test_entropy_objects_bit_exact(be, etype):
     P.check_entropy_encode(be, etype)
 
@@ -30,6 +30,8 @@ def test_entropy_objects_bit_exact(be, etype):
     ("BWT", "HUFFMAN", 1 << 16, 200000), ("BWT+RANK+ZRLT", "ANS0", 1 << 16, 200000), ("BWT+RANK+ZRLT", "ANS1", 1 << 16, 300000),
     ("BWT+MTFT+ZRLT", "ANS0", 1 << 15, 100003), ("RANK", "HUFFMAN", 1 << 16, 100000), ("ZRLT", "NONE", 1 << 16, 150000),
     ("BWT+RANK+ZRLT", "ANS1", 1024, 1000), ("BWT+RANK+ZRLT", "ANS1", 1024, 12), ("BWT+RANK+ZRLT", "ANS1", 1 << 20, 3 * (1 << 20) + 5),
+    ("NONE", "FPAQ", 1 << 16, 300000), ("NONE", "FPAQ", 1024, 1000), ("NONE", "FPAQ", 1024, 10), ("BWT+RANK+ZRLT", "FPAQ", 1 << 16, 200000),
+    ("NONE", "FPAQ", 8 << 20, (8 << 20) + 12345),     # crosses the 4 MiB sub-chunk boundary: coder state persists (FPAQCodec.go:162-168)
 ])
 def test_stream_bit_exact(be, cfg):
     P.check_stream(be, *cfg)
