@@ -31,7 +31,9 @@ CONFIGS = {
     # name: (transform, entropy, block size, BASELINE.json config index)
     "huffman": ("NONE", "HUFFMAN", 4 << 20, 1),
     "ans0": ("NONE", "ANS0", 4 << 20, 2),       # entropy half of configs[2] (LZ front end: see DESIGN.md)
+    "lz": ("LZ", "ANS0", 4 << 20, 2),
     "bwt": ("BWT+RANK+ZRLT", "ANS1", 8 << 20, 3),
+    "fpaq": ("BWT+RANK+ZRLT", "FPAQ", 32 << 20, 4),   # configs[4] codec on S-silesia-shaped data (enwik9-sized input: --size 1000000000)
 }
 
 
@@ -192,11 +194,11 @@ def main():
         per_launch = {k: v / K_ for k, v in stage.items()}
         n_local, c_local = n_my, (result.get("seg_bits", C_bytes * 8) + 7) // 8 if world > 1 else C_bytes
         kern = {
-            {"HUFFMAN": "knz_huf_encode_kernel", "ANS0": "knz_ans0_stats+encode_kernels", "ANS1": "knz_ans1_hist+stats+merge+encode_kernels"}[entropy]: (per_launch["enc_entropy"], n_local + c_local),
-            {"HUFFMAN": "knz_huf_decode_kernel", "ANS0": "knz_ans0_decode_kernel", "ANS1": "knz_ans1_dec_tables+decode_kernels"}[entropy]: (per_launch["dec_entropy"], n_local + c_local),
+            {"HUFFMAN": "knz_huf_encode_kernel", "ANS0": "knz_ans0_stats+encode_kernels", "ANS1": "knz_ans1_hist+stats+merge+encode_kernels", "FPAQ": "knz_fpaq_encode_kernel"}[entropy]: (per_launch["enc_entropy"], n_local + c_local),
+            {"HUFFMAN": "knz_huf_decode_kernel", "ANS0": "knz_ans0_decode_kernel", "ANS1": "knz_ans1_dec_tables+decode_kernels", "FPAQ": "knz_fpaq_decode_kernel"}[entropy]: (per_launch["dec_entropy"], n_local + c_local),
             "knz_dec_walk_blocks_kernel": (per_launch["dec_walk"], c_local),
-            "forward transforms (suffix sort + RANK + ZRLT stage kernels)": (per_launch["enc_transform"], 2 * n_local),
-            "inverse transforms (ZRLT^-1, RANK^-1, BWT^-1 chains)": (per_launch["dec_transform"], 2 * n_local),
+            "forward transform stage kernels (" + transform + ")": (per_launch["enc_transform"], 2 * n_local),
+            "inverse transform stage kernels (" + transform + ")": (per_launch["dec_transform"], 2 * n_local),
         }
         dom = max(kern, key=lambda k: kern[k][0])
         dur_ms, alg = kern[dom]

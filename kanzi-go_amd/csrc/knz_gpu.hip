@@ -8,6 +8,7 @@
 #include "fpaq.hip"
 #include "transforms.hip"
 #include "bwt.hip"
+#include "lz.hip"
 #include "prims.h"
 #include "layout.hip"
 #include <algorithm>
@@ -82,7 +83,7 @@ uint32_t knz_build_stream_header(const knz_cfg& cfg, int64_t inputSize, uint32_t
 static bool transform_on_device(uint64_t t) {                    // packed sequence
     for (int s = 42; s >= 0; s -= 6) {
         const uint32_t id = (uint32_t)((t >> s) & 63);
-        if (!(id == KNZ_T_NONE || id == KNZ_T_BWT || id == KNZ_T_RANK || id == KNZ_T_MTFT || id == KNZ_T_ZRLT)) return false;
+        if (!(id == KNZ_T_NONE || id == KNZ_T_BWT || id == KNZ_T_RANK || id == KNZ_T_MTFT || id == KNZ_T_ZRLT || id == KNZ_T_LZ || id == KNZ_T_LZX)) return false;
     }
     return true;
 }

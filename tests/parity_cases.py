@@ -234,7 +234,7 @@ def _transform_inputs(zrlt=False):
     yield "binary", (rng.integers(0, 256, 50000, dtype=np.uint8) & rng.integers(0, 256, 50000, dtype=np.uint8) & rng.integers(0, 256, 50000, dtype=np.uint8)).tobytes()
 
 
-_TID = {"BWT": 1, "ZRLT": 6, "MTFT": 7, "RANK": 8, "LZ": 3}
+_TID = {"BWT": 1, "ZRLT": 6, "MTFT": 7, "RANK": 8, "LZ": 3, "LZX": 16}
 
 
 def check_transform(be, tname, max_len=1 << 30):

@@ -32,6 +32,7 @@ def test_entropy_objects_bit_exact(be, etype, sched, monkeypatch):
     ("BWT+MTFT+ZRLT", "ANS0", 1 << 14, 20003), ("RANK", "HUFFMAN", 1 << 14, 20000), ("ZRLT", "NONE", 1 << 16, 150000),
     ("BWT+RANK+ZRLT", "ANS1", 1024, 1000), ("BWT+RANK+ZRLT", "ANS1", 1024, 12),
     ("NONE", "FPAQ", 1 << 16, 300000), ("NONE", "FPAQ", 1024, 1000), ("NONE", "FPAQ", 1024, 10), ("BWT+RANK+ZRLT", "FPAQ", 1 << 13, 20000),
+    ("LZ", "ANS0", 1 << 16, 300000), ("LZ", "HUFFMAN", 1 << 18, 300000), ("LZX", "HUFFMAN", 1 << 16, 150000), ("LZ", "ANS0", 1024, 1000), ("LZ", "ANS0", 1024, 20),
 ])
 def test_stream_bit_exact(be, cfg):
     P.check_stream(be, *cfg)
@@ -55,7 +56,7 @@ def test_multi_gpu_assemble(be, ranks):
     P.check_assemble(be, "ANS0", 1 << 16, 3 * (1 << 16) + 5, ranks)
 
 
-@pytest.mark.parametrize("tname", ["ZRLT", "RANK", "MTFT", "BWT"])
+@pytest.mark.parametrize("tname", ["ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX"])
 def test_transform_objects_bit_exact(be, tname):
     # the register-resident SBRT list uses ~12 cross-lane operations per byte: keep the emulated inputs small
     P.check_transform(be, tname, max_len=4096 if tname in ("RANK", "MTFT") else 1 << 30)
