@@ -203,8 +203,15 @@ def main():
         dom = max(kern, key=lambda k: kern[k][0])
         dur_ms, alg = kern[dom]
         ach = alg / 1e9 / (dur_ms / 1e3) if dur_ms > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/, see its _how)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_config2.json")))
+            if args.config == "huffman" and world == 1 and not args.size and dom in pm["kernels"]:
+                traffic = pm["kernels"][dom]["hbm_bytes_corrected"]
+        except Exception:
+            traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(dur_ms, 4),
                            "all_stage_ms": {k: round(v, 4) for k, v in per_launch.items()}}
         if not args.no_verify and world == 1:
