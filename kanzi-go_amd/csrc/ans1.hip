@@ -5,9 +5,9 @@
 //   knz_ans1_hist_kernel    16 workgroups per chunk, each owns 16 contexts in LDS and streams the chunk (L2/MALL resident)
 //   knz_ans1_stats_kernel   one wave per (chunk, context): NormalizeFrequencies to 2048, symbol parameters, header bits
 //   knz_ans1_merge_kernel   one workgroup per chunk: bit-granular concatenation of the 256 context headers (unit 0)
-//   knz_ans1_encode_kernel  one LANE per state; the symbol-table look-ups do not depend on the state, so they are issued
-//                           a group of 8 steps ahead of the dependent state arithmetic (hides the L2 latency of the 512 KiB
-//                           table); renormalisation words are placed with the ballot/popcount scheme of ans0.hip
+//   knz_ans1_expand_kernel  parallel: resolves the (context, symbol) -> parameters look-up of every coding step into a stream
+//   knz_ans1_encode_kernel  one wave per chunk, lanes 0..3 = the 4 states; only the state-dependent arithmetic is serial;
+//                           renormalisation words are placed with the ballot/popcount scheme of ans0.hip
 // Decode: knz_ans1_dec_tables_kernel (header parse, slot table {symbol,freq,slot-cum} 2 MiB per chunk) and
 // knz_ans1_decode_kernel (one lane per state, forward).
 #include "bits.h"
@@ -21,7 +21,7 @@
 #define KNZ_ANS1_PAY_OFF (KNZ_ANS1_U0_CAP + 64)
 #define KNZ_ANS1_PAY_CAP (((KNZ_ANS1_CHUNK / 8) * 11) + 64)   // a symbol costs at most log2(2048) = 11 bits
 #define KNZ_ANS1_SLOT (KNZ_ANS1_PAY_OFF + KNZ_ANS1_PAY_CAP + 64)
-#define KNZ_ANS1_RING 1024                            // 16-bit words per chunk ring (power of two)
+#define KNZ_ANS1_RING 2048                            // 16-bit words per chunk ring (power of two)
 
 struct Ans1Args {
     const uint64_t* blk_off;       // absolute device address of each block's post-transform bytes
@@ -208,110 +208,127 @@ __global__ __launch_bounds__(256) void knz_ans1_merge_kernel(Ans1Args a) {
     if (tid == 0) ubits[0] = total;
 }
 
-// one lane per state: lanes 4g..4g+3 own chunk g of the workgroup
-__global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a) {
+// Expanded per-step coder parameters: the sequence of (context, symbol) pairs a state walks does not depend on the state
+// value, so a fully parallel pass resolves the two dependent look-ups (byte -> table entry) for every step up front and
+// leaves them as a sequential 16-byte stream: entry (t, c) at ent[slot][4 * t + c] =
+//   { invFreq, xMax = freq << 20, bias, (2048 - freq) << 8 | invShift }.
+// Steps past the end are padding {0, 0xFFFFFFFF, 0, 0}: never renormalise, state unchanged.
+#define KNZ_ANS1_GROUP 16                              // steps per register buffer of the serial kernel
+#define KNZ_ANS1_ENT_STEPS ((KNZ_ANS1_CHUNK >> 2) + 128)
+#define KNZ_ANS1_ENT_STRIDE ((size_t)KNZ_ANS1_ENT_STEPS * 4)    // uint4 entries per chunk slot
+
+// number of coding steps of a chunk (0: nothing coded), and whether the Go code would panic on it
+__device__ __forceinline__ uint32_t knz_ans1_steps(const Ans1Args& a, uint32_t slotId, uint32_t& b, uint32_t& n, const uint8_t*& src, bool& bad) {
+    bad = false; b = 0; n = 0; src = nullptr;
+    if (!knz_ans1_chunk(a, slotId, b, n, src)) { n = 0; return 0; }
+    if (a.blk_status[b] != 0) { n = 0; return 0; }
+    const uint32_t q = n >> 2;
+    if (n > 1 && q == 0) { bad = true; n = 0; return 0; }   // 2..3 byte chunk: Go indexes block[-1] and panics
+    return n > 1 ? q : 0;                                    // encodeChunk: `else if len(block) > 1` (:353)
+}
+
+__device__ __forceinline__ uint32_t knz_ans1_padded_steps(uint32_t steps) {
+    return ((steps + 5 * KNZ_ANS1_GROUP - 1) / (3 * KNZ_ANS1_GROUP)) * (3 * KNZ_ANS1_GROUP) + KNZ_ANS1_GROUP;
+}
+
+__global__ __launch_bounds__(256) void knz_ans1_expand_kernel(Ans1Args a, uint4* ent) {
+    const uint32_t slotId = blockIdx.x;
+    uint32_t b, n; const uint8_t* src; bool bad;
+    const uint32_t steps = knz_ans1_steps(a, slotId, b, n, src, bad);
+    if (steps == 0) return;
+    const uint32_t q = steps;
+    const uint32_t total = knz_ans1_padded_steps(steps) * 4;
+    const uint2* __restrict__ tab = a.tab + (size_t)slotId * 65536;
+    uint4* out = ent + (size_t)slotId * KNZ_ANS1_ENT_STRIDE;
+    for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < total; i += gridDim.y * 256) {
+        const uint32_t t = i >> 2, c = i & 3;
+        uint4 o; o.x = 0; o.y = 0xFFFFFFFFu; o.z = 0; o.w = 0;
+        if (t < steps) {
+            // step t of state c codes symbol qbase[q-1-t] in context qbase[q-2-t] (context 0 for the quarter's first symbol)
+            const uint8_t* qbase = src + (size_t)c * q;
+            const uint32_t sym = qbase[q - 1 - t];
+            const uint32_t ctx = (t + 1 < q) ? (uint32_t)qbase[q - 2 - t] : 0u;
+            const uint2 e = tab[(ctx << 8) | sym];
+            const uint32_t freq = e.x & 0xFFFu, bias = (e.x >> 12) & 0x1FFFu, sh = (e.x >> 25) & 0xFu;
+            o.x = e.y;
+            o.y = freq << 20;                                   // xMax = ((ANS_TOP >> 11) << 16) * freq
+            o.z = bias;
+            o.w = (((uint32_t)KNZ_ANS1_SCALE - freq) << 8) | sh;
+        }
+        out[i] = o;
+    }
+}
+
+// One wave per chunk; lanes 0..3 carry the 4 states. Per step the dependent chain is: compare with xMax, place the 16-bit
+// word (rank among the renormalising states via the ballot), the reciprocal multiply and the state update. The entries
+// stream in through three register buffers of 16 steps (two groups in flight), renormalisation words are staged in an LDS
+// ring and flushed by the whole wave: on gfx950 stores and loads share the in-order vmcnt counter, so a global store
+// inside the dependent loop would stall every following entry load.
+__global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a, const uint4* ent) {
+    __shared__ uint16_t s_ring[KNZ_ANS1_RING + 64];
     const int lane = threadIdx.x;
-    const int c = lane & 3;
-    const uint32_t slotId = blockIdx.x * 16 + (lane >> 2);
-    uint32_t b = 0, n = 0; const uint8_t* src = nullptr;
-    bool live = slotId < a.nslots && knz_ans1_chunk(a, slotId, b, n, src);
-    if (live && a.blk_status[b] != 0) live = false;
-    const uint32_t end4 = n & ~3u;
-    const uint32_t q = end4 >> 2;
-    bool bad = false;
-    if (live && n > 1 && q == 0) { bad = true; live = false; }         // 2..3 byte chunk: Go indexes block[-1] and panics
-    const bool coded = live && n > 1;                                   // encodeChunk: `else if len(block) > 1` (:353)
-    const uint2* __restrict__ tab = a.tab + (size_t)(slotId < a.nslots ? slotId : 0) * 65536;
-    uint8_t* slot = a.scratch + (size_t)(slotId < a.nslots ? slotId : 0) * KNZ_ANS1_SLOT;
+    const uint32_t slotId = blockIdx.x;
+    uint32_t b, n; const uint8_t* src; bool bad;
+    const uint32_t steps = knz_ans1_steps(a, slotId, b, n, src, bad);
+    const bool live = n != 0;
+    uint8_t* slot = a.scratch + (size_t)slotId * KNZ_ANS1_SLOT;
     uint8_t* payEnd = slot + KNZ_ANS1_PAY_OFF + KNZ_ANS1_PAY_CAP;
-    const uint32_t steps = coded ? q : 0;                               // q-1 context steps + the final context-0 step
-    uint32_t maxSteps = steps;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = wave_shfl(maxSteps, lane ^ d); maxSteps = o > maxSteps ? o : maxSteps; }
-    // quarter c is coded from its last symbol down to its first: i = (c+1)*q-1 ... c*q (state 3 ends at end4-1)
-    const uint8_t* __restrict__ qbase = src + (size_t)c * q;           // symbols of my quarter: qbase[0..q)
+    // lanes 4..63 mirror lanes 0..3 (same entries, same state, same LDS words): no divergence, no masked loads
+    const uint4* __restrict__ my = ent + (size_t)slotId * KNZ_ANS1_ENT_STRIDE + (size_t)(lane & 3);
+    const uint32_t below = (1u << (lane & 3)) - 1u;
     uint32_t st = 1u << 15;
-    uint32_t cnt = 0;
-    const int gshift = (lane >> 2) << 2;
-    // Three-stage software pipeline per lane: symbol bytes of group g+2 are loaded while the table entries of group g+1
-    // (whose addresses need the bytes loaded one iteration earlier) are in flight and group g runs the dependent state
-    // arithmetic. Neither the table nor the data fits L2 for 16 chunks per wave: both latencies must be hidden.
-    uint2 ecur[8], enext[8];
-    uint32_t bnext[9], bnext2[9];                                     // bytes q-1-t0 .. q-9-t0 of a group (index 8 = context of step 7)
-    auto load_bytes = [&](uint32_t t0, uint32_t* bytes) {
+    uint32_t cnt = 0, flushed = 0;
+    uint4 buf0[KNZ_ANS1_GROUP], buf1[KNZ_ANS1_GROUP], buf2[KNZ_ANS1_GROUP];
+    auto load_group = [&](uint32_t t0, uint4* e) {
 #pragma unroll
-        for (int j = 0; j < 9; j++) {
-            const uint32_t t = t0 + j;
-            bytes[j] = (t < q && t <= steps) ? (uint32_t)qbase[q - 1 - t] : 0u;    // t == q: the context of the quarter's first symbol is 0
+        for (int j = 0; j < KNZ_ANS1_GROUP; j++) e[j] = my[(size_t)(t0 + j) * 4];
+    };
+    auto run_group = [&](const uint4* e) {
+#pragma unroll
+        for (int j = 0; j < KNZ_ANS1_GROUP; j++) {
+            const bool x = st >= e[j].y;
+            const uint32_t bal = (uint32_t)wave_ballot(x) & 0xFu;
+            const uint32_t r = cnt + (uint32_t)__popc(bal & below);          // cnt counts from the last flush: no wrap
+            s_ring[x ? r : (uint32_t)(KNZ_ANS1_RING + (lane & 3))] = (uint16_t)st;   // word r of the descending stream
+            st = x ? (st >> 16) : st;
+            cnt += (uint32_t)__popc(bal);
+            // q = st / freq < 2^20 after the renormalisation (st < freq << 20): the product with 2048 - freq fits mul24
+            const uint32_t qq = (uint32_t)(((uint64_t)st * e[j].x) >> 32) >> (e[j].w & 31u);
+            st = st + e[j].z + knz_mul24(qq, e[j].w >> 8);
         }
     };
-    auto load_entries = [&](uint32_t t0, const uint32_t* bytes, uint2* e) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t t = t0 + j;
-            e[j].x = 0; e[j].y = 0;
-            if (t < steps) {
-                // step t codes symbol qbase[q-1-t] in context qbase[q-2-t] (context 0 for the quarter's first symbol)
-                const uint32_t ctx = (t + 1 < q) ? bytes[j + 1] : 0u;
-                e[j] = tab[(ctx << 8) | bytes[j]];
-            }
-        }
-    };
-    load_bytes(0, bnext);
-    load_entries(0, bnext, ecur);
-    load_bytes(8, bnext);
-    // Renormalisation words are staged in an LDS ring per chunk and flushed in bursts: on gfx950 stores and loads share
-    // the in-order vmcnt counter, a global store inside the dependent loop would stall every following table load.
-    __shared__ uint16_t s_ring[16][KNZ_ANS1_RING];
-    uint16_t* ring = s_ring[lane >> 2];
-    uint32_t flushed = 0;                                                // words already copied to the slot
-    for (uint32_t t0 = 0; t0 < maxSteps; t0 += 8) {
-        load_bytes(t0 + 16, bnext2);
-        load_entries(t0 + 8, bnext, enext);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t t = t0 + j;
-            const bool act = t < steps;
-            const uint2 e = ecur[j];
-            const uint32_t x = (act && st >= ((e.x & 0xFFFu) << 20)) ? 1u : 0u;       // xMax = ((ANS_TOP>>11)<<16)*freq
-            const uint64_t bal = wave_ballot(x != 0);
-            const uint32_t gb = (uint32_t)(bal >> gshift) & 0xFu;
-            if (x) {
-                const uint32_t r = cnt + (uint32_t)__popc(gb & ((1u << c) - 1u));
-                ring[r & (KNZ_ANS1_RING - 1)] = (uint16_t)st;                             // word r of the descending stream
-                st >>= 16;
-            }
-            cnt += (uint32_t)__popc(gb);
-            if (act) {
-                const uint32_t freq = e.x & 0xFFFu, bias = (e.x >> 12) & 0x1FFFu, sh = (e.x >> 25) & 0xFu;
-                const uint32_t qq = (uint32_t)(((uint64_t)st * e.y) >> (32 + sh));
-                st = st + bias + qq * ((uint32_t)KNZ_ANS1_SCALE - freq);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) ecur[j] = enext[j];
-#pragma unroll
-        for (int j = 0; j < 9; j++) bnext[j] = bnext2[j];
-        // flush when any chunk of the wave could overflow its ring within the next group (32 words)
-        const bool last = t0 + 8 >= maxSteps;
-        if (wave_ballot(cnt - flushed > KNZ_ANS1_RING - 64) != 0 || last) {
+    auto flush = [&](bool force) {
+        if (cnt > KNZ_ANS1_RING - 4 * 3 * KNZ_ANS1_GROUP || force) {                    // wave-uniform
             wave_sync();
-            for (uint32_t r = flushed + (uint32_t)c; r < cnt; r += 4) {                   // the 4 lanes of a chunk share the copy
-                const uint16_t wv = ring[r & (KNZ_ANS1_RING - 1)];
-                uint8_t* p = payEnd - 2 * ((size_t)r + 1);
+            for (uint32_t r = (uint32_t)lane; r < cnt; r += 64) {
+                const uint16_t wv = s_ring[r];
+                uint8_t* p = payEnd - 2 * ((size_t)flushed + r + 1);
                 p[0] = (uint8_t)(wv >> 8);
                 p[1] = (uint8_t)wv;
             }
-            flushed = cnt;
+            flushed += cnt;
+            cnt = 0;
             wave_sync();
         }
+    };
+    // The pipeline starts on neutral entries (two groups of no-ops) instead of a load prologue: every load of the kernel is
+    // then issued inside the loop in program order, which is what lets the compiler wait with vmcnt(32+) instead of vmcnt(0).
+#pragma unroll
+    for (int j = 0; j < KNZ_ANS1_GROUP; j++) { buf0[j].x = 0; buf0[j].y = 0xFFFFFFFFu; buf0[j].z = 0; buf0[j].w = 0; buf1[j] = buf0[j]; }
+    for (uint32_t t0 = 0; t0 < steps + 2 * KNZ_ANS1_GROUP && steps; t0 += 3 * KNZ_ANS1_GROUP) {
+        load_group(t0, buf2); run_group(buf0);
+        load_group(t0 + KNZ_ANS1_GROUP, buf0); run_group(buf1);
+        load_group(t0 + 2 * KNZ_ANS1_GROUP, buf1); run_group(buf2);
+        flush(false);
     }
-    const uint32_t s1 = wave_shfl(st, (lane & ~3) + 1), s2 = wave_shfl(st, (lane & ~3) + 2), s3 = wave_shfl(st, (lane & ~3) + 3);
-    if (bad && c == 0) a.blk_status[b] = KNZ_ERR_PROCESS_BLOCK;
-    if (live && c == 0) {
+    flush(true);
+    const uint32_t s1 = wave_shfl(st, 1), s2 = wave_shfl(st, 2), s3 = wave_shfl(st, 3);
+    if (bad && lane == 0) a.blk_status[b] = KNZ_ERR_PROCESS_BLOCK;
+    if (live && lane == 0) {
+        const uint32_t end4 = n & ~3u;
         const uint32_t tail = n & 3;
         for (uint32_t i = 0; i < tail; i++) payEnd[i] = src[end4 + i];
-        const uint32_t nbytes = 2 * cnt + tail;
+        const uint32_t nbytes = 2 * flushed + tail;
         uint32_t w[8];
         for (int i = 0; i < 8; i++) w[i] = 0;
         KnzBitWriter bw;
@@ -324,7 +341,7 @@ __global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a) {
         uint32_t* usrc = a.unit_src + (size_t)slotId * KNZ_UNITS_PER_CHUNK;
         ubits[1] = bw.pos;
         ubits[2] = 8 * nbytes;
-        usrc[2] = (uint32_t)(KNZ_ANS1_PAY_OFF + KNZ_ANS1_PAY_CAP - 2 * cnt);
+        usrc[2] = (uint32_t)(KNZ_ANS1_PAY_OFF + KNZ_ANS1_PAY_CAP - 2 * flushed);
     }
 }
 

@@ -264,7 +264,8 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
         } else if (cfg.entropy == KNZ_E_ANS1) {
             const uint32_t ns = nblocks * cpb;
             if (h->a1_freqs.reserve((size_t)ns * 65536 * 4) || h->a1_tab.reserve((size_t)ns * 65536 * 8) ||
-                h->a1_ctxhdr.reserve((size_t)ns * 256 * KNZ_ANS1_CTXHDR_BYTES + 64) || h->a1_ctxbits.reserve((size_t)ns * 256 * 4))
+                h->a1_ctxhdr.reserve((size_t)ns * 256 * KNZ_ANS1_CTXHDR_BYTES + 64) || h->a1_ctxbits.reserve((size_t)ns * 256 * 4) ||
+                h->a1_ent.reserve((size_t)ns * KNZ_ANS1_ENT_STRIDE * 16))
                 return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
             Ans1Args a;
             a.blk_off = h->blk_off.as<uint64_t>(); a.blk_len = h->blk_len.as<uint32_t>(); a.chunks_per_block = cpb; a.nslots = ns;
@@ -274,7 +275,8 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             hipLaunchKernelGGL(knz_ans1_hist_kernel, dim3(ns * 16), dim3(256), 0, st, a);
             hipLaunchKernelGGL(knz_ans1_stats_kernel, dim3(ns * 256), dim3(64), 0, st, a);
             hipLaunchKernelGGL(knz_ans1_merge_kernel, dim3(ns), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(knz_ans1_encode_kernel, dim3((ns + 15) / 16), dim3(64), 0, st, a);
+            hipLaunchKernelGGL(knz_ans1_expand_kernel, dim3(ns, 128), dim3(256), 0, st, a, h->a1_ent.as<uint4>());
+            hipLaunchKernelGGL(knz_ans1_encode_kernel, dim3(ns), dim3(64), 0, st, a, (const uint4*)h->a1_ent.as<uint4>());
         } else if (cfg.entropy == KNZ_E_ANS0) {
             Ans0Args a;
             a.data = nullptr; a.blk_off = h->blk_off.as<uint64_t>(); a.blk_len = h->blk_len.as<uint32_t>();

@@ -59,74 +59,162 @@ __global__ void knz_xf_prepare_kernel(CommitArgs a, uint64_t* out_ptr, int32_t* 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // SBRT forward
-__device__ __forceinline__ int knz_sbrt_q(uint32_t mode, int i, int p) {
+__host__ __device__ __forceinline__ int knz_sbrt_q(uint32_t mode, int i, int p) {
     // qc = ((i & mask1) + (p[c] & mask2)) >> shift   (SBRT.go:59-76,158)
     const int m1 = mode == 3 ? 0 : -1, m2 = mode == 1 ? 0 : -1, s = mode == 2 ? 1 : 0;
     return ((i & m1) + (p & m2)) >> s;
 }
 
-// The SBRT list (256 symbols ordered by rank) lives in REGISTERS, 4 consecutive ranks per lane: symbol, q and p of the
-// symbol at rank 4*lane+k. One list update (SBRT.go:155-172) is then a handful of wave-wide compares, ballots and a
-// one-position shift across lanes, at a cost that does not depend on how far the symbol moves (the scalar loop of the
-// reference costs two dependent LDS reads per position moved).
+// The SBRT list (256 symbols ordered by rank) lives in REGISTERS: register k of lane l holds symbol, q and p of the symbol
+// at rank 64*k + l. The list is always sorted by q (descending; q never decreases on an access, SBRT.go:158-168), so the
+// accessed symbol lands at rank j = #{x : q[x] > qc} and one update is: a scalar look-up of the old entry (v_readlane), one
+// wave-wide compare + popcount for j, and a one-lane DPP shift of the ranks j..r-1 -- a cost that does not depend on how far
+// the symbol moves (the scalar loop of the reference costs two dependent memory reads per position moved). After a BWT the
+// ranks are tiny, so nearly every access stays inside register 0 (ranks 0..63), and rank 0 only rewrites q/p of lane 0.
+// All arguments of the methods are wave-uniform (SGPR values): the control flow is scalar branches, never divergence.
+template <int MODE>
 struct SbrtWave {
     uint32_t s[4];
     int q[4], p[4];
 
+    static __device__ __forceinline__ int qf(int i, int pc) { return MODE == 1 ? i : (MODE == 2 ? ((i + pc) >> 1) : pc); }
+
+    __device__ __forceinline__ void init_identity(int lane) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { s[k] = 64u * (uint32_t)k + (uint32_t)lane; q[k] = 0; p[k] = 0; }
+    }
     __device__ __forceinline__ void load(const uint8_t* r2s, const int* qBySym, const int* pBySym, int lane) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const uint32_t c = r2s[4 * lane + k]; s[k] = c; q[k] = qBySym[c]; p[k] = pBySym[c]; }
+        for (int k = 0; k < 4; k++) { const uint32_t c = r2s[64 * k + lane]; s[k] = c; q[k] = qBySym[c]; p[k] = pBySym[c]; }
     }
-    // rank of symbol c (forward direction)
-    __device__ __forceinline__ uint32_t find(uint32_t c) const {
-        uint32_t r = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const uint64_t m = wave_ballot(s[k] == c); if (m) r = 4u * (uint32_t)(__ffsll((unsigned long long)m) - 1) + (uint32_t)k; }
-        return r;
+    __device__ __forceinline__ uint32_t top() const { return wave_bcast(s[0], 0); }
+    // `count` >= 1 consecutive accesses of the symbol at rank 0, the last one at time i: it stays on top (nothing above it)
+    __device__ __forceinline__ void touch_top(int i, uint32_t count) {
+        const int pc = count > 1 ? i - 1 : (int)wave_bcast((uint32_t)p[0], 0);
+        q[0] = (int)wave_writelane0((uint32_t)q[0], (uint32_t)qf(i, pc));
+        p[0] = (int)wave_writelane0((uint32_t)p[0], (uint32_t)i);
     }
-    // symbol at rank r (inverse direction)
-    __device__ __forceinline__ uint32_t at(uint32_t r) const {
-        const uint32_t L = r >> 2, k = r & 3;
-        const uint32_t a0 = wave_readlane(s[0], L), a1 = wave_readlane(s[1], L), a2 = wave_readlane(s[2], L), a3 = wave_readlane(s[3], L);
-        return k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : a3));
+    // access at time i of symbol c sitting at rank r, 0 <= r <= 63 (branch-free)
+    __device__ __forceinline__ void access_low(int i, uint32_t c, uint32_t r, int lane) {
+        const int qc = qf(i, (int)wave_readlane((uint32_t)p[0], r));
+        const uint32_t j = (uint32_t)__popcll(wave_ballot(q[0] > qc));      // sorted list: everything with q > qc sits above r
+        const bool moved = (uint32_t)lane - j - 1u < r - j;                   // j < lane <= r: one rank down
+        const bool ins = (uint32_t)lane == j;
+        const uint32_t sp = wave_shr1(s[0]), qp = wave_shr1((uint32_t)q[0]), pp = wave_shr1((uint32_t)p[0]);
+        s[0] = ins ? c : (moved ? sp : s[0]);
+        q[0] = ins ? qc : (moved ? (int)qp : q[0]);
+        p[0] = ins ? i : (moved ? (int)pp : p[0]);
     }
-    // access of the symbol c sitting at rank r at time i
-    __device__ __forceinline__ void update(uint32_t mode, int i, uint32_t c, uint32_t r, int lane) {
-        const uint32_t L = r >> 2, k = r & 3;
-        const int p0 = (int)wave_readlane((uint32_t)p[0], L), p1 = (int)wave_readlane((uint32_t)p[1], L);
-        const int p2 = (int)wave_readlane((uint32_t)p[2], L), p3 = (int)wave_readlane((uint32_t)p[3], L);
-        const int pc = k == 0 ? p0 : (k == 1 ? p1 : (k == 2 ? p2 : p3));
-        const int qc = knz_sbrt_q(mode, i, pc);
-        // j = 1 + highest rank x < r with q[x] > qc (the symbol stops below it, :163-168)
-        int j = 0;
+    // rare: the symbol comes from rank 64+
+    __device__ __forceinline__ void access_high(int i, uint32_t c, uint32_t r, int lane) {
+        const uint32_t kr = r >> 6, l = r & 63;
+        const int pc = (int)(kr == 1 ? wave_readlane((uint32_t)p[1], l) : (kr == 2 ? wave_readlane((uint32_t)p[2], l) : wave_readlane((uint32_t)p[3], l)));
+        const int qc = qf(i, pc);
+        uint32_t j = 0;
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            const uint32_t x = 4u * (uint32_t)lane + (uint32_t)kk;
-            const uint64_t m = wave_ballot(x < r && q[kk] > qc);
-            if (m) { const int cand = 4 * (63 - __clzll((long long)m)) + kk + 1; j = cand > j ? cand : j; }
-        }
-        if ((uint32_t)j == r) {                                   // stays in place (always the case at rank 0)
-            if ((uint32_t)lane == L) {
+        for (int k = 0; k < 4; k++) j += (uint32_t)__popcll(wave_ballot(q[k] > qc));
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) if ((uint32_t)kk == k) { q[kk] = qc; p[kk] = i; }
+        for (int k = 3; k >= 0; k--) {                                            // high registers first: register k-1 is still old
+            const uint32_t x = 64u * (uint32_t)k + (uint32_t)lane;
+            const bool moved = x - j - 1u < r - j;
+            const bool ins = x == j;
+            uint32_t sp = wave_shr1(s[k]), qp = wave_shr1((uint32_t)q[k]), pp = wave_shr1((uint32_t)p[k]);
+            if (k > 0) {
+                const uint32_t s63 = wave_bcast(s[k > 0 ? k - 1 : 0], 63), q63 = wave_bcast((uint32_t)q[k > 0 ? k - 1 : 0], 63), p63 = wave_bcast((uint32_t)p[k > 0 ? k - 1 : 0], 63);
+                if (lane == 0) { sp = s63; qp = q63; pp = p63; }
             }
-            return;
+            s[k] = ins ? c : (moved ? sp : s[k]);
+            q[k] = ins ? qc : (moved ? (int)qp : q[k]);
+            p[k] = ins ? i : (moved ? (int)pp : p[k]);
         }
-        // ranks j..r-1 move down by one, c is inserted at rank j
-        const uint32_t sPrev = wave_shfl(s[3], lane - 1);
-        const int qPrev = (int)wave_shfl((uint32_t)q[3], lane - 1);
-        const int pPrev = (int)wave_shfl((uint32_t)p[3], lane - 1);
+    }
+    __device__ __forceinline__ uint32_t find_high(uint32_t c) const {
+        uint64_t m = wave_ballot(s[1] == c);
+        if (m) return 64u + (uint32_t)(__ffsll((unsigned long long)m) - 1);
+        m = wave_ballot(s[2] == c);
+        if (m) return 128u + (uint32_t)(__ffsll((unsigned long long)m) - 1);
+        m = wave_ballot(s[3] == c);
+        return 192u + (uint32_t)(__ffsll((unsigned long long)m) - 1);
+    }
+    __device__ __forceinline__ uint32_t at_high(uint32_t r) const {
+        const uint32_t k = r >> 6, l = r & 63;
+        if (k == 1) return wave_readlane(s[1], l);
+        if (k == 2) return wave_readlane(s[2], l);
+        return wave_readlane(s[3], l);
+    }
+    // one symbol through whichever path it needs (used off the hot loop only)
+    template <bool FWD>
+    __device__ __forceinline__ uint32_t step_any(uint32_t v, int t, int lane) {
+        uint32_t o;
+        if (FWD) {
+            const uint64_t hit = wave_ballot(s[0] == v);
+            if (hit) { o = (uint32_t)(__ffsll((unsigned long long)hit) - 1); access_low(t, v, o, lane); }
+            else { o = find_high(v); access_high(t, v, o, lane); }
+        } else {
+            if (v < 64) { o = wave_readlane(s[0], v); access_low(t, o, v, lane); }
+            else { o = at_high(v); access_high(t, o, v, lane); }
+        }
+        return o;
+    }
+    // 4096-byte LDS tile, walked 256 symbols per pass: lane l holds input word l of the pass and v_readlane feeds the
+    // scalar walk. Runs of words made of rank 0 only (forward: of the symbol on top) are found with one ballot per pass and
+    // cost O(1) each; every other symbol takes the branch-free access_low path. The hot loop works on whole words and is
+    // left (flag `stop`) when a symbol needs registers 1..3, so that the rare path adds no register shuffling to it.
+    template <bool FWD>
+    __device__ __forceinline__ void run_tile(const uint8_t* s_in, uint8_t* s_out, uint32_t cnt, int i0, int lane) {
+        for (uint32_t base = 0; base < cnt; base += 256) {
+            const uint32_t inw = *(const uint32_t*)(s_in + base + 4 * lane);
+            const uint32_t m = min(256u, cnt - base);                  // symbols of this pass
+            const uint32_t fullWords = m >> 2;
+            uint32_t wi = 0;
+            for (;;) {
+                uint32_t stop = 4;                                     // index of the symbol that stopped the hot loop
+                while (wi < fullWords) {
+                    // words equal to 4 x (rank 0 | top symbol), starting at word wi
+                    const uint32_t pat = FWD ? top() * 0x01010101u : 0u;
+                    const uint64_t zm = wave_ballot(inw == pat && (uint32_t)lane < fullWords) >> wi;
+                    const uint32_t run = zm == ~0ull ? 64u : (uint32_t)(__ffsll((unsigned long long)~zm) - 1);
+                    if (run) {
+                        touch_top(i0 + (int)(base + 4 * (wi + run) - 1), 4 * run);
+                        const uint32_t fill = FWD ? 0u : top() * 0x01010101u;
+                        if ((uint32_t)lane - wi < run) *(uint32_t*)(s_out + base + 4 * lane) = fill;
+                        wi += run;
+                        continue;
+                    }
+                    const uint32_t four = wave_readlane(inw, wi);
+                    const int t = i0 + (int)(base + 4 * wi);
+                    uint32_t outw = 0;
 #pragma unroll
-        for (int kk = 3; kk >= 0; kk--) {
-            const uint32_t x = 4u * (uint32_t)lane + (uint32_t)kk;
-            const bool moved = x > (uint32_t)j && x <= r;
-            const bool ins = x == (uint32_t)j;
-            const uint32_t sFrom = kk > 0 ? s[kk > 0 ? kk - 1 : 0] : sPrev;
-            const int qFrom = kk > 0 ? q[kk > 0 ? kk - 1 : 0] : qPrev;
-            const int pFrom = kk > 0 ? p[kk > 0 ? kk - 1 : 0] : pPrev;
-            s[kk] = ins ? c : (moved ? sFrom : s[kk]);
-            q[kk] = ins ? qc : (moved ? qFrom : q[kk]);
-            p[kk] = ins ? i : (moved ? pFrom : p[kk]);
+                    for (int u = 0; u < 4; u++) {
+                        if (stop == 4) {
+                            const uint32_t v = (four >> (8 * u)) & 0xFF;
+                            uint32_t o;
+                            bool ok;
+                            uint64_t hit = 0;
+                            if (FWD) { hit = wave_ballot(s[0] == v); ok = hit != 0; } else ok = v < 64;
+                            if (!ok) stop = (uint32_t)u;
+                            else {
+                                if (FWD) { o = (uint32_t)(__ffsll((unsigned long long)hit) - 1); access_low(t + u, v, o, lane); }
+                                else { o = wave_readlane(s[0], v); access_low(t + u, o, v, lane); }
+                                outw |= o << (8 * u);
+                            }
+                        }
+                    }
+                    *(uint32_t*)(s_out + base + 4 * wi) = outw;        // same word from every lane
+                    if (stop != 4) break;
+                    wi++;
+                }
+                if (stop == 4) break;
+                const uint32_t four = wave_readlane(inw, wi);
+                for (uint32_t u = stop; u < 4; u++)
+                    s_out[base + 4 * wi + u] = (uint8_t)step_any<FWD>((four >> (8 * u)) & 0xFF, i0 + (int)(base + 4 * wi + u), lane);
+                wi++;
+            }
+            if (m & 3) {
+                const uint32_t four = wave_readlane(inw, fullWords);
+                for (uint32_t u = 0; u < (m & 3); u++)
+                    s_out[base + 4 * fullWords + u] = (uint8_t)step_any<FWD>((four >> (8 * u)) & 0xFF, i0 + (int)(base + 4 * fullWords + u), lane);
+            }
         }
     }
 };
@@ -171,6 +259,7 @@ __global__ __launch_bounds__(256) void knz_sbrt_carry_kernel(XfArgs a) {
 }
 
 // 3) replay of the list update inside each segment from the reconstructed state (SBRT.go:155-172)
+template <int MODE>
 __global__ __launch_bounds__(64) void knz_sbrt_apply_kernel(XfArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[KNZ_SEG];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[KNZ_SEG];
@@ -209,27 +298,15 @@ __global__ __launch_bounds__(64) void knz_sbrt_apply_kernel(XfArgs a) {
         s_r2s[r] = (uint8_t)d;
     }
     wave_sync();
-    SbrtWave w;
+    SbrtWave<MODE> w;
     w.load(s_r2s, s_q, s_p, lane);
-    for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
-        const uint32_t four = *(const uint32_t*)(s_in + k0);                 // 4 symbols, uniform LDS read
-        uint32_t outw = 0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (k0 + u < cnt) {
-                const uint32_t c = (four >> (8 * u)) & 0xFF;
-                const uint32_t r = w.find(c);
-                outw |= r << (8 * u);
-                w.update(a.mode, (int)(lo + k0 + u), c, r, lane);
-            }
-        }
-        if (lane == 0) *(uint32_t*)(s_out + k0) = outw;
-    }
+    w.template run_tile<true>(s_in, s_out, cnt, (int)lo, lane);
     wave_sync();
     for (uint32_t i = lane; i < cnt; i += 64) dst[lo + i] = s_out[i];
 }
 
 // SBRT inverse: one chain per block (SBRT.go:204-223), tiles staged through LDS
+template <int MODE>
 __global__ __launch_bounds__(64) void knz_sbrt_inverse_kernel(XfArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[4096];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[4096];
@@ -241,28 +318,14 @@ __global__ __launch_bounds__(64) void knz_sbrt_inverse_kernel(XfArgs a) {
     if (n > a.out_cap) return;
     const uint8_t* src = (const uint8_t*)a.in_ptr[b];
     uint8_t* dst = (uint8_t*)a.out_ptr[b];
-    SbrtWave w;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { w.s[k] = 4u * (uint32_t)lane + (uint32_t)k; w.q[k] = 0; w.p[k] = 0; }
+    SbrtWave<MODE> w;
+    w.init_identity(lane);
     for (uint32_t base = 0; base < n; base += 4096) {
         const uint32_t cnt = min(4096u, n - base);
         wave_sync();
         for (uint32_t i = lane; i < cnt; i += 64) s_in[i] = src[base + i];
         wave_sync();
-        for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
-            const uint32_t four = *(const uint32_t*)(s_in + k0);
-            uint32_t outw = 0;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (k0 + u < cnt) {
-                    const uint32_t r = (four >> (8 * u)) & 0xFF;
-                    const uint32_t c = w.at(r);
-                    outw |= c << (8 * u);
-                    w.update(a.mode, (int)(base + k0 + u), c, r, lane);
-                }
-            }
-            if (lane == 0) *(uint32_t*)(s_out + k0) = outw;
-        }
+        w.template run_tile<false>(s_in, s_out, cnt, (int)base, lane);
         wave_sync();
         for (uint32_t i = lane; i < cnt; i += 64) dst[base + i] = s_out[i];
     }

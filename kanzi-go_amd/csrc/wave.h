@@ -28,8 +28,22 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// value of lane-1 (lane 0 reads 0): one DPP move, no LDS crossbar
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xF, 0xF, true); }
+// v with lane 0 replaced by the wave-uniform value `val`: v_writelane_b32 (one SGPR + an inline-constant lane select)
+__device__ __forceinline__ uint32_t wave_writelane0(uint32_t v, uint32_t val) {
+    const int sv = __builtin_amdgcn_readfirstlane((int)val);
+    asm("v_writelane_b32 %0, %1, 0" : "+v"(v) : "s"(sv));
+    return v;
+}
+// tells the compiler that v is the same in every lane (moves it to an SGPR)
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// full-rate 24 x 24 -> 32 bit multiply (v_mul_u32_u24): both factors must be < 2^24
+__device__ __forceinline__ uint32_t knz_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 #else
 // ------------------------------------------------------------------ emulator (tests only)
+inline uint32_t knz_mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+inline uint32_t wave_uniform(uint32_t v) { return v; }
 inline int lane_id() { return hipemu::lane(); }
 inline uint64_t wave_shfl64(uint64_t v, int src) {
     uint64_t* s = hipemu::wave_slots();
@@ -52,6 +66,8 @@ inline uint64_t wave_ballot(bool p) {
 inline uint32_t wave_bcast(uint32_t v, int src) { return wave_shfl(v, src); }
 inline uint32_t wave_readlane(uint32_t v, uint32_t src) { return wave_shfl(v, (int)src); }
 inline void wave_sync() { hipemu::wave_barrier(); }
+inline uint32_t wave_shr1(uint32_t v) { const uint32_t r = wave_shfl(v, hipemu::lane() - 1); return hipemu::lane() == 0 ? 0u : r; }
+inline uint32_t wave_writelane0(uint32_t v, uint32_t val) { return hipemu::lane() == 0 ? val : v; }
 #endif
 
 // inclusive prefix sum across the wave (log-step shuffles)

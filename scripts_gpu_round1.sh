@@ -1,8 +1,10 @@
 #!/bin/bash
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+cd $R
+timeout 900 python -m pytest tests/test_parity_gpu.py -x -q -k "ANS1 or RANK or MTFT or config4 or transforms" > gpurun_out/pytest_gpu.log 2>&1
+tail -3 gpurun_out/pytest_gpu.log
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify > $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch.json 2> $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch.err
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify > $GRAFT_REPO_ROOT/gpurun_out/pmc_write.json 2> $GRAFT_REPO_ROOT/gpurun_out/pmc_write.err
-timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof.err
-tail -2 $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bwt -o r1 -- python $R/bench.py --config bwt --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_bench_bwt.json 2> $R/gpurun_out/prof_bwt.err
+tail -1 $R/gpurun_out/prof_bench_bwt.json
