@@ -128,6 +128,11 @@ int knz_entropy_decode(void* handle, uint32_t type, const uint8_t* bits, uint64_
 enum { KNZ_STAGE_TRANSFORM = 0, KNZ_STAGE_ENTROPY = 1, KNZ_STAGE_LAYOUT = 2, KNZ_STAGE_GATHER = 3, KNZ_STAGE_COUNT = 4 };
 int knz_last_timing(void* handle, float* stage_ms, int cap);
 
+/* Diagnostic counters of the last device batch. KNZ_COUNTER_HUF_SERIAL_CHUNKS: Huffman chunks the wave-parallel decoder
+ * handed back to the serial (reference-order) decoder; 0 for any stream a kanzi encoder wrote. Returns 0 or an error code. */
+enum { KNZ_COUNTER_HUF_SERIAL_CHUNKS = 0 };
+int knz_last_counter(void* handle, int id, uint64_t* value);
+
 /* 1 when a transform/entropy id has a device implementation in this build */
 int knz_supports(uint64_t transform, uint32_t entropy);
 

@@ -102,6 +102,8 @@ def load_library(path=None):
     L.knz_entropy_encode.argtypes = [vp, C.c_uint32, u8p, C.c_uint32, u8p, C.c_uint64, u64p]
     L.knz_entropy_decode.argtypes = [vp, C.c_uint32, u8p, C.c_uint64, u8p, C.c_uint32, u64p]
     L.knz_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    L.knz_last_counter.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
+    L.knz_last_counter.restype = C.c_int
     L.knz_supports.argtypes = [C.c_uint64, C.c_uint32]
     _LIB, _LIB_PATH = L, path
     return L
@@ -169,6 +171,11 @@ class Codec:
         out = C.c_uint64()
         self._chk(self.L.knz_dev_assemble(self.h, header_input_size, segs, bits, n, d_dst, dst_cap, C.byref(out), stream))
         return out.value
+
+    def last_counter(self, cid=0):
+        v = C.c_uint64()
+        self._chk(self.L.knz_last_counter(self.h, cid, C.byref(v)))
+        return v.value
 
     def last_timing(self):
         t = (C.c_float * 4)()

@@ -17,8 +17,10 @@ struct KnzStreamReader {
     uint64_t next;        // next word index to load
     uint64_t win;         // left aligned
     uint32_t navail;      // valid bits in win
-    uint32_t pre;         // word `next`, loaded one refill ahead so that its latency overlaps the decoding of ~32 bits
-    __device__ __forceinline__ uint32_t ld(uint64_t i) const { return i < nwords ? knz_bswap32(words[i]) : 0u; }
+    uint32_t pre;         // word `next` as loaded (little endian), fetched one refill ahead. It is byte-swapped only when it
+                          // enters the window: touching it earlier would put the s_waitcnt right behind the load.
+    __device__ __forceinline__ uint32_t ld_raw(uint64_t i) const { return i < nwords ? words[i] : 0u; }
+    __device__ __forceinline__ uint32_t ld(uint64_t i) const { return knz_bswap32(ld_raw(i)); }
     __device__ __forceinline__ void init(const uint8_t* base, uint64_t nbytes, uint64_t bitpos) {
         words = (const uint32_t*)base;
         nwords = (nbytes + 3) >> 2;
@@ -28,13 +30,14 @@ struct KnzStreamReader {
         win <<= off;
         navail = 64 - off;
         next = q + 2;
-        pre = ld(next);
+        pre = ld_raw(next);
     }
     __device__ __forceinline__ void refill() {
-        if (navail <= 32) { win |= (uint64_t)pre << (32 - navail); navail += 32; next++; pre = ld(next); }
+        if (navail <= 32) { win |= (uint64_t)knz_bswap32(pre) << (32 - navail); navail += 32; next++; pre = ld_raw(next); }
     }
     __device__ __forceinline__ uint32_t peek(uint32_t n) { refill(); return (uint32_t)(win >> (64 - n)); } // 1..32
     __device__ __forceinline__ void skip(uint32_t n) { refill(); win <<= n; navail -= n; }                 // 0..32
+    __device__ __forceinline__ void consume(uint32_t n) { win <<= n; navail -= n; }                        // right after peek(>= n)
     __device__ __forceinline__ uint32_t read(uint32_t n) { uint32_t v = peek(n); win <<= n; navail -= n; return v; }
     __device__ __forceinline__ uint64_t tell() const { return (next << 5) - navail; }
     __device__ __forceinline__ void seek(uint64_t bitpos) { init((const uint8_t*)words, nwords << 2, bitpos); }
@@ -192,132 +195,6 @@ __device__ __forceinline__ uint32_t knz_expg_lut_entry(uint32_t w) {
     return (codes << 4) | pos;
 }
 
-// One wave per block, the serial walk runs on lane 0 only: putting several blocks on the lanes of one wave makes
-// their data-dependent loops diverge and the wave then pays for the union of all paths.
-__global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs a) {
-    __shared__ uint8_t s_lut[1 << KNZ_EXPG_WIN];
-    for (uint32_t i = threadIdx.x; i < (1u << KNZ_EXPG_WIN); i += 64) s_lut[i] = (uint8_t)knz_expg_lut_entry(i);
-    wave_sync();
-    const uint32_t b = blockIdx.x;
-    if (b >= a.nblocks) return;
-    const bool writer = threadIdx.x == 0;            // every lane runs the (uniform) parse, lane 0 stores the results
-    KnzWaveReader r;
-    const uint64_t start = a.blk_bit[b];
-    const uint64_t end = start + a.blk_bits[b];
-    // the block-local stream is its own bitstream in the reference (r = (read+7)>>3 bytes): reads past `end`
-    // rounded up to a byte are an EOS panic there; checked below per chunk
-    r.init(a.stream, a.nbytes, start);
-    int32_t status = 0;
-    uint32_t mode = 0, skipFlags = 0, preLen = a.given_len;
-    uint32_t entropy = a.entropy;
-    uint64_t ck = 0;
-    if (!a.payload_only) {
-        mode = r.read(8);
-        if (mode & 0x80) { entropy = KNZ_E_NONE; skipFlags = 0xFF; }   // copy block: no transform runs (device convention)
-        else if (mode & 0x10) skipFlags = r.read(8);
-        else skipFlags = ((mode << 4) | 0x0F) & 0xFF;
-        const uint32_t dataSize = 1 + ((mode >> 5) & 3);
-        preLen = r.read(8 * dataSize);
-        uint64_t maxLen = (uint64_t)a.block_size + a.block_size / 2;   // blockLength + blockLength/2 (:1893)
-        if (maxLen < 2048) maxLen = 2048;
-        if (maxLen > (1u << 30)) maxLen = 1u << 30;
-        if (preLen == 0 || preLen > maxLen) status = KNZ_ERR_BLOCK_SIZE;
-        if (a.checksum_bits == 32) ck = r.read(32);
-        else if (a.checksum_bits == 64) { ck = (uint64_t)r.read(32) << 32; ck |= r.read(32); }
-    }
-    if (writer) {
-        a.blk_pre_len[b] = preLen;
-        a.blk_mode[b] = (uint8_t)mode;
-        a.blk_skip[b] = (uint8_t)skipFlags;
-        a.blk_cksum[b] = ck;
-    }
-    const uint64_t limit = start + (((a.blk_bits[b] + 7) >> 3) << 3);
-    const uint32_t cpb = a.chunks_per_block;
-    if (status == 0) {
-        const uint32_t chunkSize = (a.entropy == KNZ_E_ANS1 || a.entropy == KNZ_E_FPAQ) ? (4u << 20) : (uint32_t)KNZ_HUF_CHUNK;
-        const uint32_t nchunks = (preLen + chunkSize - 1) / chunkSize;
-        if (nchunks > cpb) status = KNZ_ERR_BLOCK_SIZE;
-        for (uint32_t k = 0; k < nchunks && status == 0; k++) {
-            const uint32_t sz = min(chunkSize, preLen - k * chunkSize);
-            if (writer) a.chunk_bit[(size_t)b * cpb + k] = r.tell();
-            if (entropy == KNZ_E_NONE || (entropy == KNZ_E_HUFFMAN && sz < 32) || ((entropy == KNZ_E_ANS0 || entropy == KNZ_E_ANS1) && preLen <= 32)) {
-                r.seek(r.tell() + 8ull * sz);                          // raw bytes (HuffmanCodec.go:769-771, ANSRangeCodec.go:720-723)
-            } else if (entropy == KNZ_E_FPAQ) {                       // FPAQDecoder.Read :357-377
-                const uint32_t szb = knz_read_varint(r);
-                if ((int32_t)szb < 0 || (uint64_t)szb >= 2ull * preLen) status = KNZ_ERR_PROCESS_BLOCK;
-                r.seek(r.tell() + 56 + 8ull * szb);
-            } else if (entropy == KNZ_E_ANS1) {
-                uint32_t lr; int total;
-                if (!knz_ans1_parse_header(r, nullptr, lr, total) || total == 0) { status = KNZ_ERR_PROCESS_BLOCK; break; }
-                const uint32_t szb = knz_read_varint(r);
-                if (szb >= (1u << 27)) status = KNZ_ERR_PROCESS_BLOCK;
-                r.seek(r.tell() + 128 + 8ull * szb);
-            } else if (entropy == KNZ_E_ANS0) {
-                // decodeHeader (ANSRangeCodec.go:605-710) far enough to find the end of the chunk
-                const uint32_t lr = 8 + r.read(3);
-                uint32_t llr = 3;
-                while ((1u << llr) <= lr) llr++;
-                uint32_t count;
-                if (r.read(1) == 0) count = r.read(1) == 1 ? 0 : 256;
-                else {
-                    uint32_t lastMask = r.read(5);
-                    count = 0;
-                    for (uint32_t m = 0; m <= lastMask; m++) count += (uint32_t)__popc(r.read(8));
-                }
-                if (count == 0) { status = KNZ_ERR_PROCESS_BLOCK; break; }
-                const uint32_t chk = count < 64 ? 6 : 8;
-                for (uint32_t i = 1; i < count; i += chk) {
-                    const uint32_t logMax = r.read(llr);
-                    const uint32_t endj = min(i + chk, count);
-                    if (logMax > 16) { status = KNZ_ERR_PROCESS_BLOCK; break; }
-                    r.seek(r.tell() + (uint64_t)(endj - i) * logMax);
-                }
-                if (count > 1 && status == 0) {
-                    const uint32_t szb = knz_read_varint(r);
-                    if (szb >= (1u << 27)) status = KNZ_ERR_PROCESS_BLOCK;
-                    r.seek(r.tell() + 128 + 8ull * szb);
-                }
-            } else {
-                // alphabet (EntropyUtils.go:71-119)
-                uint32_t count;
-                if (r.read(1) == 0) {
-                    if (r.read(1) == 1) { status = KNZ_ERR_PROCESS_BLOCK; break; }  // empty alphabet: Read returns short
-                    count = 256;
-                } else {
-                    uint32_t lastMask = r.read(5);
-                    count = 0;
-                    for (uint32_t bitsLeft = 8 * (lastMask + 1); bitsLeft > 0;) {
-                        const uint32_t take = bitsLeft > 32 ? 32 : bitsLeft;
-                        count += (uint32_t)__popc(r.read(take));
-                        bitsLeft -= take;
-                    }
-                    if (count == 0) { status = KNZ_ERR_PROCESS_BLOCK; break; }
-                }
-                for (uint32_t i = 0; i < count;) {
-                    const uint32_t e = s_lut[r.peek(KNZ_EXPG_WIN)];
-                    const uint32_t nc = e >> 4;
-                    if (nc == 0 || i + nc > count) { knz_skip_expg(r); i++; }
-                    else { r.skip(e & 15); i += nc; }
-                }
-                if (count > 1) {
-                    uint64_t fb = 0;
-                    for (int j = 0; j < 4; j++) {
-                        uint32_t v = knz_read_varint(r);
-                        if ((int32_t)v < 0) status = KNZ_ERR_PROCESS_BLOCK;
-                        fb += v;
-                    }
-                    r.seek(r.tell() + fb + 8ull * (sz & 3));
-                }
-            }
-            if (r.tell() > limit) status = KNZ_ERR_PROCESS_BLOCK;       // ran past the block payload
-        }
-    }
-    if (writer) {
-        a.blk_status[b] = status;
-        a.blk_end_bit[b] = r.tell();
-    }
-}
-
 struct HufDecArgs {
     const uint8_t* stream; uint64_t nbytes;
     const uint32_t* blk_pre_len;
@@ -330,7 +207,9 @@ struct HufDecArgs {
     int32_t* blk_status;
 };
 
-__global__ __launch_bounds__(64) void knz_huf_decode_kernel(HufDecArgs a) {
+// Serial form (4 lanes, count-driven like decodeChunkV6). `only` != nullptr: handle just the chunks the parallel kernel
+// (huffman_par.hip) handed back.
+__global__ __launch_bounds__(64) void knz_huf_decode_kernel(HufDecArgs a, const uint8_t* only) {
     __shared__ uint16_t s_table[1 << KNZ_HUF_MAXLEN];
     __shared__ uint8_t s_len[256];
     __shared__ uint8_t s_alpha[256];
@@ -342,6 +221,7 @@ __global__ __launch_bounds__(64) void knz_huf_decode_kernel(HufDecArgs a) {
     __shared__ uint64_t s_tailpos;
 
     const int lane = threadIdx.x;
+    if (only && !only[blockIdx.x]) return;
     const uint32_t cpb = a.chunks_per_block;
     const uint32_t b = blockIdx.x / cpb, k = blockIdx.x % cpb;
     const uint32_t preLen = a.blk_pre_len[b];
@@ -458,16 +338,16 @@ __global__ __launch_bounds__(64) void knz_huf_decode_kernel(HufDecArgs a) {
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)];
-                    r.skip(val & 0xFF);
+                    r.consume(val & 0xFF);
                     out |= (val >> 8) << (8 * u);
                 }
                 *(uint32_t*)(d + i) = out;
             }
-            for (; i < F; i++) { const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)]; r.skip(val & 0xFF); d[i] = (uint8_t)(val >> 8); }
+            for (; i < F; i++) { const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)]; r.consume(val & 0xFF); d[i] = (uint8_t)(val >> 8); }
         } else {
             for (uint32_t i = 0; i < F; i++) {
                 const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)];
-                r.skip(val & 0xFF);
+                r.consume(val & 0xFF);
                 d[i] = (uint8_t)(val >> 8);
             }
         }

@@ -1,0 +1,606 @@
+// Wave-parallel pieces of the Huffman decode path (gfx950). The serial forms in huffman_dec.hip stay as the reference-exact
+// fallback for anything unusual (non-canonical Exp-Golomb encodings a Go encoder never writes, inconsistent fragments).
+//
+//   knz_huf_parse_header_wave   the chunk header (alphabet + signed Exp-Golomb code-length deltas + 4 varints,
+//                               HuffmanCodec.go:620-657, EntropyUtils.go:71-119, ExpGolombCodec.go:159-190) parsed by all 64
+//                               lanes: lane l owns 32 bits of the delta section, assumes a code boundary at its first bit,
+//                               and the lanes hand each other their exit offsets until nothing moves (Exp-Golomb codes
+//                               re-synchronise within a few bits, so this takes 2-3 rounds instead of 256 serial codes).
+//   knz_huf_decode_par_kernel   one wave per 16 KiB chunk; every fragment bit string is cut into 16 equal sub-ranges, one per
+//                               lane (decodeChunkV6 :832-969 runs 4 serial decoders). A lane starts on a guessed boundary,
+//                               decodes to the end of its sub-range and passes the bit position it stopped at to its
+//                               neighbour; Huffman codes self-synchronise, so after one more round every lane starts on a
+//                               true code boundary (verified: the hand-over positions must be a fixed point, the symbol
+//                               counts must add up to the fragment length, the last lane must end on the last bit).
+#include "bits.h"
+
+#ifdef KNZ_PROFILE_PHASES
+__device__ unsigned long long g_knz_prof[32];
+#define KNZ_PROF_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define KNZ_PROF_ADD(i, a, b) do { if (threadIdx.x == 0) atomicAdd(&g_knz_prof[i], (b) - (a)); } while (0)
+#define KNZ_PROF_INC(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_knz_prof[i], (unsigned long long)(v)); } while (0)
+#else
+#define KNZ_PROF_INC(i, v)
+#define KNZ_PROF_T(var)
+#define KNZ_PROF_ADD(i, a, b)
+#endif
+
+#define KNZ_HUF_SYNC_BITS 192        // look-back of the boundary search: ~20 codes, Huffman codes re-synchronise well within
+#define KNZ_HW_WORDS 136              // header window: 128 words + padding for the 64-bit look-ahead
+
+struct KnzHufHdr {
+    uint32_t count;                   // alphabet size
+    uint32_t fb[4];                   // fragment bit counts (count > 1)
+    uint32_t end;                     // bit offset (inside the window) just past the header
+    uint32_t status;                  // 0 ok, 1 unusual encoding -> serial parser, 2 invalid (ERR_PROCESS_BLOCK)
+};
+
+// 32 bits at bit offset `bit` of a window of BE words held in LDS
+__device__ __forceinline__ uint32_t knz_win32(const uint32_t* w, uint32_t bit) {
+    const uint32_t i = bit >> 5, o = bit & 31;
+    const uint32_t hi = w[i], lo = w[i + 1];
+    return o ? ((hi << o) | (lo >> (32 - o))) : hi;
+}
+
+// bits [pos, pos + 32) of the 64-bit window {hi, lo}, pos in 0..31
+__device__ __forceinline__ uint32_t knz_top32(uint32_t hi, uint32_t lo, uint32_t pos) {
+    return pos ? ((hi << pos) | (lo >> (32 - pos))) : hi;
+}
+
+// w: window of BE words (LDS), h0: bit offset of the chunk header inside it (< 32). All 64 lanes
+// of ONE wave call it; the result is wave-uniform. WANT_LEN: also fill s_alpha[0..count) and s_len[symbol] (zeroed by the
+// caller).
+template <bool WANT_LEN>
+__device__ __forceinline__ KnzHufHdr knz_huf_parse_header_wave(const uint32_t* w, uint32_t h0, uint8_t* s_alpha, uint8_t* s_len, int lane) {
+    KNZ_PROF_T(pA);
+    KnzHufHdr h;
+    h.count = 0; h.end = 0; h.status = 0;
+    h.fb[0] = h.fb[1] = h.fb[2] = h.fb[3] = 0;
+    // ---- alphabet (EntropyUtils.go:71-119) ------------------------------------------------------------------------------
+    const uint32_t b0 = wave_uniform(knz_win32(w, h0));
+    uint32_t e0, count;
+    if ((b0 >> 31) == 0) {
+        if ((b0 >> 30) & 1) { h.status = 2; return h; }                 // empty alphabet
+        count = 256;
+        e0 = h0 + 2;
+        if (WANT_LEN) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) s_alpha[64 * k + lane] = (uint8_t)(64 * k + lane);
+        }
+    } else {
+        const uint32_t lastMask = (b0 >> 26) & 31;
+        e0 = h0 + 6 + 8 * (lastMask + 1);
+        const uint32_t byte = (uint32_t)lane <= lastMask ? (knz_win32(w, h0 + 6 + 8 * (uint32_t)lane) >> 24) : 0u;
+        const uint32_t pc = (uint32_t)__popc(byte);
+        const uint32_t incl = wave_scan_incl(pc);
+        count = wave_bcast(incl, 63);
+        if (WANT_LEN) {
+            uint32_t idx = incl - pc;
+            for (int j = 0; j < 8; j++) if ((byte >> j) & 1) s_alpha[idx++] = (uint8_t)(8 * lane + j);
+        }
+        if (count == 0) { h.status = 2; return h; }
+    }
+    h.count = count;
+    // ---- code-length deltas: lane l owns the codes that START in bits [p0, p0 + 32) of the section. It assumes a boundary at
+    //      its entry offset, walks to the first boundary at or past p0 + 32 (runs of '1' = delta 0 in one step, count leading
+    //      zeros for the others) and hands that offset to its neighbour, until nothing moves ----------------------------------
+    KNZ_PROF_T(p0t);
+    const uint32_t p0 = e0 + 32u * (uint32_t)lane;
+    const uint32_t whi = knz_win32(w, p0), wlo = knz_win32(w, p0 + 32);
+    const uint64_t win = ((uint64_t)whi << 32) | wlo;
+    const bool relevant = (uint32_t)lane <= (count * 8 + 31) / 32;       // a usual code has at most 8 bits
+    uint32_t o = 0, c = 0;
+    int ds = 0;
+    bool odd = false;
+    for (int rounds = 0; ; rounds++) {
+        uint32_t pos = relevant ? o : 32u;                               // lanes behind the section carry nothing
+        c = 0; ds = 0; odd = false;
+        while (pos < 32) {
+            // one step = a run of '1' (delta 0 each) followed by at most one longer code, without branches
+            const uint32_t bits = knz_top32(whi, wlo, pos);
+            const uint32_t ones = min((uint32_t)__builtin_clz(~bits | 1u), 32u - pos);
+            const uint32_t pos1 = pos + ones;
+            const uint32_t b2 = knz_top32(whi, wlo, pos1 & 31);
+            const bool lng = pos1 < 32 && !(b2 >> 31);                     // a code with leading zeros starts inside my bits
+            const uint32_t z = (uint32_t)__builtin_clz(b2 | 1u);
+            if (lng && z > 3) odd = true;                                  // not a length delta a Go encoder writes
+            if (WANT_LEN) {
+                const uint32_t zz = z & 3;
+                const uint32_t val = (b2 << (zz + 1)) >> (31 - zz);       // the z+1 bits behind the terminator
+                const int mag = (int)((val >> 1) + (1u << zz) - 1u);
+                ds += lng ? ((val & 1) ? -mag : mag) : 0;
+            }
+            pos = odd ? 32u : pos1 + (lng ? 2 * z + 2 : 0u);
+            c += ones + ((lng && !odd) ? 1u : 0u);
+        }
+        KNZ_PROF_INC(16, 1);
+        uint32_t no = wave_shfl(pos - 32, lane - 1);
+        if (lane == 0) no = 0;
+        const bool changed = no != o;
+        o = no;
+#ifdef KNZ_EMU_STATS
+        if (lane == 0) { extern unsigned long long g_stat[8]; g_stat[1]++; }
+#endif
+        if (wave_ballot(changed && relevant) == 0) break;
+        if (rounds > 66) { h.status = 1; return h; }
+    }
+    KNZ_PROF_T(p1);
+    const uint32_t cincl = wave_scan_incl(c);
+    const uint32_t idx0 = cincl - c;
+    // the lane holding code count-1; every lane before it must be made of usual codes
+    const uint64_t em = wave_ballot(idx0 < count && idx0 + c >= count);
+    const uint64_t om = wave_ballot(odd);
+    if (em == 0) { h.status = 1; return h; }                           // section longer than 64 x 32 bits
+    const uint32_t endLane = (uint32_t)(__ffsll((unsigned long long)em) - 1);
+    // (an unusual pattern in the end lane itself lies behind the section: its codes are counted up to that point only)
+    if (om != 0 && (uint32_t)(__ffsll((unsigned long long)om) - 1) < endLane) { h.status = 1; return h; }
+    uint32_t myEnd = 0;
+    if ((uint32_t)lane == endLane) {
+        uint32_t pos = o, idx = idx0;
+        while (idx < count) {
+            const uint32_t bits = (uint32_t)((win << pos) >> 32);
+            const uint32_t ones = (uint32_t)__builtin_clz(~bits | 1u);
+            if (ones) { const uint32_t take = min(ones, count - idx); idx += take; pos += take; continue; }
+            pos += 2u * (uint32_t)__builtin_clz(bits | 1u) + 2u;
+            idx++;
+        }
+        myEnd = p0 + pos;
+    }
+    const uint32_t end = wave_readlane(myEnd, endLane);
+    KNZ_PROF_T(p2);
+    if (WANT_LEN) {
+        wave_sync_lds();                                                 // s_alpha
+        const int dincl = (int)wave_scan_incl((uint32_t)ds);
+        int cur = 2 + dincl - ds;
+        bool bad = false;
+        uint32_t pos = (uint32_t)lane <= endLane ? o : 32u, idx = idx0;
+        while (pos < 32 && idx < count) {
+            const uint32_t bits = (uint32_t)((win << pos) >> 32);
+            if (bits >> 31) pos += 1;
+            else {
+                const uint32_t z = (uint32_t)__builtin_clz(bits | 1u);
+                const uint32_t val = (bits << (z + 1)) >> (31 - z);
+                const int mag = (int)((val >> 1) + (1u << z) - 1u);
+                cur += (val & 1) ? -mag : mag;
+                pos += 2 * z + 2;
+            }
+            if (cur <= 0 || cur > KNZ_HUF_MAXLEN) { bad = true; break; }     // readLengths :640-645
+            s_len[s_alpha[idx]] = (uint8_t)cur;
+            idx++;
+        }
+        if (wave_ballot(bad) != 0) { h.status = 2; return h; }
+    }
+    KNZ_PROF_T(p3);
+    h.end = end;
+    // ---- fragment sizes: 4 varints (EntropyUtils.go:278-296), bytes fetched by 20 lanes, assembled on the scalar unit ------
+    if (count > 1) {
+        // continuation bits of the next 20 bytes -> the 4 lengths on the scalar unit; lane j then assembles varint j
+        const uint32_t vb = lane < 20 ? (knz_win32(w, end + 8u * (uint32_t)lane) >> 24) : 0u;
+        const uint32_t cm = (uint32_t)wave_ballot(vb >= 128);
+        uint32_t at[5];
+        at[0] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t rest = ~(cm >> at[j]);
+            at[j + 1] = at[j] + min(5u, (uint32_t)__ffs((int)rest));          // bytes up to and including the first one < 128
+        }
+        const uint32_t myAt = lane == 0 ? at[0] : (lane == 1 ? at[1] : (lane == 2 ? at[2] : at[3]));
+        const uint32_t myLen = (lane == 0 ? at[1] : (lane == 1 ? at[2] : (lane == 2 ? at[3] : at[4]))) - myAt;
+        const uint32_t q0 = knz_win32(w, end + 8 * myAt), q1 = knz_win32(w, end + 8 * myAt + 32);
+        uint32_t v = (q0 >> 24) & 0x7F;
+        if (myLen > 1) v |= ((q0 >> 16) & 0x7F) << 7;
+        if (myLen > 2) v |= ((q0 >> 8) & 0x7F) << 14;
+        if (myLen > 3) v |= (q0 & 0x7F) << 21;
+        if (myLen > 4) v |= ((q1 >> 24) & 0x0F) << 28;
+        h.fb[0] = wave_bcast(v, 0); h.fb[1] = wave_bcast(v, 1); h.fb[2] = wave_bcast(v, 2); h.fb[3] = wave_bcast(v, 3);
+        h.end = end + 8 * at[4];
+    }
+    KNZ_PROF_T(p4);
+    KNZ_PROF_ADD(17, pA, p0t); KNZ_PROF_ADD(18, p0t, p1); KNZ_PROF_ADD(19, p1, p2); KNZ_PROF_ADD(20, p2, p3); KNZ_PROF_ADD(21, p3, p4); KNZ_PROF_INC(22, 1); KNZ_PROF_INC(23, count);
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One 256-thread workgroup per 16 KiB chunk: wave 0 parses the header, all threads build the code table, then wave j owns
+// fragment j and lane s its sub-range s of 64.
+__global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, uint8_t* fallback) {
+    __shared__ uint16_t s_table[1 << KNZ_HUF_MAXLEN];
+    __shared__ __attribute__((aligned(16))) uint8_t s_outb[KNZ_HUF_CHUNK];
+    __shared__ uint32_t s_hw[KNZ_HW_WORDS];
+    __shared__ uint8_t s_len[256];
+    __shared__ uint8_t s_alpha[256];
+    __shared__ uint16_t s_C[258];
+    __shared__ uint8_t s_symAt[256];
+    __shared__ uint32_t s_cnt[4][16];
+    __shared__ KnzHufHdr s_hdr;
+    __shared__ int s_flag;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t cpb = a.chunks_per_block;
+    const uint32_t b = blockIdx.x / cpb, k = blockIdx.x % cpb;
+    if (tid == 0) fallback[blockIdx.x] = 0;
+    const uint32_t preLen = a.blk_pre_len[b];
+    if (a.blk_status[b] != 0) return;
+    if ((uint64_t)k * KNZ_HUF_CHUNK >= preLen) return;
+    const uint32_t n = min((uint32_t)KNZ_HUF_CHUNK, preLen - k * KNZ_HUF_CHUNK);
+    uint8_t* dst = a.out + a.blk_out_off[b] + (size_t)k * KNZ_HUF_CHUNK;
+    const uint64_t cbit = a.chunk_bit[blockIdx.x];
+    uint32_t entropy = a.entropy;
+    if (a.blk_mode[b] & 0x80) entropy = KNZ_E_NONE;
+    const uint64_t limit = a.nbytes << 3;
+
+    if (entropy == KNZ_E_NONE || n < 32) {   // raw copy at an arbitrary bit offset
+        for (uint32_t i = tid * 4; i < n; i += 1024) {
+            uint32_t w = knz_fetch32(a.stream, (int64_t)(cbit + 8ull * i), (int64_t)limit);
+            for (uint32_t j = 0; j < 4 && i + j < n; j++) dst[i + j] = (uint8_t)(w >> (24 - 8 * j));
+        }
+        return;
+    }
+
+    KNZ_PROF_T(t0);
+    // ---- header ---------------------------------------------------------------------------------------------------------
+    {
+        const uint32_t* words = (const uint32_t*)a.stream;
+        const uint64_t nwords = (a.nbytes + 3) >> 2, w0i = cbit >> 5;
+        if (tid < KNZ_HW_WORDS) s_hw[tid] = (w0i + tid < nwords) ? knz_bswap32(words[w0i + tid]) : 0u;
+        s_len[tid] = 0;
+        if (tid == 0) s_flag = 0;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const KnzHufHdr hh = knz_huf_parse_header_wave<true>(s_hw, (uint32_t)(cbit & 31), s_alpha, s_len, lane);
+        if (lane == 0) s_hdr = hh;
+    }
+    __syncthreads();
+    const KnzHufHdr hdr = s_hdr;
+    if (hdr.status == 1) { if (tid == 0) fallback[blockIdx.x] = 1; return; }
+    if (hdr.status == 2) { if (tid == 0) a.blk_status[b] = KNZ_ERR_PROCESS_BLOCK; return; }
+    KNZ_PROF_T(t1);
+    KNZ_PROF_ADD(0, t0, t1);
+    const uint32_t count = hdr.count;
+    if (count == 1) {                          // decodeV6 :778-786
+        const uint8_t v = s_alpha[0];
+        for (uint32_t i = tid; i < n; i += 256) dst[i] = v;
+        return;
+    }
+
+    // ---- canonical codes (generateCanonicalCodes :37-77): thread = symbol, codes are handed out by (length, symbol) ---------
+    const uint32_t myLen = s_len[tid];
+    uint32_t myBefore = 0;
+    {
+        const uint64_t below = ((uint64_t)1 << lane) - 1;
+        for (uint32_t L = 1; L <= KNZ_HUF_MAXLEN; L++) {
+            const uint64_t m = wave_ballot(myLen == L);
+            if (lane == 0) s_cnt[wave][L] = (uint32_t)__popcll(m);
+            if (myLen == L) myBefore = (uint32_t)__popcll(m & below);
+        }
+    }
+    __syncthreads();
+    uint32_t full = 0, myC = 0, myRank = 0, rankAcc = 0;
+    for (uint32_t L = 1; L <= KNZ_HUF_MAXLEN; L++) {
+        const uint32_t c0 = s_cnt[0][L], c1 = s_cnt[1][L], c2 = s_cnt[2][L], c3 = s_cnt[3][L];
+        if (L == myLen) {
+            const uint32_t prior = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u) + myBefore;
+            myC = full + (prior << (KNZ_HUF_MAXLEN - L));
+            myRank = rankAcc + prior;
+        }
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        full += tot << (KNZ_HUF_MAXLEN - L);
+        rankAcc += tot;
+    }
+    if (full > (1u << KNZ_HUF_MAXLEN)) { if (tid == 0) a.blk_status[b] = KNZ_ERR_PROCESS_BLOCK; return; }   // buildDecodingTable :683-685
+    if (myLen) { s_C[myRank] = (uint16_t)myC; s_symAt[myRank] = (uint8_t)tid; }
+    if (tid == 0) s_C[count] = (uint16_t)full;                          // <= 4096
+    __syncthreads();
+    // ---- 4096-entry table (buildDecodingTable :661-697): thread t fills entries [16t, 16t+16) -------------------------------
+    {
+        const uint32_t e0 = 16u * (uint32_t)tid;
+        uint32_t lo = 0, hi = count;                                    // last rank with C <= e0
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_C[mid] <= e0) lo = mid; else hi = mid; }
+        uint32_t r = lo;
+        uint32_t nextC = s_C[r + 1];
+        uint32_t sym = s_symAt[r];
+        uint32_t val = (sym << 8) | s_len[sym];
+        uint32_t pair = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint32_t e = e0 + i;
+            while (e >= nextC && r + 1 < count) { r++; nextC = s_C[r + 1]; sym = s_symAt[r]; val = (sym << 8) | s_len[sym]; }
+            const uint32_t v = e < full ? val : 7u;                       // table[i] = 7 where no code ends (:665-667)
+            if (i & 1) ((uint32_t*)s_table)[(e0 + i) >> 1] = pair | (v << 16); else pair = v;
+        }
+    }
+    __syncthreads();
+    KNZ_PROF_T(t2);
+    KNZ_PROF_ADD(1, t1, t2);
+
+    // ---- fragments: wave = fragment j, lane = sub-range s ----------------------------------------------------------------
+    const uint32_t F = n >> 2;
+    const uint32_t j = (uint32_t)wave, s = (uint32_t)lane;
+    const uint64_t hdrEnd = ((cbit >> 5) << 5) + hdr.end;
+    const uint32_t fbj = j == 0 ? hdr.fb[0] : (j == 1 ? hdr.fb[1] : (j == 2 ? hdr.fb[2] : hdr.fb[3]));
+    const uint64_t fp = hdrEnd + (j > 0 ? hdr.fb[0] : 0u) + (uint64_t)(j > 1 ? hdr.fb[1] : 0u) + (uint64_t)(j > 2 ? hdr.fb[2] : 0u);
+    const uint64_t tailpos = hdrEnd + (uint64_t)hdr.fb[0] + hdr.fb[1] + hdr.fb[2] + hdr.fb[3];
+    bool sane = (int32_t)(hdr.fb[0] | hdr.fb[1] | hdr.fb[2] | hdr.fb[3]) >= 0 && tailpos + 8ull * (n & 3) <= limit + 7;
+    sane = sane && fbj <= 12u * F;                                      // a symbol costs at most 12 bits
+    uint32_t st = 0, nsym = 0, e = 0, off = 0;
+    if (sane) {
+        const uint32_t B = (fbj + 63) >> 6;
+        const uint32_t E = min(fbj, (s + 1) * B);
+        // 1) synchronisation: start KNZ_HUF_SYNC_BITS before my sub-range on a guessed boundary and stop on the first code
+        //    boundary inside it (a symbol belongs to the lane in whose sub-range it starts, so this is where my neighbour ends)
+        const uint32_t R = min(fbj, s * B);
+        st = R;
+        if (s > 0 && R < fbj) {
+            uint32_t pos = R > KNZ_HUF_SYNC_BITS ? R - KNZ_HUF_SYNC_BITS : 0u;
+            KnzStreamReader r;
+            r.init(a.stream, a.nbytes, fp + pos);
+            while (pos < R) {
+                const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)];
+                r.consume(val & 0xFF);
+                pos += val & 0xFF;
+            }
+            st = pos;
+        }
+        // 2) decode my sub-range from there; the place I stop must be where my neighbour started, otherwise it restarts there
+        bool redo = true;
+        for (int round = 0; ; round++) {
+            if (redo) {
+                KnzStreamReader r;
+                r.init(a.stream, a.nbytes, fp + st);
+                uint32_t pos = st, cnt = 0;
+                while (pos < E) {
+                    const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)];
+                    r.consume(val & 0xFF);
+                    pos += val & 0xFF;
+                    cnt++;
+                }
+                nsym = cnt; e = pos;
+            }
+            uint32_t ns = wave_shfl(e, lane - 1);
+            if (s == 0) ns = 0;
+            redo = ns != st;
+            st = ns;
+#ifdef KNZ_EMU_STATS
+            if (tid == 0) { extern unsigned long long g_stat[8]; g_stat[0]++; }
+#endif
+            if (wave_ballot(redo) == 0) break;
+            if (round > 66) { sane = false; break; }
+        }
+        // symbol offsets inside the fragment; consistency with the count-driven reference decoder
+        const uint32_t incl = wave_scan_incl(nsym);
+        off = incl - nsym;
+        if (s == 63 && !(incl == F && e == fbj)) sane = false;
+    }
+    if (wave_ballot(!sane) != 0 && lane == 0) s_flag = 1;
+    __syncthreads();
+    KNZ_PROF_T(t3);
+    KNZ_PROF_ADD(2, t2, t3);
+    if (s_flag) { if (tid == 0) fallback[blockIdx.x] = 1; return; }
+    {
+        KnzStreamReader r;
+        r.init(a.stream, a.nbytes, fp + st);
+        uint8_t* o = s_outb + (size_t)j * F + off;
+        for (uint32_t i = 0; i < nsym; i++) {
+            const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)];
+            r.consume(val & 0xFF);
+            o[i] = (uint8_t)(val >> 8);
+        }
+    }
+    KNZ_PROF_T(t4);
+    KNZ_PROF_ADD(3, t3, t4);
+    if ((uint32_t)tid < (n & 3)) s_outb[4 * F + tid] = (uint8_t)(knz_fetch32(a.stream, (int64_t)(tailpos + 8ull * tid), (int64_t)limit) >> 24);
+    __syncthreads();
+    if ((((uintptr_t)dst) & 15) == 0) {
+        for (uint32_t i = tid; i < (n >> 4); i += 256) ((uint4*)dst)[i] = ((const uint4*)s_outb)[i];
+        for (uint32_t i = (n & ~15u) + tid; i < n; i += 256) dst[i] = s_outb[i];
+    } else {
+        for (uint32_t i = tid; i < n; i += 256) dst[i] = s_outb[i];
+    }
+    KNZ_PROF_T(t5);
+    KNZ_PROF_ADD(4, t4, t5);
+    KNZ_PROF_ADD(5, t0, t5);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One wave per block, the serial walk runs on lane 0 only: putting several blocks on the lanes of one wave makes
+// their data-dependent loops diverge and the wave then pays for the union of all paths.
+#define KNZ_WALK_RING 8192            // words of the stream kept ahead of the walk (32 KiB, power of two)
+#define KNZ_WALK_AHEAD 6656           // prefetch target: 26 KiB past the current chunk start (a chunk is < 25 KiB)
+#define KNZ_WALK_PF 12                // at most 12 KiB of loads in flight per chunk
+
+// 1 KiB of the stream (256 words from word index `base`, a multiple of 256), 16 bytes per lane; words past the end read 0
+__device__ __forceinline__ uint4 knz_walk_load_granule(const uint32_t* words, uint64_t nwords, uint64_t base, int lane) {
+    const uint64_t i = base + 4 * (uint64_t)lane;
+    uint4 v; v.x = v.y = v.z = v.w = 0;
+    if (base + 256 <= nwords) v = *(const uint4*)(words + i);           // wave-uniform: the whole granule is inside
+    else {
+        if (i < nwords) v.x = words[i];
+        if (i + 1 < nwords) v.y = words[i + 1];
+        if (i + 2 < nwords) v.z = words[i + 2];
+        if (i + 3 < nwords) v.w = words[i + 3];
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs a) {
+    __shared__ uint8_t s_lut[1 << KNZ_EXPG_WIN];
+    __shared__ __attribute__((aligned(16))) uint32_t s_ring[KNZ_WALK_RING];
+    __shared__ uint32_t s_hw[KNZ_HW_WORDS];
+    for (uint32_t i = threadIdx.x; i < (1u << KNZ_EXPG_WIN); i += 64) s_lut[i] = (uint8_t)knz_expg_lut_entry(i);
+    wave_sync_lds();
+    const uint32_t b = blockIdx.x;
+    if (b >= a.nblocks) return;
+    const bool writer = threadIdx.x == 0;            // every lane runs the (uniform) parse, lane 0 stores the results
+    KnzWaveReader r;
+    const uint64_t start = a.blk_bit[b];
+    const uint64_t end = start + a.blk_bits[b];
+    // the block-local stream is its own bitstream in the reference (r = (read+7)>>3 bytes): reads past `end`
+    // rounded up to a byte are an EOS panic there; checked below per chunk
+    r.init(a.stream, a.nbytes, start);
+    int32_t status = 0;
+    uint32_t mode = 0, skipFlags = 0, preLen = a.given_len;
+    uint32_t entropy = a.entropy;
+    uint64_t ck = 0;
+    if (!a.payload_only) {
+        mode = r.read(8);
+        if (mode & 0x80) { entropy = KNZ_E_NONE; skipFlags = 0xFF; }   // copy block: no transform runs (device convention)
+        else if (mode & 0x10) skipFlags = r.read(8);
+        else skipFlags = ((mode << 4) | 0x0F) & 0xFF;
+        const uint32_t dataSize = 1 + ((mode >> 5) & 3);
+        preLen = r.read(8 * dataSize);
+        uint64_t maxLen = (uint64_t)a.block_size + a.block_size / 2;   // blockLength + blockLength/2 (:1893)
+        if (maxLen < 2048) maxLen = 2048;
+        if (maxLen > (1u << 30)) maxLen = 1u << 30;
+        if (preLen == 0 || preLen > maxLen) status = KNZ_ERR_BLOCK_SIZE;
+        if (a.checksum_bits == 32) ck = r.read(32);
+        else if (a.checksum_bits == 64) { ck = (uint64_t)r.read(32) << 32; ck |= r.read(32); }
+    }
+    if (writer) {
+        a.blk_pre_len[b] = preLen;
+        a.blk_mode[b] = (uint8_t)mode;
+        a.blk_skip[b] = (uint8_t)skipFlags;
+        a.blk_cksum[b] = ck;
+    }
+    const uint64_t limit = start + (((a.blk_bits[b] + 7) >> 3) << 3);
+    const uint32_t cpb = a.chunks_per_block;
+    if (status == 0) {
+        const uint32_t chunkSize = (a.entropy == KNZ_E_ANS1 || a.entropy == KNZ_E_FPAQ) ? (4u << 20) : (uint32_t)KNZ_HUF_CHUNK;
+        const uint32_t nchunks = (preLen + chunkSize - 1) / chunkSize;
+        if (nchunks > cpb) status = KNZ_ERR_BLOCK_SIZE;
+        // Huffman chunks: the stream is pulled through an LDS ring AHEAD of the walk (the loads of the next 26 KiB are issued
+        // before a header is parsed and land in the ring after it), so that the chain chunk k -> chunk k+1 never waits for
+        // HBM, and the header itself is parsed by the whole wave (knz_huf_parse_header_wave).
+        const uint32_t* swords = (const uint32_t*)a.stream;
+        const uint64_t snwords = (a.nbytes + 3) >> 2;
+        uint64_t pos = r.tell();                                           // walk position, authoritative
+        uint64_t ringHi = 0;                                               // stream words [.., ringHi) are in the ring (1 KiB granules)
+        const bool ringOk = (((uintptr_t)a.stream) & 15) == 0;             // 16-byte loads; otherwise the serial parser runs
+        bool stale = false;                                                // r is behind pos
+        for (uint32_t k = 0; k < nchunks && status == 0; k++) {
+            const uint32_t sz = min(chunkSize, preLen - k * chunkSize);
+            if (writer) a.chunk_bit[(size_t)b * cpb + k] = pos;
+            if (entropy == KNZ_E_HUFFMAN && sz >= 32 && ringOk) {
+                KNZ_PROF_T(w0);
+                const uint64_t w0i = pos >> 5;
+                if (ringHi + KNZ_WALK_RING <= w0i || ringHi == 0) ringHi = w0i & ~(uint64_t)255;   // (re)start the ring here
+                // blocking part: whatever the header window still misses (first chunk, or an unusually large step)
+                while (ringHi < w0i + KNZ_HW_WORDS) {
+                    const uint4 v = knz_walk_load_granule(swords, snwords, ringHi, (int)threadIdx.x);
+                    *(uint4*)&s_ring[(ringHi + 4 * threadIdx.x) & (KNZ_WALK_RING - 1)] = v;
+                    ringHi += 256;
+                }
+                // prefetch: issue now, store behind the parse
+                uint4 pf[KNZ_WALK_PF];
+                const uint64_t pfBase = ringHi;
+                uint32_t groups = 0;
+                if (w0i + KNZ_WALK_AHEAD > ringHi) groups = (uint32_t)min((uint64_t)KNZ_WALK_PF, (w0i + KNZ_WALK_AHEAD - ringHi + 255) >> 8);
+#pragma unroll
+                for (int g = 0; g < KNZ_WALK_PF; g++)
+                    if ((uint32_t)g < groups) pf[g] = knz_walk_load_granule(swords, snwords, pfBase + 256 * g, (int)threadIdx.x);
+                KNZ_PROF_T(w1);
+                wave_sync_lds();
+                for (uint32_t i = threadIdx.x; i < KNZ_HW_WORDS; i += 64) s_hw[i] = knz_bswap32(s_ring[(w0i + i) & (KNZ_WALK_RING - 1)]);
+                wave_sync_lds();
+                KNZ_PROF_T(w2);
+                const KnzHufHdr hdr = knz_huf_parse_header_wave<false>(s_hw, (uint32_t)(pos & 31), nullptr, nullptr, (int)threadIdx.x);
+                wave_sync_lds();
+                KNZ_PROF_T(w3);
+#pragma unroll
+                for (int g = 0; g < KNZ_WALK_PF; g++)
+                    if ((uint32_t)g < groups) *(uint4*)&s_ring[(pfBase + 256 * g + 4 * threadIdx.x) & (KNZ_WALK_RING - 1)] = pf[g];
+                ringHi = pfBase + 256ull * groups;
+                KNZ_PROF_T(w4);
+                KNZ_PROF_ADD(8, w0, w1); KNZ_PROF_ADD(9, w1, w2); KNZ_PROF_ADD(10, w2, w3); KNZ_PROF_ADD(11, w3, w4);
+                if (hdr.status == 2) { status = KNZ_ERR_PROCESS_BLOCK; break; }
+                if (hdr.status == 0) {
+                    uint64_t np = (w0i << 5) + hdr.end;
+                    if (hdr.count > 1) {
+                        if ((int32_t)(hdr.fb[0] | hdr.fb[1] | hdr.fb[2] | hdr.fb[3]) < 0) status = KNZ_ERR_PROCESS_BLOCK;
+                        np += (uint64_t)hdr.fb[0] + hdr.fb[1] + hdr.fb[2] + hdr.fb[3] + 8ull * (sz & 3);
+                    }
+                    pos = np;
+                    stale = true;
+                    if (pos > limit) status = KNZ_ERR_PROCESS_BLOCK;
+                    continue;
+                }
+                // unusual header: serial parser below
+            }
+            if (stale) { r.seek(pos); stale = false; }
+            if (entropy == KNZ_E_NONE || (entropy == KNZ_E_HUFFMAN && sz < 32) || ((entropy == KNZ_E_ANS0 || entropy == KNZ_E_ANS1) && preLen <= 32)) {
+                r.seek(r.tell() + 8ull * sz);                          // raw bytes (HuffmanCodec.go:769-771, ANSRangeCodec.go:720-723)
+            } else if (entropy == KNZ_E_FPAQ) {                       // FPAQDecoder.Read :357-377
+                const uint32_t szb = knz_read_varint(r);
+                if ((int32_t)szb < 0 || (uint64_t)szb >= 2ull * preLen) status = KNZ_ERR_PROCESS_BLOCK;
+                r.seek(r.tell() + 56 + 8ull * szb);
+            } else if (entropy == KNZ_E_ANS1) {
+                uint32_t lr; int total;
+                if (!knz_ans1_parse_header(r, nullptr, lr, total) || total == 0) { status = KNZ_ERR_PROCESS_BLOCK; break; }
+                const uint32_t szb = knz_read_varint(r);
+                if (szb >= (1u << 27)) status = KNZ_ERR_PROCESS_BLOCK;
+                r.seek(r.tell() + 128 + 8ull * szb);
+            } else if (entropy == KNZ_E_ANS0) {
+                // decodeHeader (ANSRangeCodec.go:605-710) far enough to find the end of the chunk
+                const uint32_t lr = 8 + r.read(3);
+                uint32_t llr = 3;
+                while ((1u << llr) <= lr) llr++;
+                uint32_t count;
+                if (r.read(1) == 0) count = r.read(1) == 1 ? 0 : 256;
+                else {
+                    uint32_t lastMask = r.read(5);
+                    count = 0;
+                    for (uint32_t m = 0; m <= lastMask; m++) count += (uint32_t)__popc(r.read(8));
+                }
+                if (count == 0) { status = KNZ_ERR_PROCESS_BLOCK; break; }
+                const uint32_t chk = count < 64 ? 6 : 8;
+                for (uint32_t i = 1; i < count; i += chk) {
+                    const uint32_t logMax = r.read(llr);
+                    const uint32_t endj = min(i + chk, count);
+                    if (logMax > 16) { status = KNZ_ERR_PROCESS_BLOCK; break; }
+                    r.seek(r.tell() + (uint64_t)(endj - i) * logMax);
+                }
+                if (count > 1 && status == 0) {
+                    const uint32_t szb = knz_read_varint(r);
+                    if (szb >= (1u << 27)) status = KNZ_ERR_PROCESS_BLOCK;
+                    r.seek(r.tell() + 128 + 8ull * szb);
+                }
+            } else {
+                // alphabet (EntropyUtils.go:71-119)
+                uint32_t count;
+                if (r.read(1) == 0) {
+                    if (r.read(1) == 1) { status = KNZ_ERR_PROCESS_BLOCK; break; }  // empty alphabet: Read returns short
+                    count = 256;
+                } else {
+                    uint32_t lastMask = r.read(5);
+                    count = 0;
+                    for (uint32_t bitsLeft = 8 * (lastMask + 1); bitsLeft > 0;) {
+                        const uint32_t take = bitsLeft > 32 ? 32 : bitsLeft;
+                        count += (uint32_t)__popc(r.read(take));
+                        bitsLeft -= take;
+                    }
+                    if (count == 0) { status = KNZ_ERR_PROCESS_BLOCK; break; }
+                }
+                for (uint32_t i = 0; i < count;) {
+                    const uint32_t e = s_lut[r.peek(KNZ_EXPG_WIN)];
+                    const uint32_t nc = e >> 4;
+                    if (nc == 0 || i + nc > count) { knz_skip_expg(r); i++; }
+                    else { r.skip(e & 15); i += nc; }
+                }
+                if (count > 1) {
+                    uint64_t fb = 0;
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t v = knz_read_varint(r);
+                        if ((int32_t)v < 0) status = KNZ_ERR_PROCESS_BLOCK;
+                        fb += v;
+                    }
+                    r.seek(r.tell() + fb + 8ull * (sz & 3));
+                }
+            }
+            pos = r.tell();
+            if (pos > limit) status = KNZ_ERR_PROCESS_BLOCK;            // ran past the block payload
+        }
+        if (writer) a.blk_end_bit[b] = pos;
+    } else if (writer) a.blk_end_bit[b] = r.tell();
+    if (writer) a.blk_status[b] = status;
+}
+

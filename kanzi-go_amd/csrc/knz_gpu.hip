@@ -3,6 +3,7 @@
 #include "knz_internal.h"
 #include "huffman_enc.hip"
 #include "huffman_dec.hip"
+#include "huffman_par.hip"
 #include "ans0.hip"
 #include "ans1.hip"
 #include "fpaq.hip"
@@ -169,6 +170,27 @@ extern "C" int knz_last_timing(void* handle, float* stage_ms, int cap) {
     for (int i = 0; i < n; i++) stage_ms[i] = h->stage_ms[i];
     return n;
 }
+
+extern "C" int knz_last_counter(void* handle, int id, uint64_t* value) {
+    Handle* h = (Handle*)handle;
+    if (!h || !value || id != KNZ_COUNTER_HUF_SERIAL_CHUNKS) return KNZ_ERR_INVALID_PARAM;
+    *value = 0;
+    if (h->huf_fallback_n == 0) return KNZ_OK;
+    std::vector<uint8_t> f(h->huf_fallback_n);
+    if (hipMemcpy(f.data(), h->huf_fallback.p, f.size(), hipMemcpyDeviceToHost) != hipSuccess) return KNZ_ERR_UNKNOWN;
+    uint64_t n = 0;
+    for (uint8_t v : f) n += v;
+    *value = n;
+    return KNZ_OK;
+}
+
+#ifdef KNZ_PROFILE_PHASES
+extern "C" int knz_debug_prof(unsigned long long* out, int reset) {
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knz_prof), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_knz_prof), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 #include "knz_transforms.inc"
 

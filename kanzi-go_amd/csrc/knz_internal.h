@@ -25,6 +25,8 @@ struct Handle {
     DevBuf unit_bits, unit_src, ans_tab, scratch, chunk_rel, blk_written, blk_hdr, blk_dst_bit, total_bits;
     DevBuf stage_in, stage_out;       // host-pointer entry points stage through these
     DevBuf dec_tables;                // decoder per-chunk positions
+    size_t huf_fallback_n = 0;        // chunks covered by huf_fallback in the last decode batch
+    DevBuf huf_fallback;              // [chunks] 1 = the parallel Huffman decoder handed the chunk to the serial one
     // transform pipeline (knz_transforms.inc)
     DevBuf xf_r1, xf_r2, xf_outptr, xf_outlen, xf_ok, xf_side, xf_active, xf_take, xf_sega, xf_segb, xf_gstart, xf_misc;
     DevBuf lz_hash, lz_tk, lz_mb, lz_ml;

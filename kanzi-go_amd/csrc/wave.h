@@ -40,6 +40,13 @@ __device__ __forceinline__ uint32_t wave_writelane0(uint32_t v, uint32_t val) {
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // full-rate 24 x 24 -> 32 bit multiply (v_mul_u32_u24): both factors must be < 2^24
 __device__ __forceinline__ uint32_t knz_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+// Same for LDS only, for kernels that keep global loads in flight across it: DS operations of one wave execute in order, so
+// no s_waitcnt is needed at all (a workgroup-scope release would drain vmcnt and serialise every prefetch behind it).
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 #else
 // ------------------------------------------------------------------ emulator (tests only)
 inline uint32_t knz_mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
@@ -66,11 +73,25 @@ inline uint64_t wave_ballot(bool p) {
 inline uint32_t wave_bcast(uint32_t v, int src) { return wave_shfl(v, src); }
 inline uint32_t wave_readlane(uint32_t v, uint32_t src) { return wave_shfl(v, (int)src); }
 inline void wave_sync() { hipemu::wave_barrier(); }
+inline void wave_sync_lds() { hipemu::wave_barrier(); }
 inline uint32_t wave_shr1(uint32_t v) { const uint32_t r = wave_shfl(v, hipemu::lane() - 1); return hipemu::lane() == 0 ? 0u : r; }
 inline uint32_t wave_writelane0(uint32_t v, uint32_t val) { return hipemu::lane() == 0 ? val : v; }
 #endif
 
-// inclusive prefix sum across the wave (log-step shuffles)
+// inclusive prefix sum across the wave
+#ifndef KNZ_HIP_EMU
+// DPP form (row_shr 1/2/4/8 inside the rows of 16, then row_bcast:15 / row_bcast:31 across rows): six VALU moves with a few
+// cycles of latency each instead of six ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+#else
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
     int l = lane_id();
 #pragma unroll
@@ -80,6 +101,7 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
     }
     return v;
 }
+#endif
 __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += wave_shfl(v, lane_id() ^ d);
