@@ -115,3 +115,25 @@ __device__ __forceinline__ void knz_histogram_256t(const uint8_t* src, uint32_t 
         for (uint32_t i = tid; i < n; i += 256) atomicAdd(&h[src[i]], 1u);
     }
 }
+
+// Same with 16 histograms (4 per wave, picked by lane & 3): frequent symbols (spaces, zeros) make the lanes of a wave collide
+// on one LDS counter, 4 counters per wave cut that serialisation by 4. hist is [16][256], zeroed by the caller.
+__device__ __forceinline__ void knz_histogram_256t_x16(const uint8_t* src, uint32_t n, uint32_t (*hist)[256], int tid) {
+    uint32_t* h = hist[((tid >> 6) << 2) | (tid & 3)];
+    const uint32_t nvec = n >> 4;
+    if ((((uintptr_t)src) & 15) == 0) {
+        const uint4* v = (const uint4*)src;
+        for (uint32_t i = tid; i < nvec; i += 256) {
+            uint4 x = v[i];
+            uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                atomicAdd(&h[w[j] & 255], 1u); atomicAdd(&h[(w[j] >> 8) & 255], 1u);
+                atomicAdd(&h[(w[j] >> 16) & 255], 1u); atomicAdd(&h[w[j] >> 24], 1u);
+            }
+        }
+        for (uint32_t i = (nvec << 4) + tid; i < n; i += 256) atomicAdd(&h[src[i]], 1u);
+    } else {
+        for (uint32_t i = tid; i < n; i += 256) atomicAdd(&h[src[i]], 1u);
+    }
+}

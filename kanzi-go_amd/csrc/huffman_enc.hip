@@ -180,11 +180,114 @@ struct HufEncArgs {
     uint32_t* unit_bits;          // [(nblocks*CPB) * 5]
     uint32_t* unit_src;           // [(nblocks*CPB) * 5] byte offset of each unit inside its scratch slot
     int32_t* blk_status;          // [nblocks] set to ERR_PROCESS_BLOCK (13) where the Go code would panic
+    // sorted statistics between the three kernels, transposed per group of 64 chunks: entry (chunk c, rank i) at
+    // ((c / 64) * 256 + i) * 64 + c % 64, so that a wave working on 64 chunks (one per lane) reads and writes coalesced
+    uint16_t* st_freq;            // frequency of the symbol of rank i (ascending (frequency, symbol) order)
+    uint8_t* st_sym;              // that symbol
+    uint8_t* st_len;              // its code length (Moffat-Katajainen, before the 12-bit limiter)
+    uint16_t* st_count;           // [chunks] alphabet size (0: chunk absent or stored raw)
+    uint8_t* st_maxlen;           // [chunks] longest code length
+    uint32_t nchunks;
 };
 
+__device__ __forceinline__ size_t knz_huf_st(uint32_t chunk, uint32_t i) { return ((size_t)(chunk >> 6) * 256 + i) * 64 + (chunk & 63); }
+
+// ---- kernel 1: histogram (Global.go:226-251) + sort of (frequency << 8 | symbol) (sort.Ints in computeCodeLengths :303) ----
+// 256 threads per chunk, thread = symbol. The rank of a key is the number of smaller keys: every wave holds the 256 keys in
+// 4 registers (key 64*w + lane in register w) and walks them with v_readlane, no LDS in the loop.
+__global__ __launch_bounds__(256) void knz_huf_hist_kernel(HufEncArgs a) {
+    __shared__ uint32_t s_hist[16][256];
+    __shared__ uint32_t s_key[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t cpb = a.chunks_per_block;
+    const uint32_t b = blockIdx.x / cpb, k = blockIdx.x % cpb;
+    const uint32_t postLen = a.blk_len[b];
+    uint32_t n = 0;
+    if ((uint64_t)k * KNZ_HUF_CHUNK < postLen) n = min((uint32_t)KNZ_HUF_CHUNK, postLen - k * KNZ_HUF_CHUNK);
+    if (n < 32) {                                             // absent or raw (HuffmanCodec.go:411-413)
+        if (tid == 0) { a.st_count[blockIdx.x] = 0; a.st_maxlen[blockIdx.x] = 0; }
+        return;
+    }
+    const uint8_t* src = a.data + a.blk_off[b] + (size_t)k * KNZ_HUF_CHUNK;
+    for (int i = tid; i < 16 * 256; i += 256) (&s_hist[0][0])[i] = 0;
+    __syncthreads();
+    knz_histogram_256t_x16(src, n, s_hist, tid);
+    __syncthreads();
+    uint32_t myFreq = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) myFreq += s_hist[i][tid];
+    const uint32_t myKey = myFreq ? ((myFreq << 8) | (uint32_t)tid) : 0xFFFFFFFFu;
+    s_key[tid] = myKey;
+    __syncthreads();
+    uint32_t kreg[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) kreg[w] = s_key[64 * w + lane];
+    uint32_t rank = 0, count = 0;
+    for (uint32_t j = 0; j < 64; j++) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint32_t kj = wave_readlane(kreg[w], j);
+            rank += kj < myKey ? 1u : 0u;
+            count += kj != 0xFFFFFFFFu ? 1u : 0u;
+        }
+    }
+    if (myFreq) {
+        a.st_freq[knz_huf_st(blockIdx.x, rank)] = (uint16_t)myFreq;     // <= 16384
+        a.st_sym[knz_huf_st(blockIdx.x, rank)] = (uint8_t)tid;
+    }
+    if (tid == 0) a.st_count[blockIdx.x] = (uint16_t)count;
+}
+
+// ---- kernel 2: Moffat-Katajainen in-place code lengths (HuffmanCodec.go:328-385), ONE LANE PER CHUNK --------------------
+// The algorithm is a serial chain of dependent reads; 64 chunks per wave keep the LDS pipe busy instead of one lane of a
+// 256-thread workgroup. Array element i of lane l lives at s_d[i * 64 + l] (bank = lane: conflict free when the lanes move
+// in step, which they mostly do).
+__global__ __launch_bounds__(64) void knz_huf_lengths_kernel(HufEncArgs a) {
+    __shared__ uint16_t s_d[256 * 64];
+    const int lane = threadIdx.x;
+    const uint32_t chunk = blockIdx.x * 64 + lane;
+    const int n = chunk < a.nchunks ? (int)a.st_count[chunk] : 0;
+    uint16_t* d = s_d + lane;
+    for (int i = 0; i < n; i++) d[i * 64] = a.st_freq[knz_huf_st(chunk, i)];
+    if (n < 2) {                                              // 0: nothing, 1: the single symbol gets length 1 (:156-158)
+        if (n == 1) { a.st_len[knz_huf_st(chunk, 0)] = 1; a.st_maxlen[chunk] = 1; }
+        return;
+    }
+    // phase 1 (:328-356)
+    for (int s = 0, r = 0, t = 0; t < n - 1; t++) {
+        uint32_t sum = 0;
+        for (int i = 0; i < 2; i++) {
+            if (s >= n || (r < t && d[r * 64] < d[s * 64])) {
+                sum += d[r * 64];
+                d[r * 64] = (uint16_t)t;
+                r++;
+                continue;
+            }
+            sum += d[s * 64];
+            if (s > t) d[s * 64] = 0;
+            s++;
+        }
+        d[t * 64] = (uint16_t)sum;
+    }
+    // phase 2 (:359-385)
+    int levelTop = n - 2, depth = 1, i = n, totalNodesAtLevel = 2;
+    while (i > 0) {
+        int k = levelTop;
+        while (k > 0 && (int)d[(k - 1) * 64] >= levelTop) k--;
+        const int internalNodesAtLevel = levelTop - k;
+        const int leavesAtLevel = totalNodesAtLevel - internalNodesAtLevel;
+        for (int j = 0; j < leavesAtLevel; j++) { i--; d[i * 64] = (uint16_t)depth; }
+        totalNodesAtLevel = internalNodesAtLevel << 1;
+        levelTop = k;
+        depth++;
+    }
+    for (int j = 0; j < n; j++) a.st_len[knz_huf_st(chunk, j)] = (uint8_t)min(255u, (uint32_t)d[j * 64]);
+    a.st_maxlen[chunk] = (uint8_t)min(255, depth - 1);
+}
+
+// ---- kernel 3: canonical codes, the 4 fragments, the header ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
     __shared__ uint32_t s_out[4][KNZ_FRAG_BYTES / 4];
-    __shared__ uint32_t s_hist[4][256];
     __shared__ uint32_t s_freq[256];
     __shared__ uint32_t s_sorted[256];
     __shared__ uint32_t s_data[256];
@@ -193,7 +296,9 @@ __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
     __shared__ uint16_t s_code[256];
     __shared__ uint32_t s_hdr[KNZ_U0_BYTES / 4];
     __shared__ uint32_t s_fragbits[4];
-    __shared__ int s_maxLen, s_fallback, s_panic, s_limited;
+    __shared__ uint32_t s_cnt[4][16];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ int s_fallback, s_panic;
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -214,9 +319,9 @@ __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
 
     // ---- zero LDS staging ---------------------------------------------------------------------------------
     for (int i = tid; i < 4 * (KNZ_FRAG_BYTES / 4); i += 256) (&s_out[0][0])[i] = 0;
-    for (int i = tid; i < 4 * 256; i += 256) (&s_hist[0][0])[i] = 0;
     if (tid < KNZ_U0_BYTES / 4) s_hdr[tid] = 0;
-    if (tid == 0) { s_panic = 0; s_fallback = 0; s_maxLen = 0; s_limited = 0; }
+    s_freq[tid] = 0; s_len[tid] = 0; s_code[tid] = 0;
+    if (tid == 0) { s_panic = 0; s_fallback = 0; }
     __syncthreads();
 
     if (n < 32) { // HuffmanCodec.go:411-413: raw bytes
@@ -227,60 +332,40 @@ __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
         return;
     }
 
-    // ---- histogram (Global.go:226-251): coalesced 16 B per lane, per-wave private counters --------------------
-    knz_histogram_256t(src, n, s_hist, tid);
+    // ---- statistics of kernels 1 and 2: rank order -> symbol order ---------------------------------------------------------
+    const int count = (int)a.st_count[blockIdx.x];
+    if (tid < count) {
+        const uint32_t sym = a.st_sym[knz_huf_st(blockIdx.x, tid)];
+        s_sorted[tid] = sym;
+        s_freq[sym] = a.st_freq[knz_huf_st(blockIdx.x, tid)];
+        s_len[sym] = a.st_len[knz_huf_st(blockIdx.x, tid)];
+    }
+    const int maxLen0 = (int)a.st_maxlen[blockIdx.x];                   // before the limiter (every thread reads its own copy)
     __syncthreads();
-    const uint32_t myFreq = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
-    s_freq[tid] = myFreq;
-    s_len[tid] = 0;
-    s_code[tid] = 0;
     // alphabet = present symbols in increasing order (HuffmanCodec.go:137-146)
-    const bool present = myFreq > 0;
+    const bool present = s_freq[tid] > 0;
     const uint64_t bal = wave_ballot(present);
-    if (lane == 0) s_data[wave] = (uint32_t)__popcll(bal);   // per-wave counts, reused below
+    if (lane == 0) s_wsum[wave] = (uint32_t)__popcll(bal);
     __syncthreads();
     uint32_t before = 0;
-    for (int w = 0; w < wave; w++) before += s_data[w];
-    const int count = (int)(s_data[0] + s_data[1] + s_data[2] + s_data[3]);
+    for (int w = 0; w < wave; w++) before += s_wsum[w];
     const uint32_t myIdx = before + (uint32_t)__popcll(bal & (((uint64_t)1 << lane) - 1));
-    __syncthreads();               // s_data is about to be reused
     if (present) s_alpha[myIdx] = (uint8_t)tid;
-
-    // ---- sort keys (freq<<8|sym) by rank counting (sort.Ints in computeCodeLengths :303) -----------------------
-    const uint32_t myKey = present ? ((myFreq << 8) | (uint32_t)tid) : 0xFFFFFFFFu;
-    if (count > 1) {
-        uint32_t rank = 0;
-        for (int u = 0; u < 256; u++) {
-            uint32_t f = s_freq[u];
-            uint32_t key = f ? ((f << 8) | (uint32_t)u) : 0xFFFFFFFFu;
-            rank += key < myKey ? 1u : 0u;
-        }
-        if (present) s_sorted[rank] = myKey;
-    }
     __syncthreads();
 
-    // ---- code lengths: serial section on one thread (Moffat-Katajainen + limiter) ------------------------------
-    if (tid == 0) {
-        if (count == 1) {
-            s_len[s_alpha[0]] = 1;      // HuffmanCodec.go:156-158
-            s_maxLen = 1;
-        } else {
-            for (int i = 0; i < count; i++) { s_data[i] = s_sorted[i] >> 8; s_sorted[i] &= 0xFF; }
-            int maxLen = knz_huf_lengths_inplace(s_data, count);
-            for (int i = 0; i < count; i++) s_len[s_sorted[i]] = (uint8_t)s_data[i];
+    // ---- 12-bit limiter (limitCodeLengths :216-297): rare, serial on one thread ------------------------------------------------
+    if (maxLen0 > KNZ_HUF_MAXLEN) {
+        if (tid == 0) {
             int panic = 0;
-            if (maxLen > KNZ_HUF_MAXLEN) { s_limited = 1; maxLen = knz_huf_limit(s_alpha, count, s_freq, s_len, s_sorted, s_data, &panic, &s_out[0][0]); }
+            int maxLen = knz_huf_limit(s_alpha, count, s_freq, s_len, s_sorted, s_data, &panic, &s_out[0][0]);
             if (maxLen > KNZ_HUF_MAXLEN) {
                 s_fallback = 1;
                 for (int i = 0; i < count; i++) s_len[s_alpha[i]] = 8;
             }
-            s_maxLen = maxLen;
             s_panic = panic;
         }
-    }
-    __syncthreads();
-    if (s_limited) {   // the limiter used the head of the fragment staging area as scratch: zero it again
-        for (int i = tid; i < 1024; i += 256) s_out[0][i] = 0;
+        __syncthreads();
+        for (int i = tid; i < 1024; i += 256) s_out[0][i] = 0;   // the limiter used the head of the staging area as scratch
         __syncthreads();
     }
     if (s_panic) { // Go would panic (index out of range) -> encodingTask recovers it as ERR_PROCESS_BLOCK
@@ -289,22 +374,28 @@ __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
         return;
     }
 
-    // ---- canonical codes (generateCanonicalCodes :37-77): code = (sum of 2^(12-len) over symbols that sort
-    //      before (len,sym)) >> (12-len); fallback: alphabet index on 8 bits (:179-184) ---------------------------
+    // ---- canonical codes (generateCanonicalCodes :37-77): handed out by (length, symbol), one ballot per length;
+    //      fallback: alphabet index on 8 bits (:179-184) -----------------------------------------------------------------------
     const uint32_t myLen = s_len[tid];
-    if (present) {
-        uint32_t code;
-        if (s_fallback) code = myIdx;
-        else {
-            uint32_t acc = 0;
-            for (int u = 0; u < 256; u++) {
-                uint32_t lu = s_len[u];
-                bool beforeMe = lu != 0 && (lu < myLen || (lu == myLen && u < tid));
-                acc += beforeMe ? (1u << (KNZ_HUF_MAXLEN - lu)) : 0u;
-            }
-            code = acc >> (KNZ_HUF_MAXLEN - myLen);
+    {
+        uint32_t myBefore = 0;
+        const uint64_t below = ((uint64_t)1 << lane) - 1;
+        for (uint32_t L = 1; L <= KNZ_HUF_MAXLEN; L++) {
+            const uint64_t m = wave_ballot(myLen == L);
+            if (lane == 0) s_cnt[wave][L] = (uint32_t)__popcll(m);
+            if (myLen == L) myBefore = (uint32_t)__popcll(m & below);
         }
-        s_code[tid] = (uint16_t)((myLen << 12) | (code & 0x0FFF));
+        __syncthreads();
+        uint32_t full = 0, myC = 0;
+        for (uint32_t L = 1; L <= KNZ_HUF_MAXLEN; L++) {
+            const uint32_t c0 = s_cnt[0][L], c1 = s_cnt[1][L], c2 = s_cnt[2][L], c3 = s_cnt[3][L];
+            if (L == myLen) myC = full + (((wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u) + myBefore) << (KNZ_HUF_MAXLEN - L));
+            full += (c0 + c1 + c2 + c3) << (KNZ_HUF_MAXLEN - L);
+        }
+        if (present) {
+            const uint32_t code = s_fallback ? myIdx : (myC >> (KNZ_HUF_MAXLEN - myLen));
+            s_code[tid] = (uint16_t)((myLen << 12) | (code & 0x0FFF));
+        }
     }
     __syncthreads();
 
@@ -315,8 +406,21 @@ __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
         const uint32_t first = min(F, (uint32_t)lane * S);
         const uint32_t last = min(F, first + S);
         const uint8_t* fsrc = src + (size_t)wave * F;
+        // full chunks: 64 symbols per lane, fetched as 4 x 16 bytes up front (one cache line per lane) and walked in registers
+        const bool fast = S == 64 && F == 4096 && ((((uintptr_t)fsrc) & 15) == 0);
+        uint32_t wd[16];
+        if (fast) {
+            const uint4* q = (const uint4*)(fsrc + first);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint4 x = q[u]; wd[4 * u] = x.x; wd[4 * u + 1] = x.y; wd[4 * u + 2] = x.z; wd[4 * u + 3] = x.w; }
+        }
         uint32_t nbits = 0;
-        for (uint32_t i = first; i < last; i++) nbits += s_code[fsrc[i]] >> 12;
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < 64; i++) nbits += s_code[(wd[i >> 2] >> (8 * (i & 3))) & 0xFF] >> 12;
+        } else {
+            for (uint32_t i = first; i < last; i++) nbits += s_code[fsrc[i]] >> 12;
+        }
         const uint32_t incl = wave_scan_incl(nbits);
         const uint32_t start = incl - nbits;
         const uint32_t total = wave_bcast(incl, 63);
@@ -326,47 +430,71 @@ __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
         uint32_t cnt = start & 31;
         uint32_t w = start >> 5;
         bool firstWord = true;
-        for (uint32_t i = first; i < last; i++) {
-            uint32_t c = s_code[fsrc[i]];
-            uint32_t L = c >> 12;
+        auto put = [&](uint32_t c) {
+            const uint32_t L = c >> 12;
             acc = (acc << L) | (c & 0x0FFF);
             cnt += L;
             if (cnt >= 32) {
-                uint32_t word = (uint32_t)(acc >> (cnt - 32));
+                const uint32_t word = (uint32_t)(acc >> (cnt - 32));
                 if (firstWord) { atomicOr(&out[w], word); firstWord = false; }
                 else out[w] = word;
                 w++;
                 cnt -= 32;
             }
+        };
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < 64; i++) put(s_code[(wd[i >> 2] >> (8 * (i & 3))) & 0xFF]);
+        } else {
+            for (uint32_t i = first; i < last; i++) put(s_code[fsrc[i]]);
         }
         if (cnt > 0 && nbits > 0) atomicOr(&out[w], (uint32_t)(acc << (32 - cnt)) );
     } else if (lane == 0) {
         s_fragbits[wave] = 0;
     }
-    __syncthreads();
 
-    // ---- unit 0: alphabet, code length deltas, fragment sizes (updateFrequencies :148,186-210, encodeChunk :494-497)
-    if (tid == 0) {
+    // ---- unit 0: alphabet (EntropyUtils.go:46-60), code length deltas as signed Exp-Golomb codes (updateFrequencies
+    //      :148,186-210), one thread per alphabet entry: bit positions by a prefix sum, bits OR-ed into place ----------------------
+    uint32_t hdrBase;
+    if (count == 256) hdrBase = 2;                                      // '0' '0': full alphabet
+    else {
+        const uint32_t lastMask = (uint32_t)s_alpha[count - 1] >> 3;
+        hdrBase = 6 + 8 * (lastMask + 1);
+        if (tid == 0) atomicOr(&s_hdr[0], (1u << 31) | (lastMask << 26));
+        if ((uint32_t)tid <= lastMask) {
+            uint32_t mask = 0;
+            for (int bit = 0; bit < 8; bit++) mask |= (s_freq[8 * tid + bit] ? 1u : 0u) << bit;
+            const uint32_t p = 6 + 8 * (uint32_t)tid;                   // 8 bits at bit p
+            const uint32_t wi = p >> 5, off = p & 31;
+            if (off <= 24) atomicOr(&s_hdr[wi], mask << (24 - off));
+            else { atomicOr(&s_hdr[wi], mask >> (off - 24)); atomicOr(&s_hdr[wi + 1], mask << (56 - off)); }
+        }
+    }
+    uint32_t e = 0;
+    if (tid < count) {
+        const int cur = s_len[s_alpha[tid]];
+        const int prev = tid > 0 ? (int)s_len[s_alpha[tid - 1]] : 2;
+        e = knz_expg_signed((int)(int8_t)(uint8_t)(cur - prev));
+    }
+    const uint32_t elen = e >> 9;
+    const uint32_t eincl = wave_scan_incl(elen);
+    __syncthreads();                                                    // s_wsum is free again
+    if (lane == 63) s_wsum[wave] = eincl;
+    __syncthreads();
+    uint32_t epos = hdrBase + eincl - elen;
+    for (int w = 0; w < wave; w++) epos += s_wsum[w];
+    if (elen) {
+        const uint32_t bitsv = e & 0x1FF;
+        const uint32_t wi = epos >> 5, off = epos & 31;
+        if (off + elen <= 32) atomicOr(&s_hdr[wi], bitsv << (32 - off - elen));
+        else { atomicOr(&s_hdr[wi], bitsv >> (off + elen - 32)); atomicOr(&s_hdr[wi + 1], bitsv << (64 - off - elen)); }
+    }
+    const uint32_t hdrBits = hdrBase + s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    __syncthreads();
+    if (tid == 0) {                                                     // 4 varint fragment sizes (encodeChunk :494-497)
         KnzBitWriter bw;
         bw.init(s_hdr);
-        if (count == 256) { bw.put(0, 1); bw.put(0, 1); }     // EntropyUtils.go:46-51
-        else {
-            bw.put(1, 1);
-            int lastMask = s_alpha[count - 1] >> 3;
-            bw.put((uint32_t)lastMask, 5);
-            for (int m = 0; m <= lastMask; m++) {
-                uint32_t mask = 0;
-                for (int bit = 0; bit < 8; bit++) mask |= (s_freq[8 * m + bit] ? 1u : 0u) << bit;
-                bw.put(mask, 8);
-            }
-        }
-        int prev = 2;
-        for (int i = 0; i < count; i++) {
-            int cur = s_len[s_alpha[i]];
-            uint32_t e = knz_expg_signed((int)(int8_t)(uint8_t)(cur - prev));
-            bw.put(e & 0x1FF, e >> 9);
-            prev = cur;
-        }
+        bw.pos = hdrBits;
         if (count > 1) for (int j = 0; j < 4; j++) knz_put_varint(bw, s_fragbits[j]);
         s_data[0] = bw.pos;
     }

@@ -275,7 +275,17 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             a.data = nullptr; a.blk_off = h->blk_off.as<uint64_t>(); a.blk_len = h->blk_len.as<uint32_t>();
             a.chunks_per_block = cpb; a.scratch = h->scratch.as<uint8_t>(); a.unit_bits = h->unit_bits.as<uint32_t>(); a.unit_src = h->unit_src.as<uint32_t>();
             a.blk_status = h->blk_status.as<int32_t>();
-            if (cfg.entropy == KNZ_E_HUFFMAN) hipLaunchKernelGGL(knz_huf_encode_kernel, dim3(nblocks * cpb), dim3(256), 0, st, a);
+            if (cfg.entropy == KNZ_E_HUFFMAN) {
+                const uint32_t nc = nblocks * cpb, groups = (nc + 63) / 64;
+                if (h->huf_stfreq.reserve((size_t)groups * 256 * 64 * 2) || h->huf_stsym.reserve((size_t)groups * 256 * 64) ||
+                    h->huf_stlen.reserve((size_t)groups * 256 * 64) || h->huf_stcnt.reserve((size_t)groups * 64 * 2) || h->huf_stmax.reserve((size_t)groups * 64))
+                    return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
+                a.st_freq = h->huf_stfreq.as<uint16_t>(); a.st_sym = h->huf_stsym.as<uint8_t>(); a.st_len = h->huf_stlen.as<uint8_t>();
+                a.st_count = h->huf_stcnt.as<uint16_t>(); a.st_maxlen = h->huf_stmax.as<uint8_t>(); a.nchunks = nc;
+                hipLaunchKernelGGL(knz_huf_hist_kernel, dim3(nc), dim3(256), 0, st, a);
+                hipLaunchKernelGGL(knz_huf_lengths_kernel, dim3(groups), dim3(64), 0, st, a);
+                hipLaunchKernelGGL(knz_huf_encode_kernel, dim3(nc), dim3(256), 0, st, a);
+            }
             else hipLaunchKernelGGL(knz_raw_units_kernel, dim3(nblocks * cpb), dim3(256), 0, st, a);
         } else if (cfg.entropy == KNZ_E_FPAQ) {
             FpaqArgs a;

@@ -78,6 +78,9 @@ int lane() { return (int)(fibers[cur].tid & 63); }
 void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     unsigned nt = block.x * block.y * block.z;
     if (nt == 0 || nt > 1024) { fprintf(stderr, "hipemu: bad block size %u\n", nt); abort(); }
+    static unsigned long launchNo = 0;
+    launchNo++;
+    if (getenv("KNZ_EMU_TRACE")) fprintf(stderr, "hipemu: launch #%lu grid %u x %u block %u\n", launchNo, grid.x, grid.y, nt);
     const char* mode = getenv("KNZ_EMU_SCHED");
     int sched = 0; // 0 fwd, 1 rev, 2 random
     if (mode && !strcmp(mode, "rev")) sched = 1;
@@ -120,7 +123,15 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                 knz_emu_switch(&schedSp, f.sp);
                 if (f.done) remaining--;
             }
-            if (progress == lastProgress) { if (++stalls > 2) { fprintf(stderr, "hipemu: deadlock (divergent barrier / cross-lane op) in block %u\n", bx); abort(); } }
+            if (progress == lastProgress) {
+                if (++stalls > 2) {
+                    fprintf(stderr, "hipemu: deadlock (divergent barrier / cross-lane op) in block %u, %u of %u threads left, block barrier %u/%u, stuck:", bx, remaining, nt, blkArrived, blkAlive);
+                    for (unsigned i = 0, shown = 0; i < nt && shown < 12; i++) if (!fibers[i].done) { fprintf(stderr, " %u", i); shown++; }
+                    for (unsigned w = 0; w < (nt + 63) / 64; w++) fprintf(stderr, " [wave %u: %u/%u]", w, wvArrived[w], wvAlive[w]);
+                    fprintf(stderr, "\n");
+                    abort();
+                }
+            }
             else { stalls = 0; lastProgress = progress; }
         }
     }
