@@ -190,7 +190,7 @@ class BlockBatch:
         self.c = codec
 
     def encode(self, blocks):
-        """blocks: list of bytes. Returns [(block_local_stream_bytes, written_bits, mode, post_len)] like
+        """blocks: list of bytes. Returns [(block_local_stream_bytes, written_bits, mode, post_len, skip_flags)] like
         encodingTask.encode up to obs.Close() (v2/io/CompressedStream.go:729-914)."""
         n = len(blocks)
         arr = (_Block * n)()
@@ -205,8 +205,8 @@ class BlockBatch:
             arr[i].dst = o.ctypes.data
             arr[i].dst_cap = cap
         self.c._chk(self.c.L.knz_encode_blocks(self.c.h, arr, n))
-        return [(keep[i][1][: (arr[i].out_bits + 7) // 8].tobytes(), int(arr[i].out_bits), int(arr[i].mode), int(arr[i].post_len))
-                for i in range(n)]
+        return [(keep[i][1][: (arr[i].out_bits + 7) // 8].tobytes(), int(arr[i].out_bits), int(arr[i].mode), int(arr[i].post_len),
+                 int(arr[i].skip_flags)) for i in range(n)]
 
     def decode(self, payloads):
         """payloads: list of block-local streams. Returns the decoded blocks (decodingTask.decode :1875-2011)."""

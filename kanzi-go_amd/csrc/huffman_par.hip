@@ -26,6 +26,8 @@ __device__ unsigned long long g_knz_prof[32];
 #endif
 
 #define KNZ_HUF_SYNC_BITS 192        // look-back of the boundary search: ~20 codes, Huffman codes re-synchronise well within
+#define KNZ_HUF_LANE_CAP 100          // symbols a lane keeps from its decode pass (sub-ranges hold ~64); more -> a write pass.
+                                      // 25 dwords: an odd row stride spreads the 64 rows of a wave over all 32 LDS banks
 #define KNZ_HW_WORDS 136              // header window: 128 words + padding for the 64-bit look-ahead
 
 struct KnzHufHdr {
@@ -113,7 +115,7 @@ __device__ __forceinline__ KnzHufHdr knz_huf_parse_header_wave(const uint32_t* w
             pos = odd ? 32u : pos1 + (lng ? 2 * z + 2 : 0u);
             c += ones + ((lng && !odd) ? 1u : 0u);
         }
-        KNZ_PROF_INC(16, 1);
+
         uint32_t no = wave_shfl(pos - 32, lane - 1);
         if (lane == 0) no = 0;
         const bool changed = no != o;
@@ -200,12 +202,36 @@ __device__ __forceinline__ KnzHufHdr knz_huf_parse_header_wave(const uint32_t* w
     return h;
 }
 
+// Bit reader of one lane over a fragment sub-range: MSB-first, 64-bit window, words fetched THREE refills ahead (a refill
+// comes every ~6 symbols; one word of look-ahead left the s_waitcnt in front of an L2 round trip, SQ_WAIT_ANY was 64 % of the
+// wave cycles). Word indexes are relative to the chunk's first word and clamped to the stream end instead of tested.
+struct KnzFragReader {
+    const uint32_t* w;
+    uint32_t maxRel, next, navail, p0, p1, p2;
+    uint64_t win;
+    __device__ __forceinline__ uint32_t ld(uint32_t i) const { return w[min(i, maxRel)]; }
+    __device__ __forceinline__ void init(const uint32_t* chunkWords, uint32_t maxRelWord, uint32_t relbit) {
+        w = chunkWords; maxRel = maxRelWord;
+        const uint32_t q = relbit >> 5, off = relbit & 31;
+        const uint32_t a = ld(q), b = ld(q + 1);
+        p0 = ld(q + 2); p1 = ld(q + 3); p2 = ld(q + 4);
+        win = (((uint64_t)knz_bswap32(a) << 32) | knz_bswap32(b)) << off;
+        navail = 64 - off;
+        next = q + 5;
+    }
+    __device__ __forceinline__ uint32_t peek12() {
+        if (navail <= 32) { win |= (uint64_t)knz_bswap32(p0) << (32 - navail); navail += 32; p0 = p1; p1 = p2; p2 = ld(next); next++; }
+        return (uint32_t)(win >> 52);
+    }
+    __device__ __forceinline__ void consume(uint32_t n) { win <<= n; navail -= n; }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
 // One 256-thread workgroup per 16 KiB chunk: wave 0 parses the header, all threads build the code table, then wave j owns
 // fragment j and lane s its sub-range s of 64.
 __global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, uint8_t* fallback) {
     __shared__ uint16_t s_table[1 << KNZ_HUF_MAXLEN];
-    __shared__ __attribute__((aligned(16))) uint8_t s_outb[KNZ_HUF_CHUNK];
+    __shared__ __attribute__((aligned(16))) uint8_t s_outb[256 * KNZ_HUF_LANE_CAP];   // >= KNZ_HUF_CHUNK: lane buffers, then the chunk
     __shared__ uint32_t s_hw[KNZ_HW_WORDS];
     __shared__ uint8_t s_len[256];
     __shared__ uint8_t s_alpha[256];
@@ -213,7 +239,7 @@ __global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, u
     __shared__ uint8_t s_symAt[256];
     __shared__ uint32_t s_cnt[4][16];
     __shared__ KnzHufHdr s_hdr;
-    __shared__ int s_flag;
+    __shared__ int s_flag, s_over;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t cpb = a.chunks_per_block;
@@ -244,7 +270,7 @@ __global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, u
         const uint64_t nwords = (a.nbytes + 3) >> 2, w0i = cbit >> 5;
         if (tid < KNZ_HW_WORDS) s_hw[tid] = (w0i + tid < nwords) ? knz_bswap32(words[w0i + tid]) : 0u;
         s_len[tid] = 0;
-        if (tid == 0) s_flag = 0;
+        if (tid == 0) { s_flag = 0; s_over = 0; }
     }
     __syncthreads();
     if (wave == 0) {
@@ -324,6 +350,11 @@ __global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, u
     bool sane = (int32_t)(hdr.fb[0] | hdr.fb[1] | hdr.fb[2] | hdr.fb[3]) >= 0 && tailpos + 8ull * (n & 3) <= limit + 7;
     sane = sane && fbj <= 12u * F;                                      // a symbol costs at most 12 bits
     uint32_t st = 0, nsym = 0, e = 0, off = 0;
+    // fragment positions relative to the chunk's first word (< 2^18 bits once `sane` holds)
+    const uint32_t* cwords = (const uint32_t*)a.stream + (cbit >> 5);
+    const uint64_t nwordsAll = (a.nbytes + 3) >> 2;
+    const uint32_t maxRel = (cbit >> 5) < nwordsAll ? (uint32_t)min((uint64_t)0x7FFFFFFFu, nwordsAll - 1 - (cbit >> 5)) : 0u;
+    const uint32_t fpRel = (uint32_t)(fp - ((cbit >> 5) << 5));
     if (sane) {
         const uint32_t B = (fbj + 63) >> 6;
         const uint32_t E = min(fbj, (s + 1) * B);
@@ -333,10 +364,10 @@ __global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, u
         st = R;
         if (s > 0 && R < fbj) {
             uint32_t pos = R > KNZ_HUF_SYNC_BITS ? R - KNZ_HUF_SYNC_BITS : 0u;
-            KnzStreamReader r;
-            r.init(a.stream, a.nbytes, fp + pos);
+            KnzFragReader r;
+            r.init(cwords, maxRel, fpRel + pos);
             while (pos < R) {
-                const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)];
+                const uint32_t val = s_table[r.peek12()];
                 r.consume(val & 0xFF);
                 pos += val & 0xFF;
             }
@@ -346,13 +377,15 @@ __global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, u
         bool redo = true;
         for (int round = 0; ; round++) {
             if (redo) {
-                KnzStreamReader r;
-                r.init(a.stream, a.nbytes, fp + st);
+                KnzFragReader r;
+                r.init(cwords, maxRel, fpRel + st);
                 uint32_t pos = st, cnt = 0;
+                uint8_t* mine = s_outb + (size_t)tid * KNZ_HUF_LANE_CAP;       // the symbols stay in my LDS row (clamped)
                 while (pos < E) {
-                    const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)];
+                    const uint32_t val = s_table[r.peek12()];
                     r.consume(val & 0xFF);
                     pos += val & 0xFF;
+                    mine[min(cnt, (uint32_t)KNZ_HUF_LANE_CAP - 1)] = (uint8_t)(val >> 8);
                     cnt++;
                 }
                 nsym = cnt; e = pos;
@@ -373,16 +406,40 @@ __global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, u
         if (s == 63 && !(incl == F && e == fbj)) sane = false;
     }
     if (wave_ballot(!sane) != 0 && lane == 0) s_flag = 1;
+    if (wave_ballot(nsym > KNZ_HUF_LANE_CAP) != 0 && lane == 0) s_over = 1;
     __syncthreads();
     KNZ_PROF_T(t3);
     KNZ_PROF_ADD(2, t2, t3);
     if (s_flag) { if (tid == 0) fallback[blockIdx.x] = 1; return; }
-    {
-        KnzStreamReader r;
-        r.init(a.stream, a.nbytes, fp + st);
+    KNZ_PROF_INC(24, s_over ? 1 : 0);
+    if (!s_over) {
+        // every lane kept all of its symbols: pull the row into registers, then (the rows and the chunk share the LDS area)
+        // store it at its place j*F + off: whole words through a byte funnel, the ragged ends byte by byte
+        uint32_t row[KNZ_HUF_LANE_CAP / 4];
+#pragma unroll
+        for (int m = 0; m < KNZ_HUF_LANE_CAP / 4; m++) row[m] = ((const uint32_t*)(s_outb + (size_t)tid * KNZ_HUF_LANE_CAP))[m];
+        __syncthreads();
+        const uint32_t d0 = j * F + off, aoff = d0 & 3;
+        uint32_t* wout = (uint32_t*)s_outb + (d0 >> 2);
+#pragma unroll
+        for (int m = 0; m <= KNZ_HUF_LANE_CAP / 4; m++) {
+            // destination word m holds my bytes [4m - aoff, 4m - aoff + 4)
+            const uint32_t lo = m > 0 ? row[m > 0 ? m - 1 : 0] : 0u, hi = m < KNZ_HUF_LANE_CAP / 4 ? row[m < KNZ_HUF_LANE_CAP / 4 ? m : 0] : 0u;
+            const uint32_t v = aoff ? (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (4 - aoff))) : hi;
+            const int b0 = 4 * m - (int)aoff;                       // first source byte of this word
+            if (b0 >= 0 && b0 + 4 <= (int)nsym) wout[m] = v;
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (b0 + q >= 0 && b0 + q < (int)nsym) ((uint8_t*)(wout + m))[q] = (uint8_t)(v >> (8 * q));
+            }
+        }
+    } else {
+        __syncthreads();
+        KnzFragReader r;
+        r.init(cwords, maxRel, fpRel + st);
         uint8_t* o = s_outb + (size_t)j * F + off;
         for (uint32_t i = 0; i < nsym; i++) {
-            const uint32_t val = s_table[r.peek(KNZ_HUF_MAXLEN)];
+            const uint32_t val = s_table[r.peek12()];
             r.consume(val & 0xFF);
             o[i] = (uint8_t)(val >> 8);
         }

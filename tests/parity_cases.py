@@ -156,11 +156,12 @@ def check_block_batch(be, transform, entropy, block_size, nblocks, last_len):
     blocks = [corpus(block_size, 10 + i) for i in range(nblocks - 1)] + [corpus(last_len, 99)]
     res = bb.encode(blocks)
     tt, et = O.transform_type(transform), O.entropy_type(entropy)
-    for blk, (bits, written, mode, post) in zip(blocks, res):
+    for blk, (bits, written, mode, post, skip) in zip(blocks, res):
         o = O.encode_block(blk, tt, et)
         assert written == o["written"]
         assert bits == o["bits"]
         assert mode == o["mode"] and post == o["post_len"]
+        assert skip == o["skip_flags"], (skip, o["skip_flags"])
     back = bb.decode([r[0] for r in res])
     assert back == blocks
     c.close()
@@ -256,4 +257,80 @@ def check_transform(be, tname, max_len=1 << 30):
         back = t.inverse(o, len(data) + max(512, len(data) >> 4))
         assert back == data, (tname, name)
     assert applied >= 6
+    c.close()
+
+
+def _huffman_header_with_wrapped_delta(payload, nbits):
+    """Re-encodes one negative code-length delta (-2..-11) of a Huffman chunk header with the 16-bit Exp-Golomb form whose
+    magnitude wraps as int8 (ExpGolombCodec.go:159-190, readLengths casts to int8): a stream no kanzi encoder writes but
+    every kanzi decoder accepts. Returns (payload', nbits') or None when the header holds no such delta."""
+    bits = "".join(f"{b:08b}" for b in payload)[:nbits]
+    pos = 0
+    if bits[0] == "0":
+        assert bits[1] == "0"
+        count, pos = 256, 2
+    else:
+        last = int(bits[1:6], 2)
+        pos = 6
+        count = 0
+        for _ in range(last + 1):
+            count += bits[pos:pos + 8].count("1")
+            pos += 8
+    for _ in range(count):
+        if bits[pos] == "1":
+            pos += 1
+            continue
+        z = 0
+        while bits[pos + z] == "0":
+            z += 1
+        val = int(bits[pos + z + 1: pos + 2 * z + 2], 2)
+        mag = (val >> 1) + (1 << z) - 1
+        if (val & 1) and 2 <= mag <= 11:
+            wrapped = "0000000" + "1" + f"{((256 - mag - 127) << 1):08b}"    # res = 256 - mag, int8(res) = -mag
+            nb = bits[:pos] + wrapped + bits[pos + 2 * z + 2:]
+            out = bytes(int(nb[i:i + 8].ljust(8, "0"), 2) for i in range(0, len(nb), 8))
+            return out, len(nb)
+        pos += 2 * z + 2
+    return None
+
+
+def check_huffman_shapes(be):
+    """Inputs that drive the parallel Huffman decoder down its less common paths: many synchronisation rounds
+    (incompressible bytes), more symbols in a lane than its LDS row holds (long runs of a 1-bit code between 9-bit codes),
+    and a header only the serial parser takes (int8-wrapped Exp-Golomb delta)."""
+    rng = np.random.default_rng(11)
+    n = 5 * 16384 + 1234
+    runs = np.empty(n, dtype=np.uint8)
+    for i in range(0, n, 1024):
+        runs[i:i + 512] = 65
+        runs[i + 512:i + 1024] = rng.integers(0, 256, len(runs[i + 512:i + 1024]), dtype=np.uint8)
+    cases = [("rand", rng.integers(0, 256, n, dtype=np.uint8).tobytes()), ("runs", runs.tobytes())]
+    for name, data in cases:
+        c = K.Codec("NONE", "HUFFMAN", 1 << 16, lib=be.lib)
+        exp = O.compress(data, "NONE", "HUFFMAN", 1 << 16)
+        sp, ks = be.to_dev(exp, 4)
+        out, kout = be.empty(len(data) + 64)
+        nd = c.dev_decompress(sp, len(exp), out, len(data) + 64)
+        assert nd == len(data) and be.to_host(kout, nd) == data, name
+        assert c.last_counter(0) == 0, name
+        c.close()
+    # the header the parallel parser must hand back
+    c = K.Codec("NONE", "HUFFMAN", 1 << 16, lib=be.lib)
+    dec = K.EntropyDecoder(c, "HUFFMAN")
+    et = O.entropy_type("HUFFMAN")
+    done = False
+    for seed in range(8):
+        data = np.minimum(np.random.default_rng(seed).geometric(0.03, 9000), 255).astype(np.uint8).tobytes()
+        ob, obits = O.entropy_encode(et, data)
+        alt = _huffman_header_with_wrapped_delta(ob, obits)
+        if alt is None:
+            continue
+        ab, abits = alt
+        assert O.entropy_decode(et, ab, len(data))[0] == data          # the reference-order decoder accepts it
+        dd, used = dec.read(ab, len(data))
+        assert dd == data and used == abits
+        assert c.last_counter(0) == 1                                   # ... and the device took its serial path for it
+        done = True
+        break
+    assert done, "no negative delta found in 8 headers"
     c.close()

@@ -65,3 +65,7 @@ def test_transform_objects_bit_exact(be, tname):
 def test_block_batch_hook_transforms(be):
     P.check_block_batch(be, "BWT+RANK+ZRLT", "ANS1", 1 << 13, 3, 4321)
     P.check_block_batch(be, "BWT+RANK+ZRLT", "ANS0", 1 << 13, 2, 9)
+
+
+def test_huffman_decoder_paths(be):
+    P.check_huffman_shapes(be)

@@ -126,3 +126,7 @@ def test_config4_8m_blocks(be):
     assert c.dev_decompress(dst, nb, out, len(ramp) + 64) == len(ramp)
     assert be.to_host(ko, len(ramp)) == ramp
     c.close()
+
+
+def test_huffman_decoder_paths(be):
+    P.check_huffman_shapes(be)

@@ -30,7 +30,7 @@ L.knz_debug_prof(buf, 0)
 names = {0: "dec stage+parse", 1: "dec table", 2: "dec sync passes", 3: "dec write pass", 4: "dec copy out", 5: "dec total",
          8: "walk fill+issue", 9: "walk window copy", 10: "walk parse", 11: "walk ring store",
          16: "EG rounds (both)", 17: "parse alphabet", 18: "parse EG rounds", 19: "parse scan+end", 20: "parse lengths", 21: "parse varints",
-         22: "parses", 23: "sum count"}
+         22: "parses", 23: "sum count", 24: "chunks with a write pass"}
 chunks = (n + 16383) // 16384
 for i, nm in names.items():
     print(f"{nm:20s} total {buf[i]:>14d} ticks   per chunk {buf[i] / chunks:10.1f}")
