@@ -547,14 +547,20 @@ __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs 
                     *(uint4*)&s_ring[(ringHi + 4 * threadIdx.x) & (KNZ_WALK_RING - 1)] = v;
                     ringHi += 256;
                 }
-                // prefetch: issue now, store behind the parse
-                uint4 pf[KNZ_WALK_PF];
+                // prefetch: issue now, store behind the parse. Only granules that lie wholly inside the stream (the ragged end
+                // is left to the blocking path above), so the loop is a pointer walk without bounds tests.
+                uint32_t pf[KNZ_WALK_PF][4];                          // (scalar elements: an array of uint4 lands in scratch)
                 const uint64_t pfBase = ringHi;
                 uint32_t groups = 0;
                 if (w0i + KNZ_WALK_AHEAD > ringHi) groups = (uint32_t)min((uint64_t)KNZ_WALK_PF, (w0i + KNZ_WALK_AHEAD - ringHi + 255) >> 8);
+                const uint64_t wholeGranules = snwords >> 8;
+                groups = (pfBase >> 8) >= wholeGranules ? 0u : (uint32_t)min((uint64_t)groups, wholeGranules - (pfBase >> 8));
+                {
+                    const uint4* gp = (const uint4*)swords + (pfBase >> 2) + threadIdx.x;
 #pragma unroll
-                for (int g = 0; g < KNZ_WALK_PF; g++)
-                    if ((uint32_t)g < groups) pf[g] = knz_walk_load_granule(swords, snwords, pfBase + 256 * g, (int)threadIdx.x);
+                    for (int g = 0; g < KNZ_WALK_PF; g++)
+                        if ((uint32_t)g < groups) { const uint4 v = gp[64 * g]; pf[g][0] = v.x; pf[g][1] = v.y; pf[g][2] = v.z; pf[g][3] = v.w; }
+                }
                 KNZ_PROF_T(w1);
                 wave_sync_lds();
                 for (uint32_t i = threadIdx.x; i < KNZ_HW_WORDS; i += 64) s_hw[i] = knz_bswap32(s_ring[(w0i + i) & (KNZ_WALK_RING - 1)]);
@@ -563,9 +569,15 @@ __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs 
                 const KnzHufHdr hdr = knz_huf_parse_header_wave<false>(s_hw, (uint32_t)(pos & 31), nullptr, nullptr, (int)threadIdx.x);
                 wave_sync_lds();
                 KNZ_PROF_T(w3);
+                {
+                    const uint32_t r0 = (uint32_t)(pfBase & (KNZ_WALK_RING - 1)) + 4 * threadIdx.x;   // granules never straddle the ring end
 #pragma unroll
-                for (int g = 0; g < KNZ_WALK_PF; g++)
-                    if ((uint32_t)g < groups) *(uint4*)&s_ring[(pfBase + 256 * g + 4 * threadIdx.x) & (KNZ_WALK_RING - 1)] = pf[g];
+                    for (int g = 0; g < KNZ_WALK_PF; g++)
+                        if ((uint32_t)g < groups) {
+                            uint4 v; v.x = pf[g][0]; v.y = pf[g][1]; v.z = pf[g][2]; v.w = pf[g][3];
+                            *(uint4*)&s_ring[(r0 + 256 * g) & (KNZ_WALK_RING - 1)] = v;
+                        }
+                }
                 ringHi = pfBase + 256ull * groups;
                 KNZ_PROF_T(w4);
                 KNZ_PROF_ADD(8, w0, w1); KNZ_PROF_ADD(9, w1, w2); KNZ_PROF_ADD(10, w2, w3); KNZ_PROF_ADD(11, w3, w4);

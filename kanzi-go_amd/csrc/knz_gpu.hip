@@ -10,6 +10,7 @@
 #include "transforms.hip"
 #include "bwt.hip"
 #include "lz.hip"
+#include "xxhash.hip"
 #include "prims.h"
 #include "layout.hip"
 #include <algorithm>
@@ -262,6 +263,12 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
         }
     }
     hipEventRecord(h->ev[0], st);
+    if (nblocks && cfg.checksum_bits != 0) {        // checksum of the untransformed block (encodingTask.encode :760-767)
+        XxhArgs xa;
+        xa.nblocks = nblocks; xa.ptr = h->blk_off.as<uint64_t>(); xa.len = h->blk_len.as<uint32_t>(); xa.cksum = h->blk_cksum.as<uint64_t>();
+        xa.status = h->blk_status.as<int32_t>(); xa.mode = nullptr; xa.bits = cfg.checksum_bits; xa.verify = 0;
+        hipLaunchKernelGGL(knz_xxhash_kernel, dim3(nblocks), dim3(64), 0, st, xa);
+    }
     if (nblocks && cfg.transform != 0) {
         xb.cur_ptr = h->blk_off.as<uint64_t>(); xb.cur_len = h->blk_len.as<uint32_t>(); xb.skip = h->blk_skip.as<uint8_t>();
         xb.blk_status = h->blk_status.as<int32_t>();

@@ -334,3 +334,44 @@ def check_huffman_shapes(be):
         break
     assert done, "no negative delta found in 8 headers"
     c.close()
+
+
+def check_checksums(be):
+    """-x / --checksum: XXHash32/64 of every block on the device (stream bit-exact vs the oracle, verified on decode,
+    a flipped payload bit is reported as ERR_CRC_CHECK = 19 like decodingTask.decode)."""
+    n, bs = 3 * 65536 + 4321, 65536
+    data = corpus(n, 21)
+    for bits in (32, 64):
+        for transform, entropy in (("NONE", "HUFFMAN"), ("RANK+ZRLT", "ANS0")):
+            c = K.Codec(transform, entropy, bs, checksum_bits=bits, lib=be.lib)
+            src, ks = be.to_dev(data)
+            cap = 2 * n + 262144
+            dst, kd = be.empty(cap)
+            nb = c.dev_compress(src, n, dst, cap)
+            got = be.to_host(kd, nb)
+            exp = O.compress(data, transform, entropy, bs, checksum_bits=bits)
+            assert got == exp, (bits, transform)
+            out, ko = be.empty(n + 64)
+            assert c.dev_decompress(dst, nb, out, n + 64) == n
+            assert be.to_host(ko, n) == data
+            # flip one bit of the last block's payload: the entropy decoder still runs, the checksum catches it
+            bad = bytearray(exp)
+            bad[len(bad) - 40] ^= 0x10
+            sp, ksp = be.to_dev(bytes(bad), 4)
+            try:
+                c.dev_decompress(sp, len(bad), out, n + 64)
+                raised = None
+            except K.KnzError as e:
+                raised = e.code
+            assert raised in (19, 13), raised       # CRC mismatch (or a payload the entropy decoder already rejects)
+            c.close()
+    # batch hook: per-block checksum value
+    c = K.Codec("NONE", "HUFFMAN", bs, checksum_bits=32, lib=be.lib)
+    bb = K.BlockBatch(c)
+    for blocks in ([corpus(bs, 30), corpus(1000, 31)], [corpus(bs, 32), b"tiny"]):
+        res = bb.encode(blocks)
+        for blk, r in zip(blocks, res):
+            o = O.encode_block(blk, O.transform_type("NONE"), O.entropy_type("HUFFMAN"), 32)
+            assert r[0] == o["bits"] and r[1] == o["written"]
+        assert bb.decode([r[0] for r in res]) == blocks
+    c.close()

@@ -69,3 +69,7 @@ def test_block_batch_hook_transforms(be):
 
 def test_huffman_decoder_paths(be):
     P.check_huffman_shapes(be)
+
+
+def test_block_checksums(be):
+    P.check_checksums(be)

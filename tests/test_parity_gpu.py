@@ -130,3 +130,7 @@ def test_config4_8m_blocks(be):
 
 def test_huffman_decoder_paths(be):
     P.check_huffman_shapes(be)
+
+
+def test_block_checksums(be):
+    P.check_checksums(be)
