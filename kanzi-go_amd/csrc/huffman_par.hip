@@ -49,6 +49,99 @@ __device__ __forceinline__ uint32_t knz_top32(uint32_t hi, uint32_t lo, uint32_t
     return pos ? ((hi << pos) | (lo >> (32 - pos))) : hi;
 }
 
+// The signed Exp-Golomb code-length deltas of a chunk header (readLengths, HuffmanCodec.go:620-657; ExpGolombCodec.go:159-190),
+// `count` codes from bit e0 of the window. Lane l owns the codes that START in bits [p0, p0 + W) of the section, p0 = e0 + W*l.
+// It assumes a code boundary at its entry offset, walks to the first boundary at or past p0 + W (a run of '1' = delta 0 codes
+// and at most one longer code per step, no branches) and hands that offset to its neighbour, until nothing moves: lane 0 is
+// exact, and these codes re-synchronise within a few bits, so this takes 2-3 rounds instead of `count` serial steps.
+// Returns 0 and the bit offset just past the section, 1 when the serial parser has to take over (a delta a Go encoder never
+// writes, or a section longer than 64 * W bits), 2 for an invalid length.
+template <bool WANT_LEN, int W>
+__device__ __forceinline__ uint32_t knz_huf_delta_section(const uint32_t* w, uint32_t e0, uint32_t count, uint8_t* s_alpha, uint8_t* s_len, int lane, uint32_t& endOut) {
+    const uint32_t p0 = e0 + (uint32_t)W * (uint32_t)lane;
+    const uint32_t whi = knz_win32(w, p0), wlo = knz_win32(w, p0 + 32);
+    const uint64_t win = ((uint64_t)whi << 32) | wlo;
+    const bool relevant = (uint32_t)lane <= (count * 8 + W - 1) / W;     // a usual code has at most 8 bits
+    uint32_t o = 0, c = 0;
+    int ds = 0;
+    bool odd = false;
+    for (int rounds = 0; ; rounds++) {
+        uint32_t pos = relevant ? o : (uint32_t)W;                       // lanes behind the section carry nothing
+        c = 0; ds = 0; odd = false;
+        while (pos < (uint32_t)W) {
+            const uint32_t bits = knz_top32(whi, wlo, pos);
+            const uint32_t ones = min((uint32_t)__builtin_clz(~bits | 1u), (uint32_t)W - pos);
+            const uint32_t pos1 = pos + ones;
+            const uint32_t b2 = knz_top32(whi, wlo, pos1 & 31);
+            const bool lng = pos1 < (uint32_t)W && !(b2 >> 31);            // a code with leading zeros starts inside my bits
+            const uint32_t z = (uint32_t)__builtin_clz(b2 | 1u);
+            if (lng && z > 3) odd = true;                                  // not a length delta a Go encoder writes
+            if (WANT_LEN) {
+                const uint32_t zz = z & 3;
+                const uint32_t val = (b2 << (zz + 1)) >> (31 - zz);       // the z+1 bits behind the terminator
+                const int mag = (int)((val >> 1) + (1u << zz) - 1u);
+                ds += lng ? ((val & 1) ? -mag : mag) : 0;
+            }
+            pos = odd ? (uint32_t)W : pos1 + (lng ? 2 * z + 2 : 0u);
+            c += ones + ((lng && !odd) ? 1u : 0u);
+        }
+        uint32_t no = wave_shfl(pos - (uint32_t)W, lane - 1);
+        if (lane == 0) no = 0;
+        const bool changed = no != o;
+        o = no;
+#ifdef KNZ_EMU_STATS
+        if (lane == 0) { extern unsigned long long g_stat[8]; g_stat[1]++; }
+#endif
+        if (wave_ballot(changed && relevant) == 0) break;
+        if (rounds > 66) return 1;
+    }
+    const uint32_t cincl = wave_scan_incl(c);
+    const uint32_t idx0 = cincl - c;
+    // the lane holding code count-1; every lane before it must be made of usual codes
+    const uint64_t em = wave_ballot(idx0 < count && idx0 + c >= count);
+    const uint64_t om = wave_ballot(odd);
+    if (em == 0) return 1;                                               // section longer than 64 x W bits
+    const uint32_t endLane = (uint32_t)(__ffsll((unsigned long long)em) - 1);
+    // (an unusual pattern in the end lane itself lies behind the section: its codes are counted up to that point only)
+    if (om != 0 && (uint32_t)(__ffsll((unsigned long long)om) - 1) < endLane) return 1;
+    uint32_t myEnd = 0;
+    if ((uint32_t)lane == endLane) {
+        uint32_t pos = o, idx = idx0;
+        while (idx < count) {
+            const uint32_t bits = (uint32_t)((win << pos) >> 32);
+            const uint32_t ones = (uint32_t)__builtin_clz(~bits | 1u);
+            if (ones) { const uint32_t take = min(ones, count - idx); idx += take; pos += take; continue; }
+            pos += 2u * (uint32_t)__builtin_clz(bits | 1u) + 2u;
+            idx++;
+        }
+        myEnd = p0 + pos;
+    }
+    endOut = wave_readlane(myEnd, endLane);
+    if (WANT_LEN) {
+        wave_sync_lds();                                                 // s_alpha
+        const int dincl = (int)wave_scan_incl((uint32_t)ds);
+        int cur = 2 + dincl - ds;
+        bool bad = false;
+        uint32_t pos = (uint32_t)lane <= endLane ? o : (uint32_t)W, idx = idx0;
+        while (pos < (uint32_t)W && idx < count) {
+            const uint32_t bits = (uint32_t)((win << pos) >> 32);
+            if (bits >> 31) pos += 1;
+            else {
+                const uint32_t z = (uint32_t)__builtin_clz(bits | 1u);
+                const uint32_t val = (bits << (z + 1)) >> (31 - z);
+                const int mag = (int)((val >> 1) + (1u << z) - 1u);
+                cur += (val & 1) ? -mag : mag;
+                pos += 2 * z + 2;
+            }
+            if (cur <= 0 || cur > KNZ_HUF_MAXLEN) { bad = true; break; }     // readLengths :640-645
+            s_len[s_alpha[idx]] = (uint8_t)cur;
+            idx++;
+        }
+        if (wave_ballot(bad) != 0) return 2;
+    }
+    return 0;
+}
+
 // w: window of BE words (LDS), h0: bit offset of the chunk header inside it (< 32). All 64 lanes
 // of ONE wave call it; the result is wave-uniform. WANT_LEN: also fill s_alpha[0..count) and s_len[symbol] (zeroed by the
 // caller).
@@ -83,95 +176,13 @@ __device__ __forceinline__ KnzHufHdr knz_huf_parse_header_wave(const uint32_t* w
         if (count == 0) { h.status = 2; return h; }
     }
     h.count = count;
-    // ---- code-length deltas: lane l owns the codes that START in bits [p0, p0 + 32) of the section. It assumes a boundary at
-    //      its entry offset, walks to the first boundary at or past p0 + 32 (runs of '1' = delta 0 in one step, count leading
-    //      zeros for the others) and hands that offset to its neighbour, until nothing moves ----------------------------------
     KNZ_PROF_T(p0t);
-    const uint32_t p0 = e0 + 32u * (uint32_t)lane;
-    const uint32_t whi = knz_win32(w, p0), wlo = knz_win32(w, p0 + 32);
-    const uint64_t win = ((uint64_t)whi << 32) | wlo;
-    const bool relevant = (uint32_t)lane <= (count * 8 + 31) / 32;       // a usual code has at most 8 bits
-    uint32_t o = 0, c = 0;
-    int ds = 0;
-    bool odd = false;
-    for (int rounds = 0; ; rounds++) {
-        uint32_t pos = relevant ? o : 32u;                               // lanes behind the section carry nothing
-        c = 0; ds = 0; odd = false;
-        while (pos < 32) {
-            // one step = a run of '1' (delta 0 each) followed by at most one longer code, without branches
-            const uint32_t bits = knz_top32(whi, wlo, pos);
-            const uint32_t ones = min((uint32_t)__builtin_clz(~bits | 1u), 32u - pos);
-            const uint32_t pos1 = pos + ones;
-            const uint32_t b2 = knz_top32(whi, wlo, pos1 & 31);
-            const bool lng = pos1 < 32 && !(b2 >> 31);                     // a code with leading zeros starts inside my bits
-            const uint32_t z = (uint32_t)__builtin_clz(b2 | 1u);
-            if (lng && z > 3) odd = true;                                  // not a length delta a Go encoder writes
-            if (WANT_LEN) {
-                const uint32_t zz = z & 3;
-                const uint32_t val = (b2 << (zz + 1)) >> (31 - zz);       // the z+1 bits behind the terminator
-                const int mag = (int)((val >> 1) + (1u << zz) - 1u);
-                ds += lng ? ((val & 1) ? -mag : mag) : 0;
-            }
-            pos = odd ? 32u : pos1 + (lng ? 2 * z + 2 : 0u);
-            c += ones + ((lng && !odd) ? 1u : 0u);
-        }
-
-        uint32_t no = wave_shfl(pos - 32, lane - 1);
-        if (lane == 0) no = 0;
-        const bool changed = no != o;
-        o = no;
-#ifdef KNZ_EMU_STATS
-        if (lane == 0) { extern unsigned long long g_stat[8]; g_stat[1]++; }
-#endif
-        if (wave_ballot(changed && relevant) == 0) break;
-        if (rounds > 66) { h.status = 1; return h; }
-    }
-    KNZ_PROF_T(p1);
-    const uint32_t cincl = wave_scan_incl(c);
-    const uint32_t idx0 = cincl - c;
-    // the lane holding code count-1; every lane before it must be made of usual codes
-    const uint64_t em = wave_ballot(idx0 < count && idx0 + c >= count);
-    const uint64_t om = wave_ballot(odd);
-    if (em == 0) { h.status = 1; return h; }                           // section longer than 64 x 32 bits
-    const uint32_t endLane = (uint32_t)(__ffsll((unsigned long long)em) - 1);
-    // (an unusual pattern in the end lane itself lies behind the section: its codes are counted up to that point only)
-    if (om != 0 && (uint32_t)(__ffsll((unsigned long long)om) - 1) < endLane) { h.status = 1; return h; }
-    uint32_t myEnd = 0;
-    if ((uint32_t)lane == endLane) {
-        uint32_t pos = o, idx = idx0;
-        while (idx < count) {
-            const uint32_t bits = (uint32_t)((win << pos) >> 32);
-            const uint32_t ones = (uint32_t)__builtin_clz(~bits | 1u);
-            if (ones) { const uint32_t take = min(ones, count - idx); idx += take; pos += take; continue; }
-            pos += 2u * (uint32_t)__builtin_clz(bits | 1u) + 2u;
-            idx++;
-        }
-        myEnd = p0 + pos;
-    }
-    const uint32_t end = wave_readlane(myEnd, endLane);
-    KNZ_PROF_T(p2);
-    if (WANT_LEN) {
-        wave_sync_lds();                                                 // s_alpha
-        const int dincl = (int)wave_scan_incl((uint32_t)ds);
-        int cur = 2 + dincl - ds;
-        bool bad = false;
-        uint32_t pos = (uint32_t)lane <= endLane ? o : 32u, idx = idx0;
-        while (pos < 32 && idx < count) {
-            const uint32_t bits = (uint32_t)((win << pos) >> 32);
-            if (bits >> 31) pos += 1;
-            else {
-                const uint32_t z = (uint32_t)__builtin_clz(bits | 1u);
-                const uint32_t val = (bits << (z + 1)) >> (31 - z);
-                const int mag = (int)((val >> 1) + (1u << z) - 1u);
-                cur += (val & 1) ? -mag : mag;
-                pos += 2 * z + 2;
-            }
-            if (cur <= 0 || cur > KNZ_HUF_MAXLEN) { bad = true; break; }     // readLengths :640-645
-            s_len[s_alpha[idx]] = (uint8_t)cur;
-            idx++;
-        }
-        if (wave_ballot(bad) != 0) { h.status = 2; return h; }
-    }
+    // ---- code-length deltas: 16 bits of the section per lane when that can cover it, 32 otherwise ----------------------------
+    uint32_t end = 0;
+    uint32_t est = 1;
+    if (count <= 192) est = knz_huf_delta_section<WANT_LEN, 16>(w, e0, count, s_alpha, s_len, lane, end);
+    if (est == 1) est = knz_huf_delta_section<WANT_LEN, 32>(w, e0, count, s_alpha, s_len, lane, end);   // (section longer than 64 x 16 bits)
+    if (est != 0) { h.status = est; return h; }
     KNZ_PROF_T(p3);
     h.end = end;
     // ---- fragment sizes: 4 varints (EntropyUtils.go:278-296), bytes fetched by 20 lanes, assembled on the scalar unit ------
@@ -198,7 +209,7 @@ __device__ __forceinline__ KnzHufHdr knz_huf_parse_header_wave(const uint32_t* w
         h.end = end + 8 * at[4];
     }
     KNZ_PROF_T(p4);
-    KNZ_PROF_ADD(17, pA, p0t); KNZ_PROF_ADD(18, p0t, p1); KNZ_PROF_ADD(19, p1, p2); KNZ_PROF_ADD(20, p2, p3); KNZ_PROF_ADD(21, p3, p4); KNZ_PROF_INC(22, 1); KNZ_PROF_INC(23, count);
+    KNZ_PROF_ADD(17, pA, p0t); KNZ_PROF_ADD(18, p0t, p3); KNZ_PROF_ADD(21, p3, p4); KNZ_PROF_INC(22, 1); KNZ_PROF_INC(23, count);
     return h;
 }
 
