@@ -194,8 +194,8 @@ def main():
         per_launch = {k: v / K_ for k, v in stage.items()}
         n_local, c_local = n_my, (result.get("seg_bits", C_bytes * 8) + 7) // 8 if world > 1 else C_bytes
         kern = {
-            {"HUFFMAN": "knz_huf_encode_kernel", "ANS0": "knz_ans0_stats+encode_kernels", "ANS1": "knz_ans1_hist+stats+merge+encode_kernels", "FPAQ": "knz_fpaq_encode_kernel"}[entropy]: (per_launch["enc_entropy"], n_local + c_local),
-            {"HUFFMAN": "knz_huf_decode_kernel", "ANS0": "knz_ans0_decode_kernel", "ANS1": "knz_ans1_dec_tables+decode_kernels", "FPAQ": "knz_fpaq_decode_kernel"}[entropy]: (per_launch["dec_entropy"], n_local + c_local),
+            {"HUFFMAN": "knz_huf_hist+lengths+encode_kernels", "ANS0": "knz_ans0_stats+encode_kernels", "ANS1": "knz_ans1_hist+stats+merge+encode_kernels", "FPAQ": "knz_fpaq_encode_kernel"}[entropy]: (per_launch["enc_entropy"], n_local + c_local),
+            {"HUFFMAN": "knz_huf_decode_par_kernel", "ANS0": "knz_ans0_decode_kernel", "ANS1": "knz_ans1_dec_tables+decode_kernels", "FPAQ": "knz_fpaq_decode_kernel"}[entropy]: (per_launch["dec_entropy"], n_local + c_local),
             "knz_dec_walk_blocks_kernel": (per_launch["dec_walk"], c_local),
             "forward transform stage kernels (" + transform + ")": (per_launch["enc_transform"], 2 * n_local),
             "inverse transform stage kernels (" + transform + ")": (per_launch["dec_transform"], 2 * n_local),
@@ -205,7 +205,7 @@ def main():
         ach = alg / 1e9 / (dur_ms / 1e3) if dur_ms > 0 else 0.0
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/, see its _how)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_config2.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_config2_v2.json")))
             if args.config == "huffman" and world == 1 and not args.size and dom in pm["kernels"]:
                 traffic = pm["kernels"][dom]["hbm_bytes_corrected"]
         except Exception:
