@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, u
 // their data-dependent loops diverge and the wave then pays for the union of all paths.
 #define KNZ_WALK_RING 8192            // words of the stream kept ahead of the walk (32 KiB, power of two)
 #define KNZ_WALK_AHEAD 6656           // prefetch target: 26 KiB past the current chunk start (a chunk is < 25 KiB)
-#define KNZ_WALK_PF 12                // at most 12 KiB of loads in flight per chunk
+
 
 // 1 KiB of the stream (256 words from word index `base`, a multiple of 256), 16 bytes per lane; words past the end read 0
 __device__ __forceinline__ uint4 knz_walk_load_granule(const uint32_t* words, uint64_t nwords, uint64_t base, int lane) {
@@ -491,14 +491,62 @@ __device__ __forceinline__ uint4 knz_walk_load_granule(const uint32_t* words, ui
     return v;
 }
 
-__global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs a) {
+// Wave 0 walks the block (the chain chunk k -> chunk k+1 is serial by format). Wave 1 is its feeder: it streams the block's
+// compressed bytes into the LDS ring ahead of the walk (up to KNZ_WALK_AHEAD words past the chunk being parsed, never over
+// words the walker may still read), so that ring traffic costs the chain nothing. The two meet through three LDS words:
+// s_sync[0] = stream word index (relative to the ring origin) up to which the ring is filled, [1] = first word the walker
+// still needs, [2] = walker finished.
+__global__ __launch_bounds__(128) void knz_dec_walk_blocks_kernel(WalkBlocksArgs a) {
     __shared__ uint8_t s_lut[1 << KNZ_EXPG_WIN];
     __shared__ __attribute__((aligned(16))) uint32_t s_ring[KNZ_WALK_RING];
     __shared__ uint32_t s_hw[KNZ_HW_WORDS];
-    for (uint32_t i = threadIdx.x; i < (1u << KNZ_EXPG_WIN); i += 64) s_lut[i] = (uint8_t)knz_expg_lut_entry(i);
-    wave_sync_lds();
+    __shared__ uint32_t s_sync[4];
     const uint32_t b = blockIdx.x;
     if (b >= a.nblocks) return;
+    volatile uint32_t* vsync = s_sync;
+    if (threadIdx.x < 4) s_sync[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t ringOrigin = (a.blk_bit[b] >> 5) & ~(uint64_t)255;  // ring word r holds stream word ringOrigin + r (mod ring size)
+    const bool ringOk = (((uintptr_t)a.stream) & 15) == 0;             // 16-byte loads; otherwise the serial parser runs
+    if (threadIdx.x >= 64) {
+        // ---- feeder ---------------------------------------------------------------------------------------------------------
+        const int fl = (int)threadIdx.x - 64;
+        const uint32_t* swords = (const uint32_t*)a.stream;
+        const uint64_t snwords = (a.nbytes + 3) >> 2;
+        uint32_t hi = 0;                                                // relative words filled
+        uint32_t idle = 0;
+        while (vsync[2] == 0) {
+            const uint32_t cons = vsync[1];
+            // next granules: wanted (inside the look-ahead), allowed (not over [cons, ..)), inside the stream. Up to 8 loads are
+            // issued before the first one is stored: one granule per HBM round trip could not keep up with the walker.
+            uint32_t g = 0;
+            if (ringOk && a.entropy == KNZ_E_HUFFMAN && hi < cons + KNZ_WALK_AHEAD && ringOrigin + hi < snwords) {
+                const uint32_t room = ((cons & ~255u) + KNZ_WALK_RING - hi) >> 8;          // granules that fit without touching cons
+                const uint32_t want = (cons + KNZ_WALK_AHEAD - hi + 255) >> 8;
+                const uint32_t left = (uint32_t)min((uint64_t)8, (snwords - ringOrigin - hi + 255) >> 8);
+                g = min(min(room, want), left);
+            }
+            if (g) {
+                uint32_t pf[8][4];
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if ((uint32_t)q < g) { const uint4 v = knz_walk_load_granule(swords, snwords, ringOrigin + hi + 256 * q, fl); pf[q][0] = v.x; pf[q][1] = v.y; pf[q][2] = v.z; pf[q][3] = v.w; }
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if ((uint32_t)q < g) { uint4 v; v.x = pf[q][0]; v.y = pf[q][1]; v.z = pf[q][2]; v.w = pf[q][3]; *(uint4*)&s_ring[(hi + 256 * q + 4 * (uint32_t)fl) & (KNZ_WALK_RING - 1)] = v; }
+                hi += 256 * g;
+                wg_fence_release();
+                if (fl == 0) vsync[0] = hi;
+                idle = 0;
+            } else {
+                wave_spin_pause();
+                if (++idle > (1u << 26)) break;                         // never in practice: the walker sets s_sync[2]
+            }
+        }
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < (1u << KNZ_EXPG_WIN); i += 64) s_lut[i] = (uint8_t)knz_expg_lut_entry(i);
+    wave_sync_lds();
     const bool writer = threadIdx.x == 0;            // every lane runs the (uniform) parse, lane 0 stores the results
     KnzWaveReader r;
     const uint64_t start = a.blk_bit[b];
@@ -542,8 +590,6 @@ __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs 
         const uint32_t* swords = (const uint32_t*)a.stream;
         const uint64_t snwords = (a.nbytes + 3) >> 2;
         uint64_t pos = r.tell();                                           // walk position, authoritative
-        uint64_t ringHi = 0;                                               // stream words [.., ringHi) are in the ring (1 KiB granules)
-        const bool ringOk = (((uintptr_t)a.stream) & 15) == 0;             // 16-byte loads; otherwise the serial parser runs
         bool stale = false;                                                // r is behind pos
         for (uint32_t k = 0; k < nchunks && status == 0; k++) {
             const uint32_t sz = min(chunkSize, preLen - k * chunkSize);
@@ -551,45 +597,20 @@ __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs 
             if (entropy == KNZ_E_HUFFMAN && sz >= 32 && ringOk) {
                 KNZ_PROF_T(w0);
                 const uint64_t w0i = pos >> 5;
-                if (ringHi + KNZ_WALK_RING <= w0i || ringHi == 0) ringHi = w0i & ~(uint64_t)255;   // (re)start the ring here
-                // blocking part: whatever the header window still misses (first chunk, or an unusually large step)
-                while (ringHi < w0i + KNZ_HW_WORDS) {
-                    const uint4 v = knz_walk_load_granule(swords, snwords, ringHi, (int)threadIdx.x);
-                    *(uint4*)&s_ring[(ringHi + 4 * threadIdx.x) & (KNZ_WALK_RING - 1)] = v;
-                    ringHi += 256;
-                }
-                // prefetch: issue now, store behind the parse. Only granules that lie wholly inside the stream (the ragged end
-                // is left to the blocking path above), so the loop is a pointer walk without bounds tests.
-                uint32_t pf[KNZ_WALK_PF][4];                          // (scalar elements: an array of uint4 lands in scratch)
-                const uint64_t pfBase = ringHi;
-                uint32_t groups = 0;
-                if (w0i + KNZ_WALK_AHEAD > ringHi) groups = (uint32_t)min((uint64_t)KNZ_WALK_PF, (w0i + KNZ_WALK_AHEAD - ringHi + 255) >> 8);
-                const uint64_t wholeGranules = snwords >> 8;
-                groups = (pfBase >> 8) >= wholeGranules ? 0u : (uint32_t)min((uint64_t)groups, wholeGranules - (pfBase >> 8));
-                {
-                    const uint4* gp = (const uint4*)swords + (pfBase >> 2) + threadIdx.x;
-#pragma unroll
-                    for (int g = 0; g < KNZ_WALK_PF; g++)
-                        if ((uint32_t)g < groups) { const uint4 v = gp[64 * g]; pf[g][0] = v.x; pf[g][1] = v.y; pf[g][2] = v.z; pf[g][3] = v.w; }
-                }
+                const uint32_t rel = (uint32_t)(w0i - ringOrigin);
+                if (writer) vsync[1] = rel;                             // everything before this word may be overwritten
+                // the feeder is normally far ahead; wait for the header window otherwise (bounded: a stuck feeder = error)
+                const uint32_t need = (uint32_t)min((uint64_t)rel + KNZ_HW_WORDS, ((snwords - ringOrigin + 255) & ~(uint64_t)255));
+                uint32_t spins = 0;
+                while (vsync[0] < need) { wave_spin_pause(); if (++spins > (1u << 24)) break; }
+                if (spins > (1u << 24)) { status = KNZ_ERR_PROCESS_BLOCK; break; }
+                wg_fence_acquire();
                 KNZ_PROF_T(w1);
-                wave_sync_lds();
-                for (uint32_t i = threadIdx.x; i < KNZ_HW_WORDS; i += 64) s_hw[i] = knz_bswap32(s_ring[(w0i + i) & (KNZ_WALK_RING - 1)]);
+                for (uint32_t i = threadIdx.x; i < KNZ_HW_WORDS; i += 64) s_hw[i] = knz_bswap32(s_ring[(rel + i) & (KNZ_WALK_RING - 1)]);
                 wave_sync_lds();
                 KNZ_PROF_T(w2);
                 const KnzHufHdr hdr = knz_huf_parse_header_wave<false>(s_hw, (uint32_t)(pos & 31), nullptr, nullptr, (int)threadIdx.x);
-                wave_sync_lds();
                 KNZ_PROF_T(w3);
-                {
-                    const uint32_t r0 = (uint32_t)(pfBase & (KNZ_WALK_RING - 1)) + 4 * threadIdx.x;   // granules never straddle the ring end
-#pragma unroll
-                    for (int g = 0; g < KNZ_WALK_PF; g++)
-                        if ((uint32_t)g < groups) {
-                            uint4 v; v.x = pf[g][0]; v.y = pf[g][1]; v.z = pf[g][2]; v.w = pf[g][3];
-                            *(uint4*)&s_ring[(r0 + 256 * g) & (KNZ_WALK_RING - 1)] = v;
-                        }
-                }
-                ringHi = pfBase + 256ull * groups;
                 KNZ_PROF_T(w4);
                 KNZ_PROF_ADD(8, w0, w1); KNZ_PROF_ADD(9, w1, w2); KNZ_PROF_ADD(10, w2, w3); KNZ_PROF_ADD(11, w3, w4);
                 if (hdr.status == 2) { status = KNZ_ERR_PROCESS_BLOCK; break; }
@@ -681,6 +702,6 @@ __global__ __launch_bounds__(64) void knz_dec_walk_blocks_kernel(WalkBlocksArgs 
         }
         if (writer) a.blk_end_bit[b] = pos;
     } else if (writer) a.blk_end_bit[b] = r.tell();
-    if (writer) a.blk_status[b] = status;
+    if (writer) { a.blk_status[b] = status; vsync[2] = 1; }
 }
 

@@ -47,8 +47,15 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// polling loops between waves of one workgroup (LDS flags): give the issue slot away for a few cycles
+__device__ __forceinline__ void wave_spin_pause() { __builtin_amdgcn_s_sleep(1); }
+__device__ __forceinline__ void wg_fence_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void wg_fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 #else
 // ------------------------------------------------------------------ emulator (tests only)
+inline void wave_spin_pause() { hipemu::spin_pause(); }
+inline void wg_fence_release() {}
+inline void wg_fence_acquire() {}
 inline uint32_t knz_mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 inline uint32_t wave_uniform(uint32_t v) { return v; }
 inline int lane_id() { return hipemu::lane(); }

@@ -58,6 +58,7 @@ static void trampoline() {
     abort();   // a finished fiber is never resumed
 }
 static inline void yield() { knz_emu_switch(&fibers[cur].sp, schedSp); }
+void spin_pause() { progress++; yield(); }       // a polling loop lets the other fibers run (kernels bound their own spins)
 
 void block_barrier() {
     unsigned g = blkGen;

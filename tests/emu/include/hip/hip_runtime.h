@@ -39,6 +39,7 @@ namespace hipemu {
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void block_barrier();
 void wave_barrier();
+void spin_pause();
 uint64_t* wave_slots();     // 64 exchange slots of the calling fiber's wave
 int lane();
 }
