@@ -26,8 +26,8 @@ __device__ unsigned long long g_knz_prof[32];
 #endif
 
 #define KNZ_HUF_SYNC_BITS 192        // look-back of the boundary search: ~20 codes, Huffman codes re-synchronise well within
-#define KNZ_HUF_LANE_CAP 100          // symbols a lane keeps from its decode pass (sub-ranges hold ~64); more -> a write pass.
-                                      // 25 dwords: an odd row stride spreads the 64 rows of a wave over all 32 LDS banks
+#define KNZ_HUF_LANE_CAP 84           // symbols a lane keeps from its decode pass (sub-ranges hold ~64); more -> a write pass.
+                                      // 21 dwords: an odd row stride spreads the 64 rows of a wave over all 32 LDS banks
 #define KNZ_HW_WORDS 136              // header window: 128 words + padding for the 64-bit look-ahead
 
 struct KnzHufHdr {

@@ -136,28 +136,42 @@ __device__ __forceinline__ void knz_or_bits(uint32_t* words, uint64_t bit, uint3
 // framing fields), then OR the stream header, the per-block length fields and the block headers.
 __global__ __launch_bounds__(256) void knz_layout_stream_kernel(StreamArgs a) {
     __shared__ uint64_t s_total;
-    const int tid = threadIdx.x;
-    // serial scan over blocks (a few hundred at most per batch)
-    if (tid == 0) {
-        uint64_t pos = a.first_bit + (a.framed ? a.header_bits : 0);
-        for (uint32_t b = 0; b < a.nblocks; b++) {
-            uint64_t written = a.blk_written[b];
-            if (a.framed) {
-                uint32_t lw = 3;
-                if (written >= 8) lw = (31u - (uint32_t)__builtin_clz((uint32_t)(written >> 3))) + 4;
-                pos += 5 + lw;
-                a.blk_dst_bit[b] = pos;
-                pos += written;
-            } else {
-                a.blk_dst_bit[b] = (uint64_t)b * a.block_stride_bits;
-                pos = (uint64_t)b * a.block_stride_bits + written;
-            }
+    __shared__ uint64_t s_wsum[4];
+    __shared__ uint64_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // scan over blocks: bit position of every block-local stream behind its (lw-3):5, written:lw framing (:951-959)
+    if (tid == 0) s_carry = a.first_bit + (a.framed ? a.header_bits : 0);
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < a.nblocks; b0 += 256) {
+        const uint32_t b = b0 + tid;
+        uint64_t written = 0, sz = 0;
+        uint32_t lw = 3;
+        if (b < a.nblocks) {
+            written = a.blk_written[b];
+            if (written >= 8) lw = (31u - (uint32_t)__builtin_clz((uint32_t)(written >> 3))) + 4;
+            sz = a.framed ? 5 + lw + written : 0;
         }
+        // 64-bit inclusive scan across the workgroup (block-local streams are < 2^34 bits)
+        uint64_t incl = sz;
+        for (int d = 1; d < 64; d <<= 1) { const uint64_t t = wave_shfl64(incl, lane - d); if (lane >= d) incl += t; }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint64_t before = s_carry;
+        for (int w = 0; w < wave; w++) before += s_wsum[w];
+        if (b < a.nblocks) a.blk_dst_bit[b] = a.framed ? before + incl - written : (uint64_t)b * a.block_stride_bits;
+        __syncthreads();
+        if (tid == 255) s_carry = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        uint64_t pos = s_carry;
+        if (!a.framed) pos = a.nblocks ? (uint64_t)(a.nblocks - 1) * a.block_stride_bits + a.blk_written[a.nblocks - 1] : 0;
         if (a.framed && a.end_marker) pos += 8;
         s_total = pos;
         a.total_bits[0] = pos;
         a.total_bits[1] = (pos > a.dst_cap_bits) ? 1 : 0;
     }
+    __threadfence();
     __syncthreads();
     if (s_total > a.dst_cap_bits) return;     // caller reports ERR_WRITE_FILE; nothing is written
     const uint32_t cpb = a.chunks_per_block;
@@ -167,20 +181,23 @@ __global__ __launch_bounds__(256) void knz_layout_stream_kernel(StreamArgs a) {
         for (uint64_t w = hw0 + tid; w <= hw1; w += 256) a.dst_words[w] = 0;
         if (tid == 0) { uint64_t e = (s_total - 1) >> 5; a.dst_words[e] = 0; if (e) a.dst_words[e - 1] = 0; }
     }
-    for (uint32_t b = 0; b < a.nblocks; b++) {
+    for (uint32_t b = tid; b < a.nblocks; b += 256) {
         const uint64_t base = a.blk_dst_bit[b];
         const uint32_t hdrBits = a.blk_hdr[(size_t)b * 6];
-        if (tid < 8) { // framing field (<= 39 bits before base) and block header (<= 112 bits after base)
-            uint64_t lo = (base >= 64 ? base - 64 : 0) >> 5, hi = (base + hdrBits + 31) >> 5;
-            for (uint64_t w = lo + tid; w <= hi; w += 8) a.dst_words[w] = 0;
-        }
+        // framing field (<= 39 bits before base) and block header (<= 112 bits after base)
+        const uint64_t lo = (base >= 64 ? base - 64 : 0) >> 5, hi = (base + hdrBits + 31) >> 5;
+        for (uint64_t w = lo; w <= hi; w++) a.dst_words[w] = 0;
+        const uint64_t e = base + a.blk_written[b];
+        a.dst_words[e >> 5] = 0;
+        if (e >= 32) a.dst_words[(e >> 5) - 1] = 0;
+    }
+    for (uint32_t idx = tid; idx < a.nblocks * cpb; idx += 256) {
+        const uint32_t b = idx / cpb, k = idx % cpb;
         const uint32_t nchunks = (a.blk_len[b] + a.chunk_size - 1) / a.chunk_size;
-        for (uint32_t k = tid; k < nchunks; k += 256) {
-            uint64_t p0 = base + a.chunk_rel[(size_t)b * cpb + k];
-            a.dst_words[p0 >> 5] = 0;                     // first word of this chunk (shared with its predecessor)
-            if (p0) a.dst_words[(p0 - 1) >> 5] = 0;       // last word of the predecessor when p0 is word aligned
-        }
-        if (tid == 0) { uint64_t e = base + a.blk_written[b]; a.dst_words[e >> 5] = 0; if (e >= 32) a.dst_words[(e >> 5) - 1] = 0; }
+        if (k >= nchunks) continue;
+        const uint64_t p0 = a.blk_dst_bit[b] + a.chunk_rel[idx];
+        a.dst_words[p0 >> 5] = 0;                         // first word of this chunk (shared with its predecessor)
+        if (p0) a.dst_words[(p0 - 1) >> 5] = 0;           // last word of the predecessor when p0 is word aligned
     }
     __threadfence();
     __syncthreads();

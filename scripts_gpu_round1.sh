@@ -3,7 +3,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout 600 python -m pytest tests/test_parity_gpu.py -x -q -k "HUFFMAN or stream or config2 or stress or entropy or decoder_paths or checksums" > gpurun_out/pytest_gpu.log 2>&1
+timeout 900 python -m pytest tests/test_parity_gpu.py -x -q > gpurun_out/pytest_gpu.log 2>&1
 tail -2 gpurun_out/pytest_gpu.log
 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_q.json 2> gpurun_out/bench_q.err
 python - <<'PY'
