@@ -229,8 +229,30 @@ __global__ __launch_bounds__(256) void knz_bwt_inv_links_kernel(BwtInvArgs a, ui
     links[p] = e;
 }
 
-// one wave per block, lanes 0..7 follow the 8 chunk chains (one lane when n < 256)
-__global__ __launch_bounds__(64) void knz_bwt_inv_chains_kernel(BwtInvArgs a, const uint2* links) {
+// Pointer doubling of the LF links: out[p] = two hops of in[p] with the symbols of both packed little-endian. Applied twice
+// (1 -> 2 -> 4 symbols per hop, an entry stays 8 bytes) it cuts the dependent pointer chase of every chain by 4 for two fully
+// parallel gather passes. A hop that leaves the block (corrupt stream, or the end of the permutation cycle) makes the composite
+// link invalid (0xFFFFFFFF); the chains only follow composites while at least that many symbols are still due.
+__global__ __launch_bounds__(256) void knz_bwt_inv_double_kernel(BwtInvArgs a, uint32_t total, const uint32_t* skeys, const uint2* in, uint2* out, uint32_t symBits) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const uint32_t b = skeys[p] >> 8;
+    const uint32_t gs0 = a.gstart[b];
+    const uint32_t cnt = a.in_len[b] - a.hdr[(size_t)b * 12];
+    const uint2 e0 = in[p];
+    uint2 o;
+    o.x = 0xFFFFFFFFu; o.y = e0.y;
+    if (e0.x < cnt) {
+        const uint2 e1 = in[gs0 + e0.x];
+        o.x = e1.x < cnt ? e1.x : 0xFFFFFFFFu;
+        o.y = e0.y | (e1.y << symBits);
+    }
+    out[p] = o;
+}
+
+// one wave per block, lanes 0..7 follow the 8 chunk chains (one lane when n < 256): 4 symbols per hop through links4,
+// the last < 4 symbols of a chain through the single links
+__global__ __launch_bounds__(64) void knz_bwt_inv_chains_kernel(BwtInvArgs a, const uint2* links, const uint2* links4) {
     const uint32_t b = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t* h = a.hdr + (size_t)b * 12;
@@ -240,6 +262,7 @@ __global__ __launch_bounds__(64) void knz_bwt_inv_chains_kernel(BwtInvArgs a, co
     const uint8_t* src = (const uint8_t*)a.in_ptr[b] + h[0];
     if (cnt == 1) { if (lane == 0) dst[0] = src[0]; return; }
     const uint2* L = links + a.gstart[b];
+    const uint2* L4 = links4 + a.gstart[b];
     const uint32_t chunks = h[1];
     if ((uint32_t)lane >= chunks) return;
     uint32_t ck = chunks == 8 ? (cnt >> 3) : cnt;
@@ -247,7 +270,20 @@ __global__ __launch_bounds__(64) void knz_bwt_inv_chains_kernel(BwtInvArgs a, co
     const uint32_t start = (uint32_t)lane * ck;
     const uint32_t end = min(cnt, start + ck);
     uint32_t t = h[2 + lane] - 1;
-    for (uint32_t i = start; i < end; i++) {
+    uint32_t i = start;
+    for (; i + 4 <= end; i += 4) {
+        if (t >= cnt) { a.ok[b] = -KNZ_ERR_PROCESS_BLOCK; return; }
+        const uint2 e = L4[t];
+        dst[i] = (uint8_t)e.y; dst[i + 1] = (uint8_t)(e.y >> 8); dst[i + 2] = (uint8_t)(e.y >> 16); dst[i + 3] = (uint8_t)(e.y >> 24);
+        if (e.x == 0xFFFFFFFFu) {
+            // the composite left the block. Legitimate only as the link behind the chain's very last symbol (the last chain
+            // ends on the terminator): the 3 hops inside must still be good.
+            uint32_t q = t;
+            for (int hop = 0; hop < 3; hop++) { q = L[q].x; if (q >= cnt) { a.ok[b] = -KNZ_ERR_PROCESS_BLOCK; return; } }
+        }
+        t = e.x;
+    }
+    for (; i < end; i++) {                                           // < 4 symbols left: single links
         if (t >= cnt) { a.ok[b] = -KNZ_ERR_PROCESS_BLOCK; return; }
         const uint2 e = L[t];
         dst[i] = (uint8_t)e.y;

@@ -510,6 +510,7 @@ __global__ __launch_bounds__(128) void knz_dec_walk_blocks_kernel(WalkBlocksArgs
     const bool ringOk = (((uintptr_t)a.stream) & 15) == 0;             // 16-byte loads; otherwise the serial parser runs
     if (threadIdx.x >= 64) {
         // ---- feeder ---------------------------------------------------------------------------------------------------------
+        if (!ringOk || a.entropy != KNZ_E_HUFFMAN) return;             // nothing to feed: the other walks read the stream directly
         const int fl = (int)threadIdx.x - 64;
         const uint32_t* swords = (const uint32_t*)a.stream;
         const uint64_t snwords = (a.nbytes + 3) >> 2;
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(128) void knz_dec_walk_blocks_kernel(WalkBlocksArgs
             // next granules: wanted (inside the look-ahead), allowed (not over [cons, ..)), inside the stream. Up to 8 loads are
             // issued before the first one is stored: one granule per HBM round trip could not keep up with the walker.
             uint32_t g = 0;
-            if (ringOk && a.entropy == KNZ_E_HUFFMAN && hi < cons + KNZ_WALK_AHEAD && ringOrigin + hi < snwords) {
+            if (hi < cons + KNZ_WALK_AHEAD && ringOrigin + hi < snwords) {
                 const uint32_t room = ((cons & ~255u) + KNZ_WALK_RING - hi) >> 8;          // granules that fit without touching cons
                 const uint32_t want = (cons + KNZ_WALK_AHEAD - hi + 255) >> 8;
                 const uint32_t left = (uint32_t)min((uint64_t)8, (snwords - ringOrigin - hi + 255) >> 8);
