@@ -21,6 +21,8 @@
 #define KNZ_ANS1_PAY_OFF (KNZ_ANS1_U0_CAP + 64)
 #define KNZ_ANS1_PAY_CAP (((KNZ_ANS1_CHUNK / 8) * 11) + 64)   // a symbol costs at most log2(2048) = 11 bits
 #define KNZ_ANS1_SLOT (KNZ_ANS1_PAY_OFF + KNZ_ANS1_PAY_CAP + 64)
+#define KNZ_ANS1_CUM_STRIDE 257                       // cum[ctx][0..256]
+#define KNZ_ANS1_PAYRING 8192                         // 16-bit payload words staged in LDS by the LDS decoder
 #define KNZ_ANS1_RING 2048                            // 16-bit words per chunk ring (power of two)
 
 struct Ans1Args {
@@ -409,7 +411,7 @@ __device__ static bool knz_ans1_parse_header(R& r, uint16_t* freq16, uint32_t& l
 }
 
 // one workgroup per chunk: lane 0 parses the 256 context headers, then all threads fill the slot table
-__global__ __launch_bounds__(256) void knz_ans1_dec_tables_kernel(Ans1DecArgs a, uint16_t* freq16) {
+__global__ __launch_bounds__(256) void knz_ans1_dec_tables_kernel(Ans1DecArgs a, uint16_t* freq16, uint16_t* cum16) {
     __shared__ int s_mode;
     __shared__ uint32_t s_lr;
     const int tid = threadIdx.x;
@@ -442,9 +444,17 @@ __global__ __launch_bounds__(256) void knz_ans1_dec_tables_kernel(Ans1DecArgs a,
     }
     __syncthreads();
     if (s_mode != 3) return;
-    // thread = context: cumulated frequencies and the slot table of that context
+    // thread = context: cumulated frequencies (for the LDS decoder: cum[ctx][0..256], 2048 behind the last symbol)
+    // and the slot table of that context (for the table decoder)
     uint32_t* dt = a.dtab + ((size_t)slotId * 256 + tid) * KNZ_ANS1_SCALE;
     const uint16_t* f = f16 + (size_t)tid * 256;
+    if (cum16) {
+        uint16_t* cq = cum16 + ((size_t)slotId * 256 + tid) * KNZ_ANS1_CUM_STRIDE;
+        uint32_t cc = 0;
+        for (uint32_t s = 0; s < 256; s++) { cq[s] = (uint16_t)cc; cc += f[s]; }
+        cq[256] = (uint16_t)cc;
+        return;
+    }
     uint32_t cum = 0;
     for (uint32_t s = 0; s < 256; s++) {
         const uint32_t fr = f[s];
@@ -513,6 +523,80 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_kernel(Ans1DecArgs a) {
         }
     }
     if (live && c == 0) {
+        for (uint32_t i = end4; i < n; i++)
+            dst[i] = (uint8_t)(knz_fetch32(a.stream, (int64_t)(paybit + 16ull * cnt + 8ull * (i - end4)), (int64_t)limit) >> 24);
+    }
+}
+
+// LDS-resident decoder: one wave per chunk. The 2 MiB slot table of the decoder above costs one trip to the MALL per step
+// (~0.85 us: 64 K of them do not fit any cache level that is close); here the chunk keeps only the cumulated frequencies of its
+// 256 contexts in LDS (257 x u16 each, 129 KiB of the CU's 160 KiB) and finds the symbol of a slot with two 16-way searches:
+// lanes 16g..16g+15 serve state g; lane l reads cum[ctx][16 l], a ballot + popcount picks the group of 16 symbols, a second
+// read + ballot the symbol; freq = cum[s + 1] - cum[s]. Renormalisation words are staged from the stream into an LDS ring.
+__global__ __launch_bounds__(64) void knz_ans1_decode_lds_kernel(Ans1DecArgs a, const uint16_t* cum16) {
+    __shared__ uint16_t s_cum[256 * KNZ_ANS1_CUM_STRIDE];
+    __shared__ uint16_t s_pay[KNZ_ANS1_PAYRING];
+    __shared__ uint8_t s_ob[4][256];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    const uint32_t slotId = blockIdx.x;
+    const uint64_t limit = a.nbytes << 3;
+    const uint32_t b = slotId / a.chunks_per_block, k = slotId % a.chunks_per_block;
+    if (a.info[(size_t)slotId * 8] != 3 || a.blk_status[b] != 0) return;
+    const uint32_t preLen = a.blk_pre_len[b];
+    const uint32_t n = min(KNZ_ANS1_CHUNK, preLen - k * KNZ_ANS1_CHUNK);
+    uint8_t* dst = (uint8_t*)a.blk_out_off[b] + (size_t)k * KNZ_ANS1_CHUNK;
+    const uint64_t paybit = a.paybit[slotId];
+    {
+        const uint32_t* src = (const uint32_t*)(cum16 + (size_t)slotId * 256 * KNZ_ANS1_CUM_STRIDE);   // 131,584 B, 4-byte aligned
+        for (uint32_t i = lane; i < 256 * KNZ_ANS1_CUM_STRIDE / 2; i += 64) ((uint32_t*)s_cum)[i] = src[i];
+    }
+    uint32_t st = a.info[(size_t)slotId * 8 + 1 + g];
+    const uint32_t end4 = n & ~3u;
+    const uint32_t q = end4 >> 2;
+    uint8_t* qdst = dst + (size_t)g * q;
+    uint32_t ctx = 0, cnt = 0;
+    uint32_t payHi = 0;                                                  // words [payHi - ring, payHi) are staged
+    const uint64_t below = ((uint64_t)1 << lane) - 1;
+    wave_sync();
+    for (uint32_t t = 0; t < q; t++) {
+        if (cnt + 4 > payHi) {                                           // stage the next half ring of renormalisation words
+            wave_sync();
+            for (uint32_t j = lane; j < KNZ_ANS1_PAYRING / 2; j += 64) {
+                const uint32_t wi = payHi + j;
+                s_pay[wi & (KNZ_ANS1_PAYRING - 1)] = (uint16_t)(knz_fetch32(a.stream, (int64_t)(paybit + 16ull * wi), (int64_t)limit) >> 16);
+            }
+            payHi += KNZ_ANS1_PAYRING / 2;
+            wave_sync();
+        }
+        const uint32_t slot = st & (KNZ_ANS1_SCALE - 1);
+        const uint16_t* cq = s_cum + ctx * KNZ_ANS1_CUM_STRIDE;
+        // 16 x 16 search: largest s with cum[s] <= slot (an absent symbol shares its cum with the next present one)
+        const uint32_t mA = (uint32_t)(wave_ballot(cq[16 * l] <= slot) >> (16 * g)) & 0xFFFFu;
+        const uint32_t gi = (uint32_t)__popc(mA) - 1;
+        const uint32_t mB = (uint32_t)(wave_ballot(cq[16 * gi + l] <= slot) >> (16 * g)) & 0xFFFFu;
+        const uint32_t sym = 16 * gi + (uint32_t)__popc(mB) - 1;
+        const uint32_t lo = cq[sym], hi = cq[sym + 1];
+        const uint32_t fr = min(hi - lo, (uint32_t)KNZ_ANS1_SCALE - 1);     // decSymbol.reset :972-977
+        if (l == 0) s_ob[g][t & 255] = (uint8_t)sym;
+        st = fr * (st >> KNZ_ANS1_LR) + slot - lo;                          // (:846-858)
+        ctx = sym;
+        const bool need = st < (1u << 15);
+        const uint64_t nb = wave_ballot(need);
+        const uint32_t gb = (uint32_t)((nb & 1) | ((nb >> 15) & 2) | ((nb >> 30) & 4) | ((nb >> 45) & 8));
+        if (need) {
+            const uint32_t r = cnt + (uint32_t)__popc(gb >> (g + 1));          // refill order st3, st2, st1, st0 (:918-949)
+            st = (st << 16) | s_pay[r & (KNZ_ANS1_PAYRING - 1)];
+        }
+        cnt += (uint32_t)__popc(gb);
+        if ((t & 255) == 255 || t + 1 == q) {
+            wave_sync();
+            const uint32_t base = t & ~255u, m = t + 1 - base;
+            for (uint32_t i = l; i < m; i += 16) qdst[base + i] = s_ob[g][i];
+            wave_sync();
+        }
+    }
+    if (lane == 0) {
         for (uint32_t i = end4; i < n; i++)
             dst[i] = (uint8_t)(knz_fetch32(a.stream, (int64_t)(paybit + 16ull * cnt + 8ull * (i - end4)), (int64_t)limit) >> 24);
     }

@@ -375,3 +375,15 @@ def check_checksums(be):
             assert r[0] == o["bits"] and r[1] == o["written"]
         assert bb.decode([r[0] for r in res]) == blocks
     c.close()
+
+
+def check_ans1_table_decoder(be):
+    """The order-1 rANS decoder has two forms (LDS-resident cumulated frequencies for small batches, slot tables in HBM for
+    large ones); KNZ_ANS1_TABLE_DECODER forces the second."""
+    import os
+    os.environ["KNZ_ANS1_TABLE_DECODER"] = "1"
+    try:
+        check_stream(be, "NONE", "ANS1", 1 << 16, 3 * 65536 + 777)
+        check_entropy_encode(be, "ANS1")
+    finally:
+        del os.environ["KNZ_ANS1_TABLE_DECODER"]

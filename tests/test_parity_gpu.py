@@ -134,3 +134,7 @@ def test_huffman_decoder_paths(be):
 
 def test_block_checksums(be):
     P.check_checksums(be)
+
+
+def test_ans1_table_decoder(be):
+    P.check_ans1_table_decoder(be)
