@@ -230,8 +230,42 @@ __device__ __forceinline__ int knz_lz_read_length(const uint8_t* block, int& adv
     res += (int)block[1] << 16; res += (int)block[2] << 8; res += block[3]; adv = 4; return res;
 }
 
+// A wave-uniform sequential reader: the next bytes of one of the block's streams staged in an LDS ring by the whole wave
+// (coalesced loads, half a ring at a time), read back as LDS broadcasts. inverseV6 walks four such streams (literals with
+// their inline length extensions, tokens, distances, match length extensions); reading them byte by byte from global memory
+// put an L2 round trip on every step of the token chain.
+template <int SIZE>
+struct KnzLzRing {
+    const uint8_t* src; uint8_t* ring; long long hi, limit;            // bytes [hi - SIZE, hi) are staged; reads past limit give 0
+    __device__ __forceinline__ void init(const uint8_t* s, uint8_t* r, long long start, long long lim) {
+        src = s; ring = r; limit = lim; hi = start & ~(long long)(SIZE / 2 - 1);
+    }
+    // makes bytes [idx, idx + need) available, need <= SIZE / 2
+    __device__ __forceinline__ void ensure(long long idx, int need, int lane) {
+        if (idx + need <= hi && idx >= hi - SIZE) return;
+        if (idx >= hi + SIZE / 2 || idx < hi - SIZE) hi = idx & ~(long long)(SIZE / 2 - 1);   // far jump: restart the ring there
+        while (idx + need > hi) {
+            wave_sync_lds();
+            for (int i = lane; i < SIZE / 2; i += 64) ring[(hi + i) & (SIZE - 1)] = (hi + i < limit) ? src[hi + i] : (uint8_t)0;
+            hi += SIZE / 2;
+            wave_sync_lds();
+        }
+    }
+    __device__ __forceinline__ uint32_t at(long long idx) const { return ring[idx & (SIZE - 1)]; }
+};
+
+template <int SIZE>
+__device__ __forceinline__ int knz_lz_read_length_ring(KnzLzRing<SIZE>& r, long long idx, int& adv, int lane) {   // :216-232
+    r.ensure(idx, 4, lane);
+    int res = (int)wave_uniform(r.at(idx));
+    if (res < 254) { adv = 1; return res; }
+    if (res == 254) { res += (int)wave_uniform(r.at(idx + 1)) << 8; res += (int)wave_uniform(r.at(idx + 2)); adv = 3; return res; }
+    res += (int)wave_uniform(r.at(idx + 1)) << 16; res += (int)wave_uniform(r.at(idx + 2)) << 8; res += (int)wave_uniform(r.at(idx + 3)); adv = 4; return res;
+}
+
 // inverseV6 (:621-778): token driven; every copy is done by the whole wave
 __global__ __launch_bounds__(64) void knz_lz_inverse_kernel(LzArgs a) {
+    __shared__ uint8_t s_lit[4096], s_tk[1024], s_md[1024], s_ml[512];
     const int lane = threadIdx.x;
     const bool writer = lane == 0;
     const uint32_t b = blockIdx.x;
@@ -255,19 +289,31 @@ __global__ __launch_bounds__(64) void knz_lz_inverse_kernel(LzArgs a) {
             const int minMatch = ((src[12] >> 1) & 7) + 2;
             long long srcIdx = 13;
             long long repd0 = count, repd1 = count;
-            const long long tkEnd = mIdx;                                  // tokens live in [tkIdx0, mIdx)
+            KnzLzRing<4096> lit; lit.init(src, s_lit, srcIdx, count);
+            KnzLzRing<1024> tk; tk.init(src, s_tk, tkIdx, count);
+            KnzLzRing<1024> md; md.init(src, s_md, mIdx, count);
+            KnzLzRing<512> ml; ml.init(src, s_ml, mLenIdx, count);
+            // output bytes below `visible` are known to be readable by every lane (a fence has passed since they were stored)
+            long long visible = 0;
             for (;;) {
                 if (tkIdx >= count) { status = -KNZ_ERR_PROCESS_BLOCK; break; }
-                const int token = src[tkIdx++];
+                tk.ensure(tkIdx, 1, lane);
+                const int token = (int)wave_uniform(tk.at(tkIdx));
+                tkIdx++;
                 if (token >= 32) {
                     long long litLen;
                     if (token >= 0xE0) {
                         if (srcIdx + 4 > count) { status = -KNZ_ERR_PROCESS_BLOCK; break; }
-                        int adv; const int ll = knz_lz_read_length(src + srcIdx, adv);
+                        int adv; const int ll = knz_lz_read_length_ring(lit, srcIdx, adv, lane);
                         litLen = 7 + ll; srcIdx += adv;
                     } else litLen = token >> 5;
                     if (srcIdx + litLen > count || dstIdx + litLen > (long long)a.out_cap) { status = -KNZ_ERR_PROCESS_BLOCK; break; }
-                    for (long long i = lane; i < litLen; i += 64) dst[dstIdx + i] = src[srcIdx + i];
+                    if (litLen <= 2048) {
+                        lit.ensure(srcIdx, (int)litLen, lane);
+                        for (long long i = lane; i < litLen; i += 64) dst[dstIdx + i] = (uint8_t)lit.at(srcIdx + i);
+                    } else {
+                        for (long long i = lane; i < litLen; i += 64) dst[dstIdx + i] = src[srcIdx + i];   // long run: straight copy
+                    }
                     srcIdx += litLen;
                     dstIdx += litLen;
                     if (srcIdx >= srcEnd) break;
@@ -276,32 +322,37 @@ __global__ __launch_bounds__(64) void knz_lz_inverse_kernel(LzArgs a) {
                 const int f = token & 0x18;
                 if (f == 0) {
                     mLen = token & 0x03;
-                    if (mLen == 3) { if (mLenIdx + 4 > count + 3) { status = -KNZ_ERR_PROCESS_BLOCK; break; } int adv; const int ml = knz_lz_read_length(src + mLenIdx, adv); mLen += minMatch + ml; mLenIdx += adv; }
+                    if (mLen == 3) { if (mLenIdx + 4 > count + 3) { status = -KNZ_ERR_PROCESS_BLOCK; break; } int adv; const int mx = knz_lz_read_length_ring(ml, mLenIdx, adv, lane); mLen += minMatch + mx; mLenIdx += adv; }
                     else mLen += minMatch;
                     dist = (token & 0x04) == 0 ? repd0 : repd1;
                 } else {
                     mLen = token & 0x07;
-                    if (mLen == 7) { if (mLenIdx + 4 > count + 3) { status = -KNZ_ERR_PROCESS_BLOCK; break; } int adv; const int ml = knz_lz_read_length(src + mLenIdx, adv); mLen += minMatch + ml; mLenIdx += adv; }
+                    if (mLen == 7) { if (mLenIdx + 4 > count + 3) { status = -KNZ_ERR_PROCESS_BLOCK; break; } int adv; const int mx = knz_lz_read_length_ring(ml, mLenIdx, adv, lane); mLen += minMatch + mx; mLenIdx += adv; }
                     else mLen += minMatch;
                     if (mIdx + 3 > count + 2) { status = -KNZ_ERR_PROCESS_BLOCK; break; }
-                    dist = src[mIdx++];
-                    if (f >= 0x10) { dist = (dist << 8) | src[mIdx++]; if (f == 0x18) dist = (dist << 8) | src[mIdx++]; }
+                    md.ensure(mIdx, 3, lane);
+                    dist = (long long)wave_uniform(md.at(mIdx)); mIdx++;
+                    if (f >= 0x10) {
+                        dist = (dist << 8) | (long long)wave_uniform(md.at(mIdx)); mIdx++;
+                        if (f == 0x18) { dist = (dist << 8) | (long long)wave_uniform(md.at(mIdx)); mIdx++; }
+                    }
                 }
                 repd1 = repd0;
                 repd0 = dist;
                 const long long mEnd = dstIdx + mLen;
                 const long long ref = dstIdx - dist;
                 if (ref < 0 || dist > maxDist || mEnd > dstEnd || dist <= 0) { status = -KNZ_ERR_PROCESS_BLOCK; break; }
-                // the literals just written by other lanes must be visible before they are read as match source
-                wave_sync();
-                __threadfence();
+                // bytes stored since the last fence (by any lane) must be visible before they are read as match source; most
+                // matches reach further back than that
+                if (ref + (dist >= mLen ? mLen : dist) > visible) {
+                    wave_sync();
+                    __threadfence();
+                    visible = dstIdx;
+                }
                 // overlapping match = periodic pattern of period dist: byte i comes from ref + i % dist (all already written)
                 for (long long i = lane; i < mLen; i += 64) dst[dstIdx + i] = dst[ref + (dist >= mLen ? i : i % dist)];
-                wave_sync();
-                __threadfence();
                 dstIdx = mEnd;
             }
-            (void)tkEnd;
             if (status == 1 && srcIdx != srcEnd + 13) status = -KNZ_ERR_PROCESS_BLOCK;
         }
     }
