@@ -148,10 +148,6 @@ extern "C" int knz_open(const knz_cfg* cfg, void** handle) {
 extern "C" int knz_close(void* handle) {
     Handle* h = (Handle*)handle;
     if (!h) return KNZ_OK;
-    DevBuf* bufs[] = {&h->blk_off, &h->blk_len, &h->blk_src_len, &h->blk_skip, &h->blk_cksum, &h->blk_status, &h->unit_bits, &h->unit_src, &h->ans_tab,
-                      &h->scratch, &h->chunk_rel, &h->blk_written, &h->blk_hdr, &h->blk_dst_bit, &h->total_bits,
-                      &h->stage_in, &h->stage_out, &h->dec_tables};
-    for (DevBuf* b : bufs) b->release();
     if (h->pinned) hipHostFree(h->pinned);
     for (int i = 0; i <= KNZ_STAGE_COUNT; i++) hipEventDestroy(h->ev[i]);
     delete h;

@@ -9,6 +9,10 @@
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }          // every workspace buffer of a Handle goes with it (knz_close)
     int reserve(size_t n);            // grows (never shrinks); contents are not preserved
     void release();
     template <typename T> T* as() const { return (T*)p; }
