@@ -250,6 +250,8 @@ struct Ans0DecArgs {
 __global__ __launch_bounds__(64) void knz_ans0_decode_kernel(Ans0DecArgs a) {
     __shared__ uint8_t s_f2s[KNZ_ANS0_DEC_CHUNKS][4096];
     __shared__ uint32_t s_sym[KNZ_ANS0_DEC_CHUNKS][256];      // freq | cumFreq << 16
+    __shared__ uint16_t s_pay[KNZ_ANS0_DEC_CHUNKS][256];       // renormalisation words of each chunk, ring
+    __shared__ uint8_t s_ob[KNZ_ANS0_DEC_CHUNKS][256];         // decoded bytes of each chunk, 64 steps at a time
     __shared__ uint16_t s_freq[256];
     __shared__ uint8_t s_alpha[256];
     __shared__ uint32_t s_state[KNZ_ANS0_DEC_CHUNKS][4];
@@ -391,13 +393,31 @@ __global__ __launch_bounds__(64) void knz_ans0_decode_kernel(Ans0DecArgs a) {
     for (int d = 32; d >= 1; d >>= 1) { uint32_t o = wave_shfl(maxT, lane ^ d); maxT = o > maxT ? o : maxT; }
     uint32_t cnt = 0;
     const int gshift = (lane >> 2) << 2;
+    // Neither the renormalisation words nor the decoded bytes touch global memory inside the dependent loop: the payload of
+    // each chunk is staged 128 words at a time into an LDS ring (s_pay), the output leaves through a 256-byte LDS row per
+    // chunk every 64 steps (a global access in the loop would put its latency, and the in-order vmcnt, on every step).
+    uint32_t payHi = 0;                                                  // words [payHi - 256, payHi) of my chunk are staged
     for (uint32_t t = 0; t < maxT; t++) {
+        if (wave_ballot(live && cnt + 4 > payHi) != 0) {                 // some chunk of the wave is about to run dry
+            wave_sync();
+            for (int cg = 0; cg < KNZ_ANS0_DEC_CHUNKS; cg++) {
+                const uint32_t hiC = wave_readlane(payHi, 4 * cg), cntC = wave_readlane(cnt, 4 * cg);
+                if (cntC + 4 <= hiC || wave_readlane((uint32_t)live, 4 * cg) == 0) continue;
+                const uint64_t pb = wave_shfl64(paybit, 4 * cg);
+                for (uint32_t j = lane; j < 128; j += 64) {
+                    const uint32_t wi = hiC + j;
+                    s_pay[cg][wi & 255] = (uint16_t)(knz_fetch32(a.stream, (int64_t)(pb + 16ull * wi), (int64_t)limit) >> 16);
+                }
+            }
+            if (live && cnt + 4 > payHi) payHi += 128;
+            wave_sync();
+        }
         const bool act = t < T;
         uint32_t need = 0;
         if (act) {
             const uint32_t slot = st & 4095u;
             const uint32_t sym = s_f2s[g][slot];
-            dst[4 * t + (3 - c)] = (uint8_t)sym;                      // block[i]=cur3 .. block[i+3]=cur0 (:908-919)
+            s_ob[g][(4 * t + (3 - c)) & 255] = (uint8_t)sym;              // block[i]=cur3 .. block[i+3]=cur0 (:908-919)
             const uint32_t e = s_sym[g][sym];
             st = (e & 0xFFFFu) * (st >> 12) + slot - (e >> 16);        // decodeSymbol :846-858
             need = st < (1u << 15) ? 1u : 0u;
@@ -407,10 +427,21 @@ __global__ __launch_bounds__(64) void knz_ans0_decode_kernel(Ans0DecArgs a) {
         if (need) {
             // refill order inside one iteration: st3, st2, st1, st0
             const uint32_t r = cnt + (uint32_t)__popc(gb >> (c + 1));
-            const uint32_t w = knz_fetch32(a.stream, (int64_t)(paybit + 16ull * r), (int64_t)limit) >> 16;
-            st = (st << 16) | w;
+            st = (st << 16) | s_pay[g][r & 255];
         }
         cnt += (uint32_t)__popc(gb);
+        if ((t & 63) == 63 || t + 1 == maxT) {                           // 256 decoded bytes per chunk (or the rest)
+            wave_sync();
+            const uint32_t base = (t & ~63u) * 4;
+            for (int cg = 0; cg < KNZ_ANS0_DEC_CHUNKS; cg++) {
+                const uint32_t Tc = wave_readlane(T, 4 * cg);
+                if (4 * Tc <= base) continue;
+                const uint32_t m = min(256u, 4 * Tc - base);
+                uint8_t* dc = (uint8_t*)wave_shfl64((uint64_t)dst, 4 * cg);
+                for (uint32_t i = lane; i < m; i += 64) dc[base + i] = s_ob[cg][i];
+            }
+            wave_sync();
+        }
     }
     if (live && c == 0) {
         for (uint32_t i = end4; i < n; i++)

@@ -3,12 +3,11 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout 900 python -m pytest tests/test_parity_gpu.py -x -q -k "LZ or lz or transforms or full_size" > gpurun_out/pytest_gpu.log 2>&1
+timeout 900 python -m pytest tests/test_parity_gpu.py -x -q -k "ANS0 or ans0 or stream or checksums or batch" > gpurun_out/pytest_gpu.log 2>&1
 tail -2 gpurun_out/pytest_gpu.log
-timeout 900 python bench.py --config lz --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_lz_q.json 2> gpurun_out/bench_lz_q.err
+timeout 600 python bench.py --config ans0 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_ans0_q.json 2> gpurun_out/bench_ans0_q.err
 python - <<PY
 import json
-d=json.loads(open('gpurun_out/bench_lz_q.json').read().strip().splitlines()[-1])
+d=json.loads(open('gpurun_out/bench_ans0_q.json').read().strip().splitlines()[-1])
 print(d['value'], d['encode_MBps'], d['decode_MBps'], d['roofline']['all_stage_ms'], d['bit_exact_vs_oracle'], d['roundtrip_ok'])
 PY
-timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_q.json 2> gpurun_out/bench_q.err; tail -c 300 gpurun_out/bench_q.json
