@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void knz_ans1_expand_kernel(Ans1Args a, uint4*
 // ring and flushed by the whole wave: on gfx950 stores and loads share the in-order vmcnt counter, so a global store
 // inside the dependent loop would stall every following entry load.
 __global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a, const uint4* ent) {
-    __shared__ uint16_t s_ring[KNZ_ANS1_RING + 64];
+    __shared__ uint16_t s_w[3 * KNZ_ANS1_GROUP * 4];                    // candidate word of (step, state) of the current 48 steps
     const int lane = threadIdx.x;
     const uint32_t slotId = blockIdx.x;
     uint32_t b, n; const uint8_t* src; bool bad;
@@ -277,53 +277,60 @@ __global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a, const u
     uint8_t* payEnd = slot + KNZ_ANS1_PAY_OFF + KNZ_ANS1_PAY_CAP;
     // lanes 4..63 mirror lanes 0..3 (same entries, same state, same LDS words): no divergence, no masked loads
     const uint4* __restrict__ my = ent + (size_t)slotId * KNZ_ANS1_ENT_STRIDE + (size_t)(lane & 3);
-    const uint32_t below = (1u << (lane & 3)) - 1u;
     uint32_t st = 1u << 15;
-    uint32_t cnt = 0, flushed = 0;
+    uint32_t flushed = 0;
     uint4 buf0[KNZ_ANS1_GROUP], buf1[KNZ_ANS1_GROUP], buf2[KNZ_ANS1_GROUP];
     auto load_group = [&](uint32_t t0, uint4* e) {
 #pragma unroll
         for (int j = 0; j < KNZ_ANS1_GROUP; j++) e[j] = my[(size_t)(t0 + j) * 4];
     };
-    auto run_group = [&](const uint4* e) {
+    // Per step only the state arithmetic is on the dependent chain. Whether a state renormalises goes, as 4 bits per step,
+    // into a wave-uniform 64-bit mask per group (scalar unit); the low 16 bits of every state go to a FIXED LDS slot of
+    // (step, state). Which of those candidates are real words and where they land in the descending stream is sorted out
+    // once per 48 steps by all 64 lanes (emit order = step, then state = bit order of the masks).
+    auto run_group = [&](const uint4* e, uint16_t* wslot, uint64_t& mask) {
+        mask = 0;
 #pragma unroll
         for (int j = 0; j < KNZ_ANS1_GROUP; j++) {
             const bool x = st >= e[j].y;
-            const uint32_t bal = (uint32_t)wave_ballot(x) & 0xFu;
-            const uint32_t r = cnt + (uint32_t)__popc(bal & below);          // cnt counts from the last flush: no wrap
-            s_ring[x ? r : (uint32_t)(KNZ_ANS1_RING + (lane & 3))] = (uint16_t)st;   // word r of the descending stream
+            mask |= (wave_ballot(x) & 0xFull) << (4 * j);
+            wslot[4 * j + (lane & 3)] = (uint16_t)st;
             st = x ? (st >> 16) : st;
-            cnt += (uint32_t)__popc(bal);
             // q = st / freq < 2^20 after the renormalisation (st < freq << 20): the product with 2048 - freq fits mul24
             const uint32_t qq = (uint32_t)(((uint64_t)st * e[j].x) >> 32) >> (e[j].w & 31u);
             st = st + e[j].z + knz_mul24(qq, e[j].w >> 8);
         }
     };
-    auto flush = [&](bool force) {
-        if (cnt > KNZ_ANS1_RING - 4 * 3 * KNZ_ANS1_GROUP || force) {                    // wave-uniform
-            wave_sync();
-            for (uint32_t r = (uint32_t)lane; r < cnt; r += 64) {
-                const uint16_t wv = s_ring[r];
-                uint8_t* p = payEnd - 2 * ((size_t)flushed + r + 1);
+    auto flush = [&](uint64_t m0, uint64_t m1, uint64_t m2) {
+        wave_sync_lds();
+        const uint64_t below = ((uint64_t)1 << lane) - 1;
+        const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2);
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const uint64_t m = r == 0 ? m0 : (r == 1 ? m1 : m2);
+            const uint32_t before = r == 0 ? 0u : (r == 1 ? c0 : c0 + c1);
+            if ((m >> lane) & 1) {
+                const uint32_t pos = flushed + before + (uint32_t)__popcll(m & below);
+                const uint16_t wv = s_w[64 * r + lane];
+                uint8_t* p = payEnd - 2 * ((size_t)pos + 1);
                 p[0] = (uint8_t)(wv >> 8);
                 p[1] = (uint8_t)wv;
             }
-            flushed += cnt;
-            cnt = 0;
-            wave_sync();
         }
+        flushed += c0 + c1 + c2;
+        wave_sync_lds();
     };
     // The pipeline starts on neutral entries (two groups of no-ops) instead of a load prologue: every load of the kernel is
     // then issued inside the loop in program order, which is what lets the compiler wait with vmcnt(32+) instead of vmcnt(0).
 #pragma unroll
     for (int j = 0; j < KNZ_ANS1_GROUP; j++) { buf0[j].x = 0; buf0[j].y = 0xFFFFFFFFu; buf0[j].z = 0; buf0[j].w = 0; buf1[j] = buf0[j]; }
     for (uint32_t t0 = 0; t0 < steps + 2 * KNZ_ANS1_GROUP && steps; t0 += 3 * KNZ_ANS1_GROUP) {
-        load_group(t0, buf2); run_group(buf0);
-        load_group(t0 + KNZ_ANS1_GROUP, buf0); run_group(buf1);
-        load_group(t0 + 2 * KNZ_ANS1_GROUP, buf1); run_group(buf2);
-        flush(false);
+        uint64_t m0, m1, m2;
+        load_group(t0, buf2); run_group(buf0, s_w, m0);
+        load_group(t0 + KNZ_ANS1_GROUP, buf0); run_group(buf1, s_w + 4 * KNZ_ANS1_GROUP, m1);
+        load_group(t0 + 2 * KNZ_ANS1_GROUP, buf1); run_group(buf2, s_w + 8 * KNZ_ANS1_GROUP, m2);
+        flush(m0, m1, m2);
     }
-    flush(true);
     const uint32_t s1 = wave_shfl(st, 1), s2 = wave_shfl(st, 2), s3 = wave_shfl(st, 3);
     if (bad && lane == 0) a.blk_status[b] = KNZ_ERR_PROCESS_BLOCK;
     if (live && lane == 0) {
