@@ -2,7 +2,7 @@
 // log range 11, 256 context tables, the chunk split into 4 quarters coded BACKWARDS in lock-step by the 4 states, each
 // quarter's first symbol coded in context 0 (ANSRangeCodec.go:353-388, rebuildStatistics :414-423).
 //
-//   knz_ans1_hist_kernel    16 workgroups per chunk, each owns 16 contexts in LDS and streams the chunk (L2/MALL resident)
+//   knz_ans1_hist_kernel    4 workgroups per chunk, each owns 64 contexts in LDS and streams the chunk (L2/MALL resident)
 //   knz_ans1_stats_kernel   one wave per (chunk, context): NormalizeFrequencies to 2048, symbol parameters, header bits
 //   knz_ans1_merge_kernel   one workgroup per chunk: bit-granular concatenation of the 256 context headers (unit 0)
 //   knz_ans1_expand_kernel  parallel: resolves the (context, symbol) -> parameters look-up of every coding step into a stream
@@ -50,26 +50,34 @@ __device__ __forceinline__ bool knz_ans1_chunk(const Ans1Args& a, uint32_t slotI
     return true;
 }
 
-// order-1 histogram with the quarter rule (Global.go:252-299 called per quarter, ANSRangeCodec.go:414-423)
+// order-1 histogram with the quarter rule (Global.go:252-299 called per quarter, ANSRangeCodec.go:414-423): 4 x 8 workgroups per
+// chunk: workgroup (grp, slice) counts the contexts 64*grp.. of one eighth of the chunk in 64 KiB of LDS and adds its non-zero
+// counters to the (zeroed) chunk table
+#define KNZ_ANS1_HIST_WGS 4
+#define KNZ_ANS1_HIST_SLICES 8
+#define KNZ_ANS1_HIST_CTX (256 / KNZ_ANS1_HIST_WGS)
 __global__ __launch_bounds__(256) void knz_ans1_hist_kernel(Ans1Args a) {
-    __shared__ uint32_t s_h[16][256];
+    __shared__ uint32_t s_h[KNZ_ANS1_HIST_CTX][256];
     const int tid = threadIdx.x;
-    const uint32_t slotId = blockIdx.x >> 4, grp = blockIdx.x & 15;
+    const uint32_t slotId = blockIdx.x / (KNZ_ANS1_HIST_WGS * KNZ_ANS1_HIST_SLICES);
+    const uint32_t grp = (blockIdx.x / KNZ_ANS1_HIST_SLICES) % KNZ_ANS1_HIST_WGS, slice = blockIdx.x % KNZ_ANS1_HIST_SLICES;
     uint32_t b, n; const uint8_t* src;
     if (!knz_ans1_chunk(a, slotId, b, n, src)) return;
-    for (int i = tid; i < 16 * 256; i += 256) (&s_h[0][0])[i] = 0;
+    for (int i = tid; i < KNZ_ANS1_HIST_CTX * 256; i += 256) (&s_h[0][0])[i] = 0;
     __syncthreads();
     const uint32_t quarter = n >> 2;
     const uint32_t counted = quarter == 0 ? n : 4 * quarter;      // the (n & 3) tail is stored raw
-    for (uint32_t p = tid; p < counted; p += 256) {
+    const uint32_t per = (counted + KNZ_ANS1_HIST_SLICES - 1) / KNZ_ANS1_HIST_SLICES;
+    const uint32_t lo = slice * per, hi = min(counted, lo + per);
+    for (uint32_t p = lo + tid; p < hi; p += 256) {
         const uint32_t sym = src[p];
         const bool first = quarter == 0 ? (p == 0) : (p % quarter == 0);
         const uint32_t ctx = first ? 0u : src[p - 1];
-        if ((ctx >> 4) == grp) atomicAdd(&s_h[ctx & 15][sym], 1u);
+        if (ctx / KNZ_ANS1_HIST_CTX == grp) atomicAdd(&s_h[ctx % KNZ_ANS1_HIST_CTX][sym], 1u);
     }
     __syncthreads();
-    uint32_t* out = a.freqs + ((size_t)slotId * 256 + grp * 16) * 256;
-    for (int i = tid; i < 16 * 256; i += 256) out[i] = (&s_h[0][0])[i];
+    uint32_t* out = a.freqs + ((size_t)slotId * 256 + grp * KNZ_ANS1_HIST_CTX) * 256;
+    for (int i = tid; i < KNZ_ANS1_HIST_CTX * 256; i += 256) { const uint32_t v = (&s_h[0][0])[i]; if (v) atomicAdd(&out[i], v); }
 }
 
 // one wave per (chunk, context)

@@ -307,7 +307,8 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             a.scratch = h->scratch.as<uint8_t>(); a.unit_bits = h->unit_bits.as<uint32_t>(); a.unit_src = h->unit_src.as<uint32_t>();
             a.freqs = h->a1_freqs.as<uint32_t>(); a.tab = h->a1_tab.as<uint2>(); a.ctx_hdr = h->a1_ctxhdr.as<uint8_t>();
             a.ctx_bits = h->a1_ctxbits.as<uint32_t>(); a.blk_status = h->blk_status.as<int32_t>();
-            hipLaunchKernelGGL(knz_ans1_hist_kernel, dim3(ns * 16), dim3(256), 0, st, a);
+            hipMemsetAsync(h->a1_freqs.p, 0, (size_t)ns * 65536 * 4, st);
+            hipLaunchKernelGGL(knz_ans1_hist_kernel, dim3(ns * KNZ_ANS1_HIST_WGS * KNZ_ANS1_HIST_SLICES), dim3(256), 0, st, a);
             hipLaunchKernelGGL(knz_ans1_stats_kernel, dim3(ns * 256), dim3(64), 0, st, a);
             hipLaunchKernelGGL(knz_ans1_merge_kernel, dim3(ns), dim3(256), 0, st, a);
             hipLaunchKernelGGL(knz_ans1_expand_kernel, dim3(ns, 128), dim3(256), 0, st, a, h->a1_ent.as<uint4>());
