@@ -455,6 +455,8 @@ static inline void decompressStream(const uint8_t* src, size_t n, int jobs, std:
                 outs[b].resize(blk);
                 size_t d = decodeBlock(payloads[b].data.data(), payloads[b].data.size(), h.transformType, h.entropyType,
                                        h.checksumBits, blk, outs[b].data(), outs[b].size());
+                // :1707-1710 a block that decodes to more than the stream block size is rejected by the reader
+                if (d > (size_t)h.blockSize) throw KnzError(ERR_PROCESS_BLOCK, "Block incorrectly decompressed");
                 outs[b].resize(d);
             } catch (const KnzError& e) { int z = 0; if (errCode.compare_exchange_strong(z, e.code)) errMsg = e.what(); return; }
         }

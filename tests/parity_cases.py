@@ -387,3 +387,44 @@ def check_ans1_table_decoder(be):
         check_entropy_encode(be, "ANS1")
     finally:
         del os.environ["KNZ_ANS1_TABLE_DECODER"]
+
+
+def check_corrupt_streams(be, trials=12):
+    """Bit flips in valid streams: the device decoder must come back (an error code or some output), never hang or touch
+    memory outside its buffers, for every codec on the path. When the oracle decodes the damaged stream without an error,
+    the device must produce the same bytes (same decoder semantics), except where only the checksum could tell."""
+    rng = np.random.default_rng(2024)
+    n, bs = 150000, 65536
+    data = corpus(n, 77)
+    for transform, entropy in (("NONE", "HUFFMAN"), ("NONE", "ANS0"), ("NONE", "ANS1"), ("RANK+ZRLT", "ANS0"), ("LZ", "NONE"),
+                               ("BWT", "NONE"), ("NONE", "FPAQ")):
+        good = O.compress(data, transform, entropy, bs)
+        c = K.Codec(transform, entropy, bs, lib=be.lib)
+        out, ko = be.empty(n + bs + 64)
+        for t in range(trials):
+            bad = bytearray(good)
+            for _ in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(24 * 8, len(bad) * 8))          # behind the stream header
+                bad[pos >> 3] ^= 0x80 >> (pos & 7)
+            sp, ks = be.to_dev(bytes(bad), 4)
+            try:
+                nd = c.dev_decompress(sp, len(bad), out, n + bs + 64)
+                got = be.to_host(ko, nd)
+            except K.KnzError as e:
+                got = None
+            try:
+                exp = O.decompress(bytes(bad), n + bs + 64)
+            except Exception:
+                exp = None
+            # a damaged ANS payload makes the reference read stale bytes of its own reusable buffer behind the payload
+            # (v2/entropy/ANSRangeDecoder.go decodeChunk): those bytes are not part of the stream, so only the block checksum
+            # can tell; for the other codecs the two decoders must agree on error-or-bytes
+            # A damaged BWT block is a permutation with several cycles: the reference walks whatever cycle the primary index
+            # is on and emits it without complaint, the device's chained inverse notices and reports ERR_PROCESS_BLOCK
+            # (DESIGN.md, deviations).
+            if entropy.startswith("ANS") or "BWT" in transform:
+                continue
+            assert (exp is None) == (got is None), (transform, entropy, t, exp is None, got is None)
+            if exp is not None:
+                assert got == exp, (transform, entropy, t)
+        c.close()

@@ -77,3 +77,8 @@ def test_block_checksums(be):
 
 def test_ans1_table_decoder(be):
     P.check_ans1_table_decoder(be)
+
+
+@pytest.mark.timeout(600)
+def test_corrupt_streams_come_back(be):
+    P.check_corrupt_streams(be)
