@@ -6,9 +6,14 @@ shaped like silesia.tar, bench_corpus.py). One step = compress the whole stream 
 decompress it back, inputs resident in HBM. value = uncompressed MB (10^6 B) per second of a whole round trip;
 encode-only and decode-only rates are reported next to it.
 
-N>1: the blocks are sharded statically (contiguous ranges) over the ranks; every rank encodes/decodes its own
-blocks, the compressed segments are gathered to rank 0 over RCCL and assembled bit-granularly there; the gather stays in
-flight while each rank decodes its own segment. Total work is fixed => "scaling": "strong".
+N>1 (weak scaling: per-GPU work is fixed): the stream is N copies of S-silesia back to back (N x 211,957,760 B, one .knz
+stream); its blocks are sharded statically (contiguous ranges, ~51 blocks per rank) over the ranks; every rank
+encodes/decodes its own blocks, the compressed segments are gathered to rank 0 over RCCL and assembled bit-granularly
+there; the gather stays in flight while each rank decodes its own segment. value = all bytes of all ranks / step time.
+
+KNZ_BENCH_EMU=1 is a TEST HARNESS switch (tests/test_bench_ranks.py): the same control flow on CPU tensors with the kernels
+compiled against tests/emu and gloo instead of RCCL, so that the N>1 step can be exercised without GPUs. It is not a
+product path and its JSON says so.
 
 Prints ONE JSON line on rank 0.
 """
@@ -81,7 +86,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="huffman", choices=sorted(CONFIGS))
-    ap.add_argument("--size", type=int, default=0, help="override the corpus size (debug)")
+    ap.add_argument("--size", type=int, default=0, help="override the per-GPU corpus size (debug)")
+    ap.add_argument("--block-size", type=int, default=0, help="override the block size (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -93,35 +99,64 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-
-    K = load_pkg()
-    K.build_library()
+    emu = os.environ.get("KNZ_BENCH_EMU") == "1"          # test harness only, see the module docstring
+    if emu:
+        import knz
+        dev = torch.device("cpu")
+        sync = lambda: None
+        if world > 1:
+            dist.init_process_group("gloo")
+        K = knz.package()
+        lib = knz.emu_library()
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
+        if world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", device_id=dev)
+        K = load_pkg()
+        K.build_library()
+        lib = None
     from kanzi_go_amd import dist as kd
     transform, entropy, bs, cfg_idx = CONFIGS[args.config]
+    bs = args.block_size or bs
 
-    size = args.size or bench_corpus.SILESIA_SIZE
-    data = bench_corpus.s_silesia(size)
+    base_size = args.size or bench_corpus.SILESIA_SIZE
+    base = bench_corpus.s_silesia(base_size)
+    size = base_size * world                                 # weak scaling: one copy of the corpus per GPU, ONE stream
     nblocks = (size + bs - 1) // bs
+    lo_b, hi_b = kd.block_range(nblocks, rank, world)
     per = (nblocks + world - 1) // world
-    lo_b, hi_b = min(rank * per, nblocks), min((rank + 1) * per, nblocks)
     lo, hi = lo_b * bs, min(hi_b * bs, size)
-    my = data[lo:hi]
+
+    def tiled(a, b):                                         # bytes [a, b) of the corpus repeated back to back
+        parts = []
+        while a < b:
+            o = a % base_size
+            take = min(b - a, base_size - o)
+            parts.append(base[o:o + take])
+            a += take
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+
+    my = tiled(lo, hi)
     n_my = len(my)
 
-    codec = K.Codec(transform, entropy, bs, device=local_rank)
-    d_src = torch.from_numpy(np.ascontiguousarray(my)).to(dev) if n_my else torch.zeros(16, dtype=torch.uint8, device=dev)
-    cap = per * bs + (per * bs) // 2 + (1 << 20)   # same on every rank (gather uses equal-sized buffers)
-    d_seg = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    d_back = torch.zeros(n_my + 4096, dtype=torch.uint8, device=dev)
-    d_stream = torch.zeros(size + size // 2 + (1 << 20), dtype=torch.uint8, device=dev) if rank == 0 and world > 1 else None
-    stream = torch.cuda.current_stream().cuda_stream
+    def dev_zeros(n):                                        # 16-byte aligned (the emulator's "device" memory is host memory)
+        t = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
+        return t[(-t.data_ptr()) % 16:][:n]
+
+    codec = K.Codec(transform, entropy, bs, device=local_rank, lib=lib)
+    d_src = dev_zeros(max(n_my, 16))
+    if n_my:
+        d_src[:n_my] = torch.from_numpy(np.ascontiguousarray(my)).to(dev)
+    cap = (per * bs + (per * bs) // 2 + (1 << 20) + 15) & ~15   # same on every rank (gather uses equal-sized buffers)
+    d_seg = dev_zeros(cap)
+    d_back = dev_zeros(n_my + 4096)
+    d_stream = dev_zeros(size + size // 2 + (1 << 20)) if rank == 0 and world > 1 else None
+    stream = 0 if emu else torch.cuda.current_stream().cuda_stream
 
     stage = {"enc_transform": 0.0, "enc_entropy": 0.0, "enc_layout": 0.0, "enc_gather": 0.0, "dec_walk": 0.0, "dec_entropy": 0.0, "dec_transform": 0.0}
     t_enc = t_dec = 0.0
@@ -140,18 +175,18 @@ def main():
             result["seg_bits"] = nbits
         tm = codec.last_timing()
         if world == 1:
-            torch.cuda.synchronize()
+            sync()
         t1 = time.perf_counter()
         if world == 1:
             nd = codec.dev_decompress(d_seg.data_ptr(), result["stream_bytes"], d_back.data_ptr(), d_back.numel(), stream=stream)
         else:
             nd = codec.dev_decompress_blocks(d_seg.data_ptr(), result["seg_bits"], d_back.data_ptr(), d_back.numel(), stream=stream) if n_my else 0
         td = codec.last_timing()
-        torch.cuda.synchronize()
+        sync()
         t2 = time.perf_counter()
         if world > 1:
             nb, _ = pending.finish()
-            torch.cuda.synchronize()
+            sync()
             t3 = time.perf_counter()
             t0 -= (t3 - t2)                        # the assembly belongs to the encode side of the step
             if rank == 0:
@@ -167,11 +202,11 @@ def main():
         one_step(False)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t_start = time.perf_counter()
     for _ in range(args.steps):
         one_step(True)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
@@ -181,6 +216,10 @@ def main():
         elapsed, t_enc, t_dec = [float(x) for x in tt.tolist()]
 
     ok_roundtrip = bool(torch.equal(d_back[:n_my], d_src[:n_my])) if n_my else True
+    if world > 1:                                            # every rank's decode must have come back right
+        okt = torch.tensor([1 if ok_roundtrip else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok_roundtrip = bool(int(okt.item()))
 
     if rank == 0:
         K_ = max(args.steps, 1)
@@ -190,10 +229,12 @@ def main():
             "metric": "encode+decode MB/s (round trip of the whole stream, uncompressed 10^6 B per second)",
             "value": round(size / 1e6 / (elapsed / K_), 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{cfg_idx}]: -t {transform} -e {entropy} -b {bs >> 20}m on S-silesia "
-                                   f"({size} B, bench_corpus.py)", "blocks": nblocks, "block_size": bs,
-                       "parallelism": f"blocks sharded over {world} GPU(s)"},
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic" if not emu else "synthetic (EMULATOR TEST HARNESS on CPU: not a measurement)",
+            "config": {"workload": f"BASELINE.json configs[{cfg_idx}]: -t {transform} -e {entropy} -b {bs >> 20}m on "
+                                   + (f"{world} x " if world > 1 else "") + f"S-silesia ({base_size} B per GPU, one stream of {size} B, bench_corpus.py)",
+                       "blocks": nblocks, "block_size": bs,
+                       "parallelism": f"contiguous block ranges over {world} GPU(s), segments gathered to rank 0"},
             "encode_MBps": round(size / 1e6 / (t_enc / K_), 2), "decode_MBps": round(size / 1e6 / (t_dec / K_), 2),
             "compressed_bytes": int(C_bytes), "roundtrip_ok": ok_roundtrip,
         }
@@ -221,18 +262,13 @@ def main():
                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(dur_ms, 4),
                            "all_stage_ms": {k: round(v, 4) for k, v in per_launch.items()}}
-        if not args.no_verify and world == 1:
+        if not args.no_verify:
             import oracle_lib as O
-            exp = O.compress(data, transform, entropy, bs, 0, jobs=os.cpu_count() or 1)
-            got = d_seg[:C_bytes].cpu().numpy().tobytes()
-            out["bit_exact_vs_oracle"] = bool(got == exp)
-        elif not args.no_verify:
-            import oracle_lib as O
-            exp = O.compress(data, transform, entropy, bs, 0, jobs=os.cpu_count() or 1)
-            got = d_stream[:C_bytes].cpu().numpy().tobytes()
+            exp = O.compress(tiled(0, size), transform, entropy, bs, 0, jobs=os.cpu_count() or 1)
+            got = (d_seg if world == 1 else d_stream)[:C_bytes].cpu().numpy().tobytes()
             out["bit_exact_vs_oracle"] = bool(got == exp)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(data, transform, entropy, bs)
+            out["cpu_baseline"] = cpu_baseline(base, transform, entropy, bs)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

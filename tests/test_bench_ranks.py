@@ -1,0 +1,43 @@
+"""bench.py's N > 1 step (weak scaling: one corpus copy per rank, one stream, gather to rank 0, assembly, per-rank decode)
+exercised without GPUs: launched exactly as the driver launches it (torch.distributed.run, one process per rank), with
+KNZ_BENCH_EMU=1 = CPU tensors + kernels on tests/emu + gloo. Checks the JSON contract and that the assembled stream is the
+oracle's stream of the whole N-copy input."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(nproc, extra):
+    import knz
+    knz.emu_library()                                    # build once, before the ranks race for it
+    env = dict(os.environ, KNZ_BENCH_EMU="1")
+    port = str(23000 + (os.getpid() % 4000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"] + extra
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(1000)
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_bench_ranks_weak_scaling(nproc):
+    size, bs = 5 * 65536 + 4321, 65536
+    out = _run(nproc, ["--size", str(size), "--block-size", str(bs)])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == nproc and out["steps"] == 2 and out["warmup"] == 1
+    assert out["scaling"] == "weak" and out["higher_is_better"] is True
+    assert out["config"]["blocks"] == (nproc * size + bs - 1) // bs
+    assert out["roundtrip_ok"] is True
+    assert out["bit_exact_vs_oracle"] is True
+    assert "EMULATOR" in out["data"]
