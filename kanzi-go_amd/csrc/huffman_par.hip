@@ -37,11 +37,22 @@ struct KnzHufHdr {
     uint32_t status;                  // 0 ok, 1 unusual encoding -> serial parser, 2 invalid (ERR_PROCESS_BLOCK)
 };
 
-// 32 bits at bit offset `bit` of a window of BE words held in LDS
-__device__ __forceinline__ uint32_t knz_win32(const uint32_t* w, uint32_t bit) {
+// Header windows: BE words (already byte-swapped) held in LDS, either a plain array or a stretch of the walker's ring.
+struct KnzLinWin {
+    const uint32_t* p;
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return p[i]; }
+};
+struct KnzRingWin {
+    const uint32_t* ring; uint32_t base, mask;
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return ring[(base + i) & mask]; }
+};
+
+// 32 bits at bit offset `bit` of a window
+template <class Win>
+__device__ __forceinline__ uint32_t knz_win32(const Win& w, uint32_t bit) {
     const uint32_t i = bit >> 5, o = bit & 31;
-    const uint32_t hi = w[i], lo = w[i + 1];
-    return o ? ((hi << o) | (lo >> (32 - o))) : hi;
+    const uint64_t v = ((uint64_t)w.at(i) << 32) | w.at(i + 1);
+    return (uint32_t)((v << o) >> 32);
 }
 
 // bits [pos, pos + 32) of the 64-bit window {hi, lo}, pos in 0..31
@@ -56,23 +67,24 @@ __device__ __forceinline__ uint32_t knz_top32(uint32_t hi, uint32_t lo, uint32_t
 // exact, and these codes re-synchronise within a few bits, so this takes 2-3 rounds instead of `count` serial steps.
 // Returns 0 and the bit offset just past the section, 1 when the serial parser has to take over (a delta a Go encoder never
 // writes, or a section longer than 64 * W bits), 2 for an invalid length.
-template <bool WANT_LEN, int W>
-__device__ __forceinline__ uint32_t knz_huf_delta_section(const uint32_t* w, uint32_t e0, uint32_t count, uint8_t* s_alpha, uint8_t* s_len, int lane, uint32_t& endOut) {
+template <bool WANT_LEN, int W, class Win>
+__device__ __forceinline__ uint32_t knz_huf_delta_section(const Win& w, uint32_t e0, uint32_t count, uint8_t* s_alpha, uint8_t* s_len, int lane, uint32_t& endOut) {
     const uint32_t p0 = e0 + (uint32_t)W * (uint32_t)lane;
     const uint32_t whi = knz_win32(w, p0), wlo = knz_win32(w, p0 + 32);
     const uint64_t win = ((uint64_t)whi << 32) | wlo;
     const bool relevant = (uint32_t)lane <= (count * 8 + W - 1) / W;     // a usual code has at most 8 bits
-    uint32_t o = 0, c = 0;
+    uint32_t o = 0, c = 0, ex = 0;
     int ds = 0;
-    bool odd = false;
+    bool odd = false, need = relevant;                                   // lanes behind the section carry nothing
     for (int rounds = 0; ; rounds++) {
-        uint32_t pos = relevant ? o : (uint32_t)W;                       // lanes behind the section carry nothing
-        c = 0; ds = 0; odd = false;
+        // only the lanes whose entry offset moved walk again: the last round (nothing moved) costs one shuffle and one ballot
+        uint32_t pos = need ? o : (uint32_t)W;
+        if (need) { c = 0; ds = 0; odd = false; }
         while (pos < (uint32_t)W) {
-            const uint32_t bits = knz_top32(whi, wlo, pos);
+            const uint32_t bits = (uint32_t)((win << pos) >> 32);
             const uint32_t ones = min((uint32_t)__builtin_clz(~bits | 1u), (uint32_t)W - pos);
             const uint32_t pos1 = pos + ones;
-            const uint32_t b2 = knz_top32(whi, wlo, pos1 & 31);
+            const uint32_t b2 = (uint32_t)((win << pos1) >> 32);             // (pos1 <= W <= 32)
             const bool lng = pos1 < (uint32_t)W && !(b2 >> 31);            // a code with leading zeros starts inside my bits
             const uint32_t z = (uint32_t)__builtin_clz(b2 | 1u);
             if (lng && z > 3) odd = true;                                  // not a length delta a Go encoder writes
@@ -84,15 +96,16 @@ __device__ __forceinline__ uint32_t knz_huf_delta_section(const uint32_t* w, uin
             }
             pos = odd ? (uint32_t)W : pos1 + (lng ? 2 * z + 2 : 0u);
             c += ones + ((lng && !odd) ? 1u : 0u);
+            ex = pos - (uint32_t)W;
         }
-        uint32_t no = wave_shfl(pos - (uint32_t)W, lane - 1);
+        uint32_t no = wave_shfl(ex, lane - 1);
         if (lane == 0) no = 0;
-        const bool changed = no != o;
+        need = relevant && no != o;
         o = no;
 #ifdef KNZ_EMU_STATS
         if (lane == 0) { extern unsigned long long g_stat[8]; g_stat[1]++; }
 #endif
-        if (wave_ballot(changed && relevant) == 0) break;
+        if (wave_ballot(need) == 0) break;
         if (rounds > 66) return 1;
     }
     const uint32_t cincl = wave_scan_incl(c);
@@ -145,8 +158,8 @@ __device__ __forceinline__ uint32_t knz_huf_delta_section(const uint32_t* w, uin
 // w: window of BE words (LDS), h0: bit offset of the chunk header inside it (< 32). All 64 lanes
 // of ONE wave call it; the result is wave-uniform. WANT_LEN: also fill s_alpha[0..count) and s_len[symbol] (zeroed by the
 // caller).
-template <bool WANT_LEN>
-__device__ __forceinline__ KnzHufHdr knz_huf_parse_header_wave(const uint32_t* w, uint32_t h0, uint8_t* s_alpha, uint8_t* s_len, int lane) {
+template <bool WANT_LEN, class Win>
+__device__ __forceinline__ KnzHufHdr knz_huf_parse_header_wave(const Win& w, uint32_t h0, uint8_t* s_alpha, uint8_t* s_len, int lane) {
     KNZ_PROF_T(pA);
     KnzHufHdr h;
     h.count = 0; h.end = 0; h.status = 0;
@@ -180,8 +193,8 @@ __device__ __forceinline__ KnzHufHdr knz_huf_parse_header_wave(const uint32_t* w
     // ---- code-length deltas: 16 bits of the section per lane when that can cover it, 32 otherwise ----------------------------
     uint32_t end = 0;
     uint32_t est = 1;
-    if (count <= 192) est = knz_huf_delta_section<WANT_LEN, 16>(w, e0, count, s_alpha, s_len, lane, end);
-    if (est == 1) est = knz_huf_delta_section<WANT_LEN, 32>(w, e0, count, s_alpha, s_len, lane, end);   // (section longer than 64 x 16 bits)
+    if (count <= 192) est = knz_huf_delta_section<WANT_LEN, 16, Win>(w, e0, count, s_alpha, s_len, lane, end);
+    if (est == 1) est = knz_huf_delta_section<WANT_LEN, 32, Win>(w, e0, count, s_alpha, s_len, lane, end);   // (section longer than 64 x 16 bits)
     if (est != 0) { h.status = est; return h; }
     KNZ_PROF_T(p3);
     h.end = end;
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, u
     }
     __syncthreads();
     if (wave == 0) {
-        const KnzHufHdr hh = knz_huf_parse_header_wave<true>(s_hw, (uint32_t)(cbit & 31), s_alpha, s_len, lane);
+        const KnzHufHdr hh = knz_huf_parse_header_wave<true>(KnzLinWin{s_hw}, (uint32_t)(cbit & 31), s_alpha, s_len, lane);
         if (lane == 0) s_hdr = hh;
     }
     __syncthreads();
@@ -499,7 +512,6 @@ __device__ __forceinline__ uint4 knz_walk_load_granule(const uint32_t* words, ui
 __global__ __launch_bounds__(128) void knz_dec_walk_blocks_kernel(WalkBlocksArgs a) {
     __shared__ uint8_t s_lut[1 << KNZ_EXPG_WIN];
     __shared__ __attribute__((aligned(16))) uint32_t s_ring[KNZ_WALK_RING];
-    __shared__ uint32_t s_hw[KNZ_HW_WORDS];
     __shared__ uint32_t s_sync[4];
     const uint32_t b = blockIdx.x;
     if (b >= a.nblocks) return;
@@ -534,7 +546,7 @@ __global__ __launch_bounds__(128) void knz_dec_walk_blocks_kernel(WalkBlocksArgs
                     if ((uint32_t)q < g) { const uint4 v = knz_walk_load_granule(swords, snwords, ringOrigin + hi + 256 * q, fl); pf[q][0] = v.x; pf[q][1] = v.y; pf[q][2] = v.z; pf[q][3] = v.w; }
 #pragma unroll
                 for (int q = 0; q < 8; q++)
-                    if ((uint32_t)q < g) { uint4 v; v.x = pf[q][0]; v.y = pf[q][1]; v.z = pf[q][2]; v.w = pf[q][3]; *(uint4*)&s_ring[(hi + 256 * q + 4 * (uint32_t)fl) & (KNZ_WALK_RING - 1)] = v; }
+                    if ((uint32_t)q < g) { uint4 v; v.x = knz_bswap32(pf[q][0]); v.y = knz_bswap32(pf[q][1]); v.z = knz_bswap32(pf[q][2]); v.w = knz_bswap32(pf[q][3]); *(uint4*)&s_ring[(hi + 256 * q + 4 * (uint32_t)fl) & (KNZ_WALK_RING - 1)] = v; }
                 hi += 256 * g;
                 wg_fence_release();
                 if (fl == 0) vsync[0] = hi;
@@ -592,6 +604,7 @@ __global__ __launch_bounds__(128) void knz_dec_walk_blocks_kernel(WalkBlocksArgs
         const uint64_t snwords = (a.nbytes + 3) >> 2;
         uint64_t pos = r.tell();                                           // walk position, authoritative
         bool stale = false;                                                // r is behind pos
+        uint32_t filled = 0;                                               // last feeder progress seen
         for (uint32_t k = 0; k < nchunks && status == 0; k++) {
             const uint32_t sz = min(chunkSize, preLen - k * chunkSize);
             if (writer) a.chunk_bit[(size_t)b * cpb + k] = pos;
@@ -600,17 +613,19 @@ __global__ __launch_bounds__(128) void knz_dec_walk_blocks_kernel(WalkBlocksArgs
                 const uint64_t w0i = pos >> 5;
                 const uint32_t rel = (uint32_t)(w0i - ringOrigin);
                 if (writer) vsync[1] = rel;                             // everything before this word may be overwritten
-                // the feeder is normally far ahead; wait for the header window otherwise (bounded: a stuck feeder = error)
+                // the feeder is normally far ahead (its progress is re-read only when the last value seen does not cover the
+                // header window); wait for the window otherwise (bounded: a stuck feeder = error)
                 const uint32_t need = (uint32_t)min((uint64_t)rel + KNZ_HW_WORDS, ((snwords - ringOrigin + 255) & ~(uint64_t)255));
-                uint32_t spins = 0;
-                while (vsync[0] < need) { wave_spin_pause(); if (++spins > (1u << 24)) break; }
-                if (spins > (1u << 24)) { status = KNZ_ERR_PROCESS_BLOCK; break; }
-                wg_fence_acquire();
+                if (filled < need) {
+                    uint32_t spins = 0;
+                    while ((filled = vsync[0]) < need) { wave_spin_pause(); if (++spins > (1u << 24)) break; }
+                    if (filled < need) { status = KNZ_ERR_PROCESS_BLOCK; break; }
+                    wg_fence_acquire();
+                }
                 KNZ_PROF_T(w1);
-                for (uint32_t i = threadIdx.x; i < KNZ_HW_WORDS; i += 64) s_hw[i] = knz_bswap32(s_ring[(rel + i) & (KNZ_WALK_RING - 1)]);
-                wave_sync_lds();
                 KNZ_PROF_T(w2);
-                const KnzHufHdr hdr = knz_huf_parse_header_wave<false>(s_hw, (uint32_t)(pos & 31), nullptr, nullptr, (int)threadIdx.x);
+                // the ring holds byte-swapped words (the feeder swaps): the header is parsed in place
+                const KnzHufHdr hdr = knz_huf_parse_header_wave<false>(KnzRingWin{s_ring, rel, KNZ_WALK_RING - 1}, (uint32_t)(pos & 31), nullptr, nullptr, (int)threadIdx.x);
                 KNZ_PROF_T(w3);
                 KNZ_PROF_T(w4);
                 KNZ_PROF_ADD(8, w0, w1); KNZ_PROF_ADD(9, w1, w2); KNZ_PROF_ADD(10, w2, w3); KNZ_PROF_ADD(11, w3, w4);
