@@ -230,6 +230,7 @@ __global__ __launch_bounds__(64) void knz_huf_decode_kernel(HufDecArgs a, const 
     const uint32_t n = min((uint32_t)KNZ_HUF_CHUNK, preLen - k * KNZ_HUF_CHUNK);
     uint8_t* dst = a.out + a.blk_out_off[b] + (size_t)k * KNZ_HUF_CHUNK;
     const uint64_t cbit = a.chunk_bit[blockIdx.x];
+    if (cbit >= ~0ull - 1) return;                                     // the walk never reached this chunk (fused walk+decode launch)
     uint32_t entropy = a.entropy;
     if (a.blk_mode[b] & 0x80) entropy = KNZ_E_NONE;
 

@@ -253,28 +253,43 @@ struct KnzFragReader {
 // ---------------------------------------------------------------------------------------------------------------------
 // One 256-thread workgroup per 16 KiB chunk: wave 0 parses the header, all threads build the code table, then wave j owns
 // fragment j and lane s its sub-range s of 64.
-__global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, uint8_t* fallback) {
-    __shared__ uint16_t s_table[1 << KNZ_HUF_MAXLEN];
-    __shared__ __attribute__((aligned(16))) uint8_t s_outb[256 * KNZ_HUF_LANE_CAP];   // >= KNZ_HUF_CHUNK: lane buffers, then the chunk
-    __shared__ uint32_t s_hw[KNZ_HW_WORDS];
-    __shared__ uint8_t s_len[256];
-    __shared__ uint8_t s_alpha[256];
-    __shared__ uint16_t s_C[258];
-    __shared__ uint8_t s_symAt[256];
-    __shared__ uint32_t s_cnt[4][16];
-    __shared__ KnzHufHdr s_hdr;
-    __shared__ int s_flag, s_over;
+// LDS of one chunk decode (a struct so that the fused walk+decode kernel can overlay it with the walker's ring)
+struct __attribute__((aligned(16))) KnzHufParShared {
+    uint16_t s_table[1 << KNZ_HUF_MAXLEN];
+    uint8_t s_outb[256 * KNZ_HUF_LANE_CAP];   // >= KNZ_HUF_CHUNK: lane buffers, then the chunk (16-byte aligned: 8192 bytes in)
+    uint32_t s_hw[KNZ_HW_WORDS];
+    uint8_t s_len[256];
+    uint8_t s_alpha[256];
+    uint16_t s_C[258];
+    uint8_t s_symAt[256];
+    uint32_t s_cnt[4][16];
+    KnzHufHdr s_hdr;
+    int s_flag, s_over;
+};
+
+// chunk `slot` (= block * chunks_per_block + chunk) whose first bit is `cbit`, by the 256 threads of a workgroup
+__device__ __forceinline__ void knz_huf_decode_par_body(const HufDecArgs& a, uint8_t* fallback, const uint32_t slot, const uint64_t cbit, KnzHufParShared& sh) {
+    uint16_t (&s_table)[1 << KNZ_HUF_MAXLEN] = sh.s_table;
+    uint8_t (&s_outb)[256 * KNZ_HUF_LANE_CAP] = sh.s_outb;
+    uint32_t (&s_hw)[KNZ_HW_WORDS] = sh.s_hw;
+    uint8_t (&s_len)[256] = sh.s_len;
+    uint8_t (&s_alpha)[256] = sh.s_alpha;
+    uint16_t (&s_C)[258] = sh.s_C;
+    uint8_t (&s_symAt)[256] = sh.s_symAt;
+    uint32_t (&s_cnt)[4][16] = sh.s_cnt;
+    KnzHufHdr& s_hdr = sh.s_hdr;
+    int& s_flag = sh.s_flag;
+    int& s_over = sh.s_over;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t cpb = a.chunks_per_block;
-    const uint32_t b = blockIdx.x / cpb, k = blockIdx.x % cpb;
-    if (tid == 0) fallback[blockIdx.x] = 0;
+    const uint32_t b = slot / cpb, k = slot % cpb;
+    if (tid == 0) fallback[slot] = 0;
     const uint32_t preLen = a.blk_pre_len[b];
     if (a.blk_status[b] != 0) return;
     if ((uint64_t)k * KNZ_HUF_CHUNK >= preLen) return;
     const uint32_t n = min((uint32_t)KNZ_HUF_CHUNK, preLen - k * KNZ_HUF_CHUNK);
     uint8_t* dst = a.out + a.blk_out_off[b] + (size_t)k * KNZ_HUF_CHUNK;
-    const uint64_t cbit = a.chunk_bit[blockIdx.x];
     uint32_t entropy = a.entropy;
     if (a.blk_mode[b] & 0x80) entropy = KNZ_E_NONE;
     const uint64_t limit = a.nbytes << 3;
@@ -303,7 +318,7 @@ __global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, u
     }
     __syncthreads();
     const KnzHufHdr hdr = s_hdr;
-    if (hdr.status == 1) { if (tid == 0) fallback[blockIdx.x] = 1; return; }
+    if (hdr.status == 1) { if (tid == 0) fallback[slot] = 1; return; }
     if (hdr.status == 2) { if (tid == 0) a.blk_status[b] = KNZ_ERR_PROCESS_BLOCK; return; }
     KNZ_PROF_T(t1);
     KNZ_PROF_ADD(0, t0, t1);
@@ -434,7 +449,7 @@ __global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, u
     __syncthreads();
     KNZ_PROF_T(t3);
     KNZ_PROF_ADD(2, t2, t3);
-    if (s_flag) { if (tid == 0) fallback[blockIdx.x] = 1; return; }
+    if (s_flag) { if (tid == 0) fallback[slot] = 1; return; }
     KNZ_PROF_INC(24, s_over ? 1 : 0);
     if (!s_over) {
         // every lane kept all of its symbols: pull the row into registers, then (the rows and the chunk share the LDS area)
@@ -483,6 +498,11 @@ __global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, u
     KNZ_PROF_ADD(5, t0, t5);
 }
 
+__global__ __launch_bounds__(256) void knz_huf_decode_par_kernel(HufDecArgs a, uint8_t* fallback) {
+    __shared__ KnzHufParShared sh;
+    knz_huf_decode_par_body(a, fallback, blockIdx.x, a.chunk_bit[blockIdx.x], sh);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // One wave per block, the serial walk runs on lane 0 only: putting several blocks on the lanes of one wave makes
 // their data-dependent loops diverge and the wave then pays for the union of all paths.
@@ -509,17 +529,71 @@ __device__ __forceinline__ uint4 knz_walk_load_granule(const uint32_t* words, ui
 // words the walker may still read), so that ring traffic costs the chain nothing. The two meet through three LDS words:
 // s_sync[0] = stream word index (relative to the ring origin) up to which the ring is filled, [1] = first word the walker
 // still needs, [2] = walker finished.
-__global__ __launch_bounds__(128) void knz_dec_walk_blocks_kernel(WalkBlocksArgs a) {
-    __shared__ uint8_t s_lut[1 << KNZ_EXPG_WIN];
-    __shared__ __attribute__((aligned(16))) uint32_t s_ring[KNZ_WALK_RING];
-    __shared__ uint32_t s_sync[4];
+struct __attribute__((aligned(16))) KnzWalkShared {
+    uint32_t s_ring[KNZ_WALK_RING];
+    uint8_t s_lut[1 << KNZ_EXPG_WIN];
+    uint32_t s_sync[4];
+};
+
+// chunk_bit values that are not positions (the fused kernel's decoders poll chunk_bit, which is preset to NOT_READY)
+#define KNZ_CHUNK_NOT_READY (~0ull)
+#define KNZ_CHUNK_ERR (~0ull - 1)
+
+struct KnzBlkHdr { uint32_t mode, skipFlags, preLen, entropy; uint64_t ck; int32_t status; };
+
+// block header (decodingTask.decode, v2/io/CompressedStream.go:1878-1914), wave-uniform
+__device__ __forceinline__ KnzBlkHdr knz_walk_block_header(const WalkBlocksArgs& a, KnzWaveReader& r) {
+    KnzBlkHdr h;
+    h.status = 0; h.mode = 0; h.skipFlags = 0; h.preLen = a.given_len; h.entropy = a.entropy; h.ck = 0;
+    if (!a.payload_only) {
+        h.mode = r.read(8);
+        if (h.mode & 0x80) { h.entropy = KNZ_E_NONE; h.skipFlags = 0xFF; }   // copy block: no transform runs (device convention)
+        else if (h.mode & 0x10) h.skipFlags = r.read(8);
+        else h.skipFlags = ((h.mode << 4) | 0x0F) & 0xFF;
+        const uint32_t dataSize = 1 + ((h.mode >> 5) & 3);
+        h.preLen = r.read(8 * dataSize);
+        uint64_t maxLen = (uint64_t)a.block_size + a.block_size / 2;   // blockLength + blockLength/2 (:1893)
+        if (maxLen < 2048) maxLen = 2048;
+        if (maxLen > (1u << 30)) maxLen = 1u << 30;
+        if (h.preLen == 0 || h.preLen > maxLen) h.status = KNZ_ERR_BLOCK_SIZE;
+        if (a.checksum_bits == 32) h.ck = r.read(32);
+        else if (a.checksum_bits == 64) { h.ck = (uint64_t)r.read(32) << 32; h.ck |= r.read(32); }
+    }
+    return h;
+}
+
+// Block headers only (one wave per block): what the host needs before anything is written (lengths, status); the fused
+// walk+decode kernel runs after it.
+__global__ __launch_bounds__(64) void knz_dec_block_headers_kernel(WalkBlocksArgs a) {
     const uint32_t b = blockIdx.x;
     if (b >= a.nblocks) return;
+    KnzWaveReader r;
+    r.init(a.stream, a.nbytes, a.blk_bit[b]);
+    const KnzBlkHdr h = knz_walk_block_header(a, r);
+    int32_t status = h.status;
+    const uint32_t chunkSize = (a.entropy == KNZ_E_ANS1 || a.entropy == KNZ_E_FPAQ) ? (4u << 20) : (uint32_t)KNZ_HUF_CHUNK;
+    if (status == 0 && (h.preLen + chunkSize - 1) / chunkSize > a.chunks_per_block) status = KNZ_ERR_BLOCK_SIZE;
+    if (threadIdx.x == 0) {
+        a.blk_pre_len[b] = h.preLen;
+        a.blk_mode[b] = (uint8_t)h.mode;
+        a.blk_skip[b] = (uint8_t)h.skipFlags;
+        a.blk_cksum[b] = h.ck;
+        a.blk_status[b] = status;
+        a.blk_end_bit[b] = r.tell();
+    }
+}
+
+// The walk of block b by threads 0..127 of a workgroup (sh.s_sync zeroed and a barrier passed). FUSED: the chunk positions
+// are consumed by decoder workgroups of the same launch as soon as they are stored.
+template <bool FUSED>
+__device__ __forceinline__ void knz_walk_block_body(const WalkBlocksArgs& a, const uint32_t b, KnzWalkShared& sh) {
+    uint8_t (&s_lut)[1 << KNZ_EXPG_WIN] = sh.s_lut;
+    uint32_t (&s_ring)[KNZ_WALK_RING] = sh.s_ring;
+    uint32_t (&s_sync)[4] = sh.s_sync;
     volatile uint32_t* vsync = s_sync;
-    if (threadIdx.x < 4) s_sync[threadIdx.x] = 0;
-    __syncthreads();
     const uint64_t ringOrigin = (a.blk_bit[b] >> 5) & ~(uint64_t)255;  // ring word r holds stream word ringOrigin + r (mod ring size)
     const bool ringOk = (((uintptr_t)a.stream) & 15) == 0;             // 16-byte loads; otherwise the serial parser runs
+    if (FUSED) wave_raise_priority();                 // the decoders of the same launch share the CU with this chain
     if (threadIdx.x >= 64) {
         // ---- feeder ---------------------------------------------------------------------------------------------------------
         if (!ringOk || a.entropy != KNZ_E_HUFFMAN) return;             // nothing to feed: the other walks read the stream directly
@@ -567,24 +641,11 @@ __global__ __launch_bounds__(128) void knz_dec_walk_blocks_kernel(WalkBlocksArgs
     // the block-local stream is its own bitstream in the reference (r = (read+7)>>3 bytes): reads past `end`
     // rounded up to a byte are an EOS panic there; checked below per chunk
     r.init(a.stream, a.nbytes, start);
-    int32_t status = 0;
-    uint32_t mode = 0, skipFlags = 0, preLen = a.given_len;
-    uint32_t entropy = a.entropy;
-    uint64_t ck = 0;
-    if (!a.payload_only) {
-        mode = r.read(8);
-        if (mode & 0x80) { entropy = KNZ_E_NONE; skipFlags = 0xFF; }   // copy block: no transform runs (device convention)
-        else if (mode & 0x10) skipFlags = r.read(8);
-        else skipFlags = ((mode << 4) | 0x0F) & 0xFF;
-        const uint32_t dataSize = 1 + ((mode >> 5) & 3);
-        preLen = r.read(8 * dataSize);
-        uint64_t maxLen = (uint64_t)a.block_size + a.block_size / 2;   // blockLength + blockLength/2 (:1893)
-        if (maxLen < 2048) maxLen = 2048;
-        if (maxLen > (1u << 30)) maxLen = 1u << 30;
-        if (preLen == 0 || preLen > maxLen) status = KNZ_ERR_BLOCK_SIZE;
-        if (a.checksum_bits == 32) ck = r.read(32);
-        else if (a.checksum_bits == 64) { ck = (uint64_t)r.read(32) << 32; ck |= r.read(32); }
-    }
+    const KnzBlkHdr bh = knz_walk_block_header(a, r);
+    int32_t status = bh.status;
+    const uint32_t mode = bh.mode, skipFlags = bh.skipFlags, preLen = bh.preLen, entropy = bh.entropy;
+    const uint64_t ck = bh.ck;
+    uint32_t published = 0;                           // chunk positions stored so far
     if (writer) {
         a.blk_pre_len[b] = preLen;
         a.blk_mode[b] = (uint8_t)mode;
@@ -607,7 +668,8 @@ __global__ __launch_bounds__(128) void knz_dec_walk_blocks_kernel(WalkBlocksArgs
         uint32_t filled = 0;                                               // last feeder progress seen
         for (uint32_t k = 0; k < nchunks && status == 0; k++) {
             const uint32_t sz = min(chunkSize, preLen - k * chunkSize);
-            if (writer) a.chunk_bit[(size_t)b * cpb + k] = pos;
+            if (writer) knz_publish64(&a.chunk_bit[(size_t)b * cpb + k], pos);
+            published = k + 1;
             if (entropy == KNZ_E_HUFFMAN && sz >= 32 && ringOk) {
                 KNZ_PROF_T(w0);
                 const uint64_t w0i = pos >> 5;
@@ -718,6 +780,58 @@ __global__ __launch_bounds__(128) void knz_dec_walk_blocks_kernel(WalkBlocksArgs
         }
         if (writer) a.blk_end_bit[b] = pos;
     } else if (writer) a.blk_end_bit[b] = r.tell();
-    if (writer) { a.blk_status[b] = status; vsync[2] = 1; }
+    if (FUSED) {
+        // a failed walk never reaches the remaining chunks: release their decoders. The status was preset by the header pass
+        // and the decoders may have put an error there already: only an error is stored.
+        if (status != 0) {
+            for (uint32_t k = published + threadIdx.x; k < cpb; k += 64) knz_publish64(&a.chunk_bit[(size_t)b * cpb + k], KNZ_CHUNK_ERR);
+            if (writer) a.blk_status[b] = status;
+        }
+        if (writer) vsync[2] = 1;
+    } else if (writer) { a.blk_status[b] = status; vsync[2] = 1; }
+}
+
+__global__ __launch_bounds__(128) void knz_dec_walk_blocks_kernel(WalkBlocksArgs a) {
+    __shared__ KnzWalkShared sh;
+    const uint32_t b = blockIdx.x;
+    if (b >= a.nblocks) return;
+    if (threadIdx.x < 4) sh.s_sync[threadIdx.x] = 0;
+    __syncthreads();
+    knz_walk_block_body<false>(a, b, sh);
+}
+
+// Walk and decode in ONE launch: workgroups [0, nblocks) are the walkers (dispatched first, 2 of their 4 waves leave at once),
+// workgroup nblocks + k * nblocks + b decodes chunk k of block b as soon as walker b has stored its position (chunk-major
+// order: the walkers of all blocks advance together at ~4 us per chunk, so the decoders become runnable in dispatch order).
+// chunk_bit is preset to KNZ_CHUNK_NOT_READY by the host. A decoder that gives up waiting hands its chunk to the serial
+// kernel that follows in the stream (never seen: the walkers are resident before the first decoder is dispatched).
+__global__ __launch_bounds__(256) void knz_huf_walk_decode_kernel(WalkBlocksArgs wa, HufDecArgs da, uint8_t* fallback) {
+    __shared__ union KnzWalkDecodeShared { KnzHufParShared d; KnzWalkShared w; } sh;
+    __shared__ uint64_t s_cbit;
+    const uint32_t nblocks = wa.nblocks;
+    if (blockIdx.x < nblocks) {
+        if (threadIdx.x < 4) sh.w.s_sync[threadIdx.x] = 0;
+        __syncthreads();
+        if (threadIdx.x >= 128) return;
+        knz_walk_block_body<true>(wa, blockIdx.x, sh.w);
+        return;
+    }
+    const uint32_t id = blockIdx.x - nblocks, cpb = da.chunks_per_block;
+    const uint32_t k = id / nblocks, b = id % nblocks;
+    const uint32_t slot = b * cpb + k;
+    if ((uint64_t)k * KNZ_HUF_CHUNK >= da.blk_pre_len[b] || da.blk_status[b] != 0) {   // lengths and status: header pass
+        if (threadIdx.x == 0) fallback[slot] = 0;
+        return;
+    }
+    if (threadIdx.x == 0) {
+        uint64_t v = knz_poll64(&da.chunk_bit[slot]);
+        for (uint32_t spins = 0; v == KNZ_CHUNK_NOT_READY && spins < (1u << 21); spins++) { wg_spin_pause(); v = knz_poll64(&da.chunk_bit[slot]); }
+        s_cbit = v;
+    }
+    __syncthreads();
+    const uint64_t cbit = s_cbit;
+    if (cbit == KNZ_CHUNK_ERR) { if (threadIdx.x == 0) fallback[slot] = 0; return; }
+    if (cbit == KNZ_CHUNK_NOT_READY) { if (threadIdx.x == 0) fallback[slot] = 1; return; }
+    knz_huf_decode_par_body(da, fallback, slot, cbit, sh.d);
 }
 

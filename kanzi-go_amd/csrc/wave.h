@@ -51,11 +51,21 @@ __device__ __forceinline__ void wave_sync_lds() {
 __device__ __forceinline__ void wave_spin_pause() { __builtin_amdgcn_s_sleep(1); }
 __device__ __forceinline__ void wg_fence_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 __device__ __forceinline__ void wg_fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// 64-bit words that are their own ready flag between workgroups of one launch (device-scope relaxed atomics: the store goes
+// to L2, the load bypasses the non-coherent caches); a longer sleep for polls that wait on another workgroup
+__device__ __forceinline__ void knz_publish64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t knz_poll64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wg_spin_pause() { __builtin_amdgcn_s_sleep(16); }
+__device__ __forceinline__ void wave_raise_priority() { __builtin_amdgcn_s_setprio(3); }
 #else
 // ------------------------------------------------------------------ emulator (tests only)
 inline void wave_spin_pause() { hipemu::spin_pause(); }
 inline void wg_fence_release() {}
 inline void wg_fence_acquire() {}
+inline void knz_publish64(uint64_t* p, uint64_t v) { *(volatile uint64_t*)p = v; }
+inline uint64_t knz_poll64(const uint64_t* p) { return *(const volatile uint64_t*)p; }
+inline void wg_spin_pause() { hipemu::spin_pause(); }
+inline void wave_raise_priority() {}
 inline uint32_t knz_mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 inline uint32_t wave_uniform(uint32_t v) { return v; }
 inline int lane_id() { return hipemu::lane(); }

@@ -389,6 +389,19 @@ def check_ans1_table_decoder(be):
         del os.environ["KNZ_ANS1_TABLE_DECODER"]
 
 
+def check_huffman_split_walk(be):
+    """The Huffman decoder has two forms: chunk walk and chunk decoders in one launch (default), or the walk as its own
+    launch before the decoders; KNZ_HUF_SPLIT_WALK forces the second."""
+    import os
+    os.environ["KNZ_HUF_SPLIT_WALK"] = "1"
+    try:
+        check_stream(be, "NONE", "HUFFMAN", 1 << 16, 3 * 65536 + 777)
+        check_stream(be, "NONE", "HUFFMAN", 4096, 4096 * 3 + 15)
+        check_block_batch(be, "NONE", "HUFFMAN", 1 << 16, 3, 12345)
+    finally:
+        del os.environ["KNZ_HUF_SPLIT_WALK"]
+
+
 def check_corrupt_streams(be, trials=12):
     """Bit flips in valid streams: the device decoder must come back (an error code or some output), never hang or touch
     memory outside its buffers, for every codec on the path. When the oracle decodes the damaged stream without an error,

@@ -79,6 +79,10 @@ def test_ans1_table_decoder(be):
     P.check_ans1_table_decoder(be)
 
 
+def test_huffman_split_walk(be):
+    P.check_huffman_split_walk(be)
+
+
 @pytest.mark.timeout(600)
 def test_corrupt_streams_come_back(be):
     P.check_corrupt_streams(be)
