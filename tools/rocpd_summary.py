@@ -13,8 +13,7 @@ def main():
         short = name.split("(")[0][:90]
         lines.append(f"| {short} | {calls} | {total:.1f} | {avg:.1f} | {pct:.2f} |")
     try:
-        rows = list(cur.execute("select k.name, p.name, sum(e.value), count(*) from pmc_events e join pmc_info p on e.pmc_id=p.id "
-                                "join kernels k on e.event_id=k.id group by k.name, p.name"))
+        rows = list(cur.execute("select name, counter_name, sum(counter_value), count(distinct dispatch_id) from pmc_events group by name, counter_name"))
     except Exception:
         rows = []
     if rows:
