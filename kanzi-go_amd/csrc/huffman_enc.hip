@@ -248,26 +248,44 @@ __global__ __launch_bounds__(64) void knz_huf_lengths_kernel(HufEncArgs a) {
     const uint32_t chunk = blockIdx.x * 64 + lane;
     const int n = chunk < a.nchunks ? (int)a.st_count[chunk] : 0;
     uint16_t* d = s_d + lane;
-    for (int i = 0; i < n; i++) d[i * 64] = a.st_freq[knz_huf_st(chunk, i)];
+    {   // the sorted frequencies, 8 loads in flight per lane (one load per trip left the chain waiting on HBM 256 times)
+        const int nmax = (int)wave_reduce_max((uint32_t)n);
+        const uint32_t cc = chunk < a.nchunks ? chunk : 0u;
+        for (int i0 = 0; i0 < nmax; i0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = i0 + u < n ? a.st_freq[knz_huf_st(cc, i0 + u)] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (i0 + u < n) d[(i0 + u) * 64] = (uint16_t)v[u];
+        }
+    }
     if (n < 2) {                                              // 0: nothing, 1: the single symbol gets length 1 (:156-158)
         if (n == 1) { a.st_len[knz_huf_st(chunk, 0)] = 1; a.st_maxlen[chunk] = 1; }
         return;
     }
-    // phase 1 (:328-356)
-    for (int s = 0, r = 0, t = 0; t < n - 1; t++) {
-        uint32_t sum = 0;
-        for (int i = 0; i < 2; i++) {
-            if (s >= n || (r < t && d[r * 64] < d[s * 64])) {
-                sum += d[r * 64];
-                d[r * 64] = (uint16_t)t;
-                r++;
-                continue;
+    // phase 1 (:328-356). The values at the two read cursors are kept in registers (vs = d[s], vr = d[r]) and re-read only
+    // when a cursor moves: one LDS round trip per pick on the chain instead of one per access.
+    {
+        int s = 0, r = 0;
+        uint32_t vs = d[0], vr = 0;
+        for (int t = 0; t < n - 1; t++) {
+            uint32_t sum = 0;
+            for (int i = 0; i < 2; i++) {
+                if (s >= n || (r < t && vr < vs)) {
+                    sum += vr;
+                    d[r * 64] = (uint16_t)t;
+                    r++;
+                    vr = d[r * 64];                           // (r == t: not stored yet, replaced below)
+                    continue;
+                }
+                sum += vs;
+                if (s > t) d[s * 64] = 0;
+                s++;
+                vs = d[min(s, n - 1) * 64];
             }
-            sum += d[s * 64];
-            if (s > t) d[s * 64] = 0;
-            s++;
+            d[t * 64] = (uint16_t)sum;
+            if (r == t) vr = sum & 0xFFFFu;
         }
-        d[t * 64] = (uint16_t)sum;
     }
     // phase 2 (:359-385)
     int levelTop = n - 2, depth = 1, i = n, totalNodesAtLevel = 2;
