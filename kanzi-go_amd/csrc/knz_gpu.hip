@@ -10,6 +10,7 @@
 #include "transforms.hip"
 #include "bwt.hip"
 #include "lz.hip"
+#include "srt_lzp.hip"
 #include "xxhash.hip"
 #include "prims.h"
 #include "layout.hip"
@@ -85,7 +86,7 @@ uint32_t knz_build_stream_header(const knz_cfg& cfg, int64_t inputSize, uint32_t
 static bool transform_on_device(uint64_t t) {                    // packed sequence
     for (int s = 42; s >= 0; s -= 6) {
         const uint32_t id = (uint32_t)((t >> s) & 63);
-        if (!(id == KNZ_T_NONE || id == KNZ_T_BWT || id == KNZ_T_RANK || id == KNZ_T_MTFT || id == KNZ_T_ZRLT || id == KNZ_T_LZ || id == KNZ_T_LZX)) return false;
+        if (!(id == KNZ_T_NONE || id == KNZ_T_BWT || id == KNZ_T_RANK || id == KNZ_T_MTFT || id == KNZ_T_ZRLT || id == KNZ_T_LZ || id == KNZ_T_LZX || id == KNZ_T_SRT || id == KNZ_T_LZP)) return false;
     }
     return true;
 }
@@ -102,13 +103,14 @@ static uint32_t seq_len(uint64_t t) {
 }
 
 extern "C" uint32_t knz_max_encoded_len(uint64_t transform, uint32_t n) {
-    // Sequence.go:189-205 over the hot-path transforms (BWT/SBRT: n+33, LZ: n+16 | n+n/64)
+    // Sequence.go:189-205 over the hot-path transforms (BWT/SBRT: n+33, LZ/LZX/LZP: n+16 | n+n/64, SRT: n+1024)
     uint64_t req = n;
     for (int s = 42; s >= 0; s -= 6) {
         uint32_t t = (uint32_t)((transform >> s) & 63);
         uint64_t nxt = req;
         if (t == KNZ_T_BWT || t == KNZ_T_RANK || t == KNZ_T_MTFT) nxt = req + 33;
-        else if (t == KNZ_T_LZ || t == KNZ_T_LZX) nxt = req <= 1024 ? req + 16 : req + req / 64;
+        else if (t == KNZ_T_LZ || t == KNZ_T_LZX || t == KNZ_T_LZP) nxt = req <= 1024 ? req + 16 : req + req / 64;
+        else if (t == KNZ_T_SRT) nxt = req + 4 * 256;
         if (nxt > req) req = nxt;
     }
     return (uint32_t)std::min<uint64_t>(req, 0xFFFFFFFFu);

@@ -17,7 +17,7 @@
 namespace knzo {
 
 // transform ids (Factory.go:31-53)
-enum : uint64_t { T_NONE = 0, T_BWT = 1, T_LZ = 3, T_ZRLT = 6, T_MTFT = 7, T_RANK = 8, T_LZX = 16 };
+enum : uint64_t { T_NONE = 0, T_BWT = 1, T_LZ = 3, T_ZRLT = 6, T_MTFT = 7, T_RANK = 8, T_SRT = 13, T_LZP = 14, T_LZX = 16 };
 // entropy ids (EntropyCodecFactory.go:26-42)
 enum : uint32_t { E_NONE = 0, E_HUFFMAN = 1, E_FPAQ = 2, E_ANS0 = 5, E_ANS1 = 8 };
 
@@ -74,12 +74,13 @@ static inline uint64_t xxhash64(const uint8_t* data, size_t len, uint64_t seed) 
 
 // ---- single transform dispatch (Factory.go:97-185 newToken) ---------------------------------
 static inline bool transformSupported(uint64_t t) {
-    return t == T_NONE || t == T_BWT || t == T_LZ || t == T_LZX || t == T_ZRLT || t == T_MTFT || t == T_RANK;
+    return t == T_NONE || t == T_BWT || t == T_LZ || t == T_LZX || t == T_ZRLT || t == T_MTFT || t == T_RANK || t == T_SRT || t == T_LZP;
 }
 static inline size_t transformMaxEncodedLen(uint64_t t, size_t n) {
     switch (t) {
         case T_BWT: case T_RANK: case T_MTFT: return n + BWT_MAX_HEADER_SIZE;
-        case T_LZ: case T_LZX: return lzMaxEncodedLen(n);
+        case T_LZ: case T_LZX: case T_LZP: return lzMaxEncodedLen(n);
+        case T_SRT: return n + SRT_MAX_HEADER_SIZE;
         default: return n;
     }
 }
@@ -96,6 +97,8 @@ static inline size_t transformForward1(uint64_t t, const uint8_t* src, size_t n,
         case T_ZRLT: return zrltForward(src, n, dst, cap);
         case T_MTFT: return SBRT(1).forward(src, n, dst, cap);
         case T_RANK: return SBRT(2).forward(src, n, dst, cap);
+        case T_SRT: return srtForward(src, n, dst, cap);
+        case T_LZP: return lzpForward(src, n, dst, cap);
         default: throw KnzError(ERR_CREATE_CODEC, "Unknown transform type");
     }
 }
@@ -110,6 +113,8 @@ static inline size_t transformInverse1(uint64_t t, const uint8_t* src, size_t n,
         case T_ZRLT: return zrltInverse(src, n, dst, cap);
         case T_MTFT: return SBRT(1).inverse(src, n, dst, cap);
         case T_RANK: return SBRT(2).inverse(src, n, dst, cap);
+        case T_SRT: return srtInverse(src, n, dst, cap);
+        case T_LZP: return lzpInverse(src, n, dst, cap);
         default: throw KnzError(ERR_INVALID_CODEC, "Unknown transform type");
     }
 }

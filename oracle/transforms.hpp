@@ -11,6 +11,8 @@
 //   v2/transform/ZRLT.go:58-137 Forward ; :142-225 Inverse
 //   v2/transform/LZCodec.go:193-236 emitLengthLZ/readLengthLZ ; :238-246 hash ; :249-591 Forward (LZ and LZX)
 //     :593-607 findMatchLZX ; :621-778 inverseV6 ; :935-941 MaxEncodedLen
+//   v2/transform/LZCodec.go:982-1088 LZPCodec.Forward ; :1091-1190 Inverse ; :1192-1207 findMatch ; :1210-1216 MaxEncodedLen
+//   v2/transform/SRT.go:49-132 Forward ; :134-167 preprocess ; :172-259 Inverse ; :261-275 encodeHeader ; :277-312 decodeHeader
 #pragma once
 #include "entropy_utils.hpp"
 
@@ -626,6 +628,236 @@ static inline size_t lzInverse(const uint8_t* src, size_t n, uint8_t* dst, size_
     }
     if (srcIdx != srcEnd + 13) throw KnzError(ERR_PROCESS_BLOCK, "LZCodec inverse transform failed");
     return (size_t)dstIdx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LZP (LZCodec.go:943-1216). Hash of the last 4 bytes predicts one position; a prediction that holds for >= 64 bytes is
+// replaced by 0xFC + length, a literal 0xFC whose context had a prediction is escaped with 0xFF.
+static const int LZP_HASH_LOG = 16;
+static const uint32_t LZP_HASH_SEED = 0x7FEB352D;
+static const int LZP_MIN_MATCH64 = 64;
+static const int LZP_MATCH_FLAG = 0xFC;
+static const int LZP_MIN_BLOCK_LENGTH = 128;
+
+static inline size_t lzpForward(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap) {   // :982-1088
+    if (n == 0 || dstCap == 0) return 0;
+    const int count = (int)n;
+    if (dstCap < lzMaxEncodedLen(n)) throw SkipTransform("Output buffer is too small");
+    if (count < LZP_MIN_BLOCK_LENGTH) throw SkipTransform("Block too small, skip");
+    const int srcEnd = count, dstEnd = count - (count >> 6);
+    std::vector<int32_t> hashes((size_t)1 << LZP_HASH_LOG, 0);
+    memcpy(dst, src, 4);
+    uint32_t ctx = le32(src);
+    int srcIdx = 4, dstIdx = 4;
+    while (srcIdx < srcEnd - LZP_MIN_MATCH64 && dstIdx < dstEnd) {
+        const uint32_t h = (LZP_HASH_SEED * ctx) >> (32 - LZP_HASH_LOG);
+        const int ref = hashes[h];
+        hashes[h] = srcIdx;
+        int bestLen = 0;
+        if (ref != 0 && le64(src + srcIdx + LZP_MIN_MATCH64 - 8) == le64(src + ref + LZP_MIN_MATCH64 - 8))
+            bestLen = lzFindMatch(src, srcIdx, ref, srcEnd - srcIdx);   // :1192-1207 is the same 8-byte stride loop
+        if (bestLen < LZP_MIN_MATCH64) {
+            const uint32_t val = src[srcIdx];
+            ctx = (ctx << 8) | val;
+            dst[dstIdx++] = src[srcIdx++];
+            if (ref != 0 && val == (uint32_t)LZP_MATCH_FLAG) dst[dstIdx++] = 0xFF;
+            continue;
+        }
+        srcIdx += bestLen;
+        ctx = le32(src + srcIdx - 4);
+        dst[dstIdx++] = (uint8_t)LZP_MATCH_FLAG;
+        bestLen -= LZP_MIN_MATCH64;
+        while (bestLen >= 254) {
+            bestLen -= 254;
+            dst[dstIdx++] = 0xFE;
+            if (dstIdx >= dstEnd) break;
+        }
+        dst[dstIdx++] = (uint8_t)bestLen;
+    }
+    while (srcIdx < srcEnd && dstIdx < dstEnd) {
+        const uint32_t h = (LZP_HASH_SEED * ctx) >> (32 - LZP_HASH_LOG);
+        const int ref = hashes[h];
+        hashes[h] = srcIdx;
+        const uint32_t val = src[srcIdx];
+        ctx = (ctx << 8) | val;
+        dst[dstIdx++] = src[srcIdx++];
+        if (ref != 0 && val == (uint32_t)LZP_MATCH_FLAG) dst[dstIdx++] = 0xFF;
+    }
+    if (srcIdx != count || dstIdx >= dstEnd) throw SkipTransform("LZP forward transform skip: output buffer too small");
+    return (size_t)dstIdx;
+}
+
+static inline size_t lzpInverse(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap) {   // :1091-1190
+    if (n == 0 || dstCap == 0) return 0;
+    if (n < 4) throw KnzError(ERR_PROCESS_BLOCK, "LZP inverse transform failed: block too small");
+    if (dstCap < 4) throw KnzError(ERR_PROCESS_BLOCK, "index out of range");
+    std::vector<int32_t> hashes((size_t)1 << LZP_HASH_LOG, 0);
+    const int64_t srcEnd = (int64_t)n, dstEnd = (int64_t)dstCap;
+    memcpy(dst, src, 4);
+    uint32_t ctx = le32(dst);
+    int64_t srcIdx = 4, dstIdx = 4;
+    bool res = true;
+    const int minMatch = LZP_MIN_MATCH64;                    // bitstream version >= 4
+    auto needS = [&](int64_t i) { if (i < 0 || i >= srcEnd) throw KnzError(ERR_PROCESS_BLOCK, "index out of range"); };
+    auto needD = [&](int64_t i) { if (i < 0 || i >= dstEnd) throw KnzError(ERR_PROCESS_BLOCK, "index out of range"); };
+    while (srcIdx < srcEnd) {
+        const uint32_t h = (LZP_HASH_SEED * ctx) >> (32 - LZP_HASH_LOG);
+        const int64_t ref = hashes[h];
+        hashes[h] = (int32_t)dstIdx;
+        if (src[srcIdx] != LZP_MATCH_FLAG || ref == 0) {
+            needD(dstIdx);
+            dst[dstIdx] = src[srcIdx];
+            ctx = (ctx << 8) | dst[dstIdx];
+            srcIdx++; dstIdx++;
+            continue;
+        }
+        srcIdx++;
+        needS(srcIdx);
+        if (src[srcIdx] == 0xFF) {
+            needD(dstIdx);
+            dst[dstIdx] = (uint8_t)LZP_MATCH_FLAG;
+            ctx = (ctx << 8) | (uint32_t)LZP_MATCH_FLAG;
+            srcIdx++; dstIdx++;
+            continue;
+        }
+        int64_t mLen = minMatch;
+        if (src[srcIdx] == 0xFE) {
+            while (srcIdx < srcEnd && src[srcIdx] == 0xFE) { srcIdx++; mLen += 254; }
+            if (srcIdx >= srcEnd) { res = false; break; }
+        }
+        mLen += src[srcIdx++];
+        const int64_t mEnd = dstIdx + mLen;
+        if (mEnd > dstEnd) { res = false; break; }
+        for (int64_t i = 0; i < mLen; i++) dst[dstIdx + i] = dst[ref + i];   // (copy() when the ranges are apart: same bytes)
+        dstIdx += mLen;
+        ctx = le32(dst + dstIdx - 4);
+    }
+    if (!res || srcIdx != srcEnd) throw KnzError(ERR_PROCESS_BLOCK, "LZP inverse transform failed: output buffer too small");
+    return (size_t)dstIdx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SRT, sorted rank transform (SRT.go). Move-to-front ranks of the run heads, written per symbol (bucket of symbol c =
+// the ranks of c's occurrences, buckets ordered by decreasing frequency), behind a header of 256 varint frequencies.
+static const int SRT_MAX_HEADER_SIZE = 4 * 256;
+
+static inline int srtPreprocess(const int32_t* freqs, uint8_t* symbols) {   // :134-167 (shell sort, decreasing frequency, ties by symbol)
+    int nbSymbols = 0;
+    for (int i = 0; i < 256; i++) if (freqs[i] != 0) symbols[nbSymbols++] = (uint8_t)i;
+    int h = 4;
+    while (h < nbSymbols) h = h * 3 + 1;
+    for (;;) {
+        h /= 3;
+        for (int i = h; i < nbSymbols; i++) {
+            const uint8_t t = symbols[i];
+            int b;
+            for (b = i - h; b >= 0 && (freqs[symbols[b]] < freqs[t] || (t < symbols[b] && freqs[t] == freqs[symbols[b]])); b -= h)
+                symbols[b + h] = symbols[b];
+            symbols[b + h] = t;
+        }
+        if (h == 1) break;
+    }
+    return nbSymbols;
+}
+
+static inline size_t srtForward(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap) {   // :49-132
+    if (n == 0 || dstCap == 0) return 0;
+    if (dstCap < n + SRT_MAX_HEADER_SIZE) throw SkipTransform("Output buffer is too small");
+    const int count = (int)n;
+    uint8_t s2r[256] = {0}, r2s[256] = {0};
+    int32_t freqs[256] = {0};
+    for (int i = 0, b = 0; i < count;) {
+        const uint8_t c = src[i];
+        if (freqs[c] == 0) { r2s[b] = c; s2r[c] = (uint8_t)b; b++; }
+        int j = i + 1;
+        while (j < count && src[j] == c) j++;
+        freqs[c] += j - i;
+        i = j;
+    }
+    uint8_t symbols[256] = {0};
+    const int nbSymbols = srtPreprocess(freqs, symbols);
+    int buckets[256] = {0};
+    for (int i = 0, pos = 0; i < nbSymbols; i++) { const uint8_t c = symbols[i]; buckets[c] = pos; pos += freqs[c]; }
+    int hs = 0;
+    for (int i = 0; i < 256; i++) {                           // encodeHeader :261-275
+        int32_t f = freqs[i];
+        while (f >= 128) { dst[hs++] = (uint8_t)(0x80 | (f & 0x7F)); f >>= 7; }
+        dst[hs++] = (uint8_t)f;
+    }
+    uint8_t* out = dst + hs;
+    for (int i = 0; i < count;) {
+        const uint8_t c = src[i];
+        uint8_t r = s2r[c];
+        int p = buckets[c];
+        out[p++] = r;
+        if (r > 0) {
+            for (;;) {
+                const uint8_t t = r2s[r - 1];
+                r2s[r] = t; s2r[t] = r;
+                if (r == 1) break;
+                r--;
+            }
+            r2s[0] = c; s2r[c] = 0;
+        }
+        i++;
+        while (i < count && src[i] == c) { out[p++] = 0; i++; }
+        buckets[c] = p;
+    }
+    return (size_t)(count + hs);
+}
+
+static inline size_t srtInverse(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap) {   // :172-259
+    if (n == 0 || dstCap == 0) return 0;
+    int32_t freqs[256];
+    size_t hs = 0;
+    auto rd = [&]() -> int32_t { if (hs >= n) throw KnzError(ERR_PROCESS_BLOCK, "index out of range"); return src[hs++]; };
+    for (int i = 0; i < 256; i++) {                           // decodeHeader :277-312
+        int32_t val = rd();
+        if (val < 128) { freqs[i] = val; continue; }
+        int32_t res = val & 0x7F;
+        val = rd(); res |= (val & 0x7F) << 7;
+        if (val >= 128) {
+            val = rd(); res |= (val & 0x7F) << 14;
+            if (val >= 128) { val = rd(); res |= (val & 0x7F) << 21; }
+        }
+        freqs[i] = res;
+    }
+    const uint8_t* in = src + hs;
+    const int64_t len = (int64_t)(n - hs);
+    if (len > (int64_t)dstCap) throw KnzError(ERR_PROCESS_BLOCK, "SRT inverse transform failed: invalid data");
+    uint8_t symbols[256] = {0};
+    int nbSymbols = srtPreprocess(freqs, symbols);
+    int64_t buckets[256] = {0}, bucketEnds[256] = {0};
+    uint8_t r2s[256] = {0};
+    int64_t bucketPos = 0;
+    for (int i = 0; i < nbSymbols; i++) {
+        const uint8_t c = symbols[i];
+        if (bucketPos < 0 || bucketPos > len) throw KnzError(ERR_PROCESS_BLOCK, "SRT inverse transform failed: invalid data");
+        if (bucketPos >= len) throw KnzError(ERR_PROCESS_BLOCK, "index out of range");
+        r2s[in[bucketPos]] = c;
+        buckets[c] = bucketPos + 1;
+        bucketPos += freqs[c];
+        bucketEnds[c] = bucketPos;
+    }
+    uint8_t c = r2s[0];
+    for (size_t i = 0; i < dstCap; i++) {                     // (the reference walks all of dst; only the first `len` bytes are returned)
+        dst[i] = c;
+        if (buckets[c] < bucketEnds[c]) {
+            if (buckets[c] >= len) throw KnzError(ERR_PROCESS_BLOCK, "index out of range");
+            const uint8_t r = in[buckets[c]];
+            buckets[c]++;
+            if (r == 0) continue;
+            for (int s = 0; s < (int)r; s++) r2s[s] = r2s[s + 1];
+            r2s[r] = c;
+            c = r2s[0];
+        } else {
+            if (nbSymbols == 1) continue;
+            nbSymbols--;
+            for (int s = 0; s < nbSymbols; s++) r2s[s] = r2s[s + 1];
+            c = r2s[0];
+        }
+    }
+    return (size_t)len;
 }
 
 } // namespace knzo

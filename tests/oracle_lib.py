@@ -16,8 +16,9 @@ _LIB = None
 
 # transform / entropy ids (v2/transform/Factory.go:31-53, v2/entropy/EntropyCodecFactory.go:26-42)
 T_NONE, T_BWT, T_LZ, T_ZRLT, T_MTFT, T_RANK, T_LZX = 0, 1, 3, 6, 7, 8, 16
+T_SRT, T_LZP = 13, 14
 E_NONE, E_HUFFMAN, E_FPAQ, E_ANS0, E_ANS1 = 0, 1, 2, 5, 8
-_TNAMES = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "LZX": 16}
+_TNAMES = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "LZP": 14, "LZX": 16}
 _ENAMES = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5, "ANS1": 8}
 
 
@@ -120,7 +121,7 @@ def entropy_decode(etype, payload, n):
 def transform_forward(t, data):
     """-> bytes or None when the transform declines (Forward error => skipped)."""
     a, p = _u8(data)
-    cap = len(a) + len(a) // 8 + 64
+    cap = max(len(a) + len(a) // 8 + 64, int(lib().knzo_max_encoded_len(t << 42, len(a))) + 64)
     out = np.zeros(cap, dtype=np.uint8)
     n = C.c_uint64()
     rc = lib().knzo_transform_forward(t, p, len(a), out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n))

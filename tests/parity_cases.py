@@ -234,10 +234,15 @@ def _transform_inputs(zrlt=False):
     yield "zeros20000", bytes(20000)
     yield "fefe", bytes([0xFE, 0xFF, 0, 0, 0xFF, 1, 0]) * 300 + bytes(900)
     yield "rand30000", rng.integers(0, 256, 30000, dtype=np.uint8).tobytes()
+    # LZP: 0xFC flag bytes with and without a prediction, predictions that hold for 64.. / 254+64.. bytes, a repeat at the very end
+    fc = bytearray(rng.integers(0, 256, 3000, dtype=np.uint8).tobytes())
+    fc[100:110] = bytes([0xFC]) * 10
+    rep = bytes(fc[200:200 + 700])
+    yield "fcrep", bytes(fc) + rep + bytes([0xFC, 1, 2, 0xFC]) + rep[:90] + bytes([0xFC]) * 70 + rep[:300] + bytes(fc[:64])
     yield "binary", (rng.integers(0, 256, 50000, dtype=np.uint8) & rng.integers(0, 256, 50000, dtype=np.uint8) & rng.integers(0, 256, 50000, dtype=np.uint8)).tobytes()
 
 
-_TID = {"BWT": 1, "ZRLT": 6, "MTFT": 7, "RANK": 8, "LZ": 3, "LZX": 16}
+_TID = {"BWT": 1, "ZRLT": 6, "MTFT": 7, "RANK": 8, "LZ": 3, "LZX": 16, "SRT": 13, "LZP": 14}
 
 
 def check_transform(be, tname, max_len=1 << 30):

@@ -201,6 +201,33 @@ def test_rank_and_mtf_known_vectors():
     assert O.transform_forward(O.T_RANK, bytes([3, 3, 3, 0])) == bytes([3, 0, 0, 1])
 
 
+def test_srt_known_vector():
+    # SRT.go:49-132 by hand for "AAB" + "A": header = 256 one-byte varints (freq[A] = 3, freq[B] = 1), buckets ordered by
+    # decreasing frequency (A: 3 entries, then B: 1). Ranks: A is the first symbol seen (rank 0), its run partner 0; B is the
+    # second symbol seen (rank 1, moves to front); the last A is then at rank 1.
+    hdr = bytearray(256)
+    hdr[65], hdr[66] = 3, 1
+    assert O.transform_forward(O.T_SRT, b"AABA") == bytes(hdr) + bytes([0, 0, 1, 1])
+    # a frequency >= 128 takes two header bytes (:261-275)
+    f = O.transform_forward(O.T_SRT, b"C" * 300)
+    hdr = bytearray(256)
+    hdr[67:68] = bytes([0x80 | (300 & 0x7F), 300 >> 7])
+    assert f == bytes(hdr) + bytes(300)
+    assert O.transform_inverse(O.T_SRT, f, 300 + 512) == b"C" * 300
+
+
+def test_lzp_known_vector():
+    # LZCodec.go:982-1088 by hand: 0..99 twice. The context is the little-endian load of bytes 0..3 at position 4 and turns into
+    # "last four bytes, big-endian" once four literals have gone through it, so position 8 is the first whose context (4,5,6,7)
+    # comes back in the second copy (position 108); the prediction holds for the 88 bytes that the 8-byte stride compare covers
+    # (92 remain), i.e. flag 0xFC + (88 - 64); the last four bytes are literals.
+    data = bytes(range(100)) * 2
+    assert O.transform_forward(O.T_LZP, data) == data[:108] + bytes([0xFC, 24]) + data[196:]
+    assert O.transform_inverse(O.T_LZP, data[:108] + bytes([0xFC, 24]) + data[196:], 200 + 512) == data
+    # blocks under 128 bytes are declined (:994-996)
+    assert O.transform_forward(O.T_LZP, bytes(range(100))) is None
+
+
 def test_ans1_two_byte_tail_chunk_is_an_error():
     # order-1 chunk of 2 or 3 bytes indexes block[-1] in Go -> panic -> ERR_PROCESS_BLOCK (13)
     data = bytes([7]) * ((4 << 20) + 2)
@@ -273,7 +300,7 @@ def _transform_cases(zrlt=False):
         yield bytes(out[:1024])
 
 
-@pytest.mark.parametrize("t", [O.T_NONE, O.T_LZ, O.T_LZX, O.T_ZRLT, O.T_RANK, O.T_MTFT, O.T_BWT])
+@pytest.mark.parametrize("t", [O.T_NONE, O.T_LZ, O.T_LZX, O.T_ZRLT, O.T_RANK, O.T_MTFT, O.T_BWT, O.T_SRT, O.T_LZP])
 def test_transform_roundtrip_reference_shapes(t):
     applied = 0
     for data in _transform_cases(zrlt=(t == O.T_ZRLT)):
@@ -282,7 +309,7 @@ def test_transform_roundtrip_reference_shapes(t):
             continue
         applied += 1
         assert O.transform_inverse(t, f, len(data) + 512) == data
-    assert applied >= 10
+    assert applied >= (4 if t == O.T_LZP else 10)
 
 
 def test_lz_specific_patterns():

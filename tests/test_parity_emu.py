@@ -33,6 +33,7 @@ def test_entropy_objects_bit_exact(be, etype, sched, monkeypatch):
     ("BWT+RANK+ZRLT", "ANS1", 1024, 1000), ("BWT+RANK+ZRLT", "ANS1", 1024, 12),
     ("NONE", "FPAQ", 1 << 16, 300000), ("NONE", "FPAQ", 1024, 1000), ("NONE", "FPAQ", 1024, 10), ("BWT+RANK+ZRLT", "FPAQ", 1 << 13, 20000),
     ("LZ", "ANS0", 1 << 16, 300000), ("LZ", "HUFFMAN", 1 << 18, 300000), ("LZX", "HUFFMAN", 1 << 16, 150000), ("LZ", "ANS0", 1024, 1000), ("LZ", "ANS0", 1024, 20),
+    ("BWT+SRT+ZRLT", "ANS0", 1 << 14, 40000), ("LZP", "HUFFMAN", 1 << 16, 200000), ("SRT", "NONE", 1024, 1000), ("LZP+SRT", "ANS0", 1 << 15, 70000),
 ])
 def test_stream_bit_exact(be, cfg):
     P.check_stream(be, *cfg)
@@ -56,7 +57,7 @@ def test_multi_gpu_assemble(be, ranks):
     P.check_assemble(be, "ANS0", 1 << 16, 3 * (1 << 16) + 5, ranks)
 
 
-@pytest.mark.parametrize("tname", ["ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX"])
+@pytest.mark.parametrize("tname", ["ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX", "SRT", "LZP"])
 def test_transform_objects_bit_exact(be, tname):
     # the register-resident SBRT list uses ~12 cross-lane operations per byte: keep the emulated inputs small
     P.check_transform(be, tname, max_len=4096 if tname in ("RANK", "MTFT") else 1 << 30)

@@ -33,7 +33,8 @@ def test_entropy_objects_bit_exact(be, etype):
     ("NONE", "FPAQ", 1 << 16, 300000), ("NONE", "FPAQ", 1024, 1000), ("NONE", "FPAQ", 1024, 10), ("BWT+RANK+ZRLT", "FPAQ", 1 << 16, 200000),
     ("NONE", "FPAQ", 8 << 20, (8 << 20) + 12345),     # crosses the 4 MiB sub-chunk boundary: coder state persists (FPAQCodec.go:162-168)
     ("LZ", "ANS0", 1 << 16, 300000), ("LZ", "HUFFMAN", 1 << 18, 300000), ("LZX", "HUFFMAN", 1 << 16, 150000), ("LZ", "ANS0", 1024, 1000),
-    ("LZ", "ANS0", 1024, 20), ("LZ", "ANS0", 4 << 20, (4 << 20) + 600000),      # 4 MiB block: 24-bit window (LZCodec.go:289-296)
+    ("LZ", "ANS0", 1024, 20),
+    ("BWT+SRT+ZRLT", "ANS0", 1 << 14, 40000), ("LZP", "HUFFMAN", 1 << 16, 200000), ("SRT", "NONE", 1024, 1000), ("LZP+SRT", "ANS0", 1 << 15, 70000), ("LZ", "ANS0", 4 << 20, (4 << 20) + 600000),      # 4 MiB block: 24-bit window (LZCodec.go:289-296)
 ])
 def test_stream_bit_exact(be, cfg):
     P.check_stream(be, *cfg)
@@ -91,7 +92,7 @@ def test_stress_inputs(be):
     P.check_stream(be, "NONE", "HUFFMAN", 1 << 20, len(data))
 
 
-@pytest.mark.parametrize("tname", ["ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX"])
+@pytest.mark.parametrize("tname", ["ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX", "SRT", "LZP"])
 def test_transform_objects_bit_exact(be, tname):
     P.check_transform(be, tname)
 
