@@ -252,33 +252,32 @@ __global__ __launch_bounds__(64) void knz_ans0_decode_kernel(Ans0DecArgs a) {
     __shared__ uint32_t s_sym[KNZ_ANS0_DEC_CHUNKS][256];      // freq | cumFreq << 16
     __shared__ uint16_t s_pay[KNZ_ANS0_DEC_CHUNKS][256];       // renormalisation words of each chunk, ring
     __shared__ uint8_t s_ob[KNZ_ANS0_DEC_CHUNKS][256];         // decoded bytes of each chunk, 64 steps at a time
-    __shared__ uint16_t s_freq[256];
-    __shared__ uint8_t s_alpha[256];
+    __shared__ uint16_t s_freqs[KNZ_ANS0_DEC_CHUNKS][256];
+    __shared__ uint8_t s_alphas[KNZ_ANS0_DEC_CHUNKS][256];
     __shared__ uint32_t s_state[KNZ_ANS0_DEC_CHUNKS][4];
     __shared__ uint64_t s_paybit[KNZ_ANS0_DEC_CHUNKS];
     __shared__ int s_mode[KNZ_ANS0_DEC_CHUNKS];               // 0 absent, 1 raw, 2 single symbol, 3 rANS, -1 error
-    __shared__ int s_cnt;
 
     const int lane = threadIdx.x;
     const uint32_t cpb = a.chunks_per_block;
     const uint64_t limit = a.nbytes << 3;
 
-    for (int cg = 0; cg < KNZ_ANS0_DEC_CHUNKS; cg++) {
+    // ---- the 8 chunk headers, one lane each (the parse is a serial bit walk: 8 in flight instead of 8 in a row) ------------
+    for (int i = lane; i < KNZ_ANS0_DEC_CHUNKS * 256; i += 64) (&s_freqs[0][0])[i] = 0;
+    wave_sync();
+    if (lane < KNZ_ANS0_DEC_CHUNKS) {
+        const int cg = lane;
+        uint16_t* s_freq = s_freqs[cg];
+        uint8_t* s_alpha = s_alphas[cg];
         const uint32_t slotId = blockIdx.x * KNZ_ANS0_DEC_CHUNKS + cg;
         int mode = 0;
-        uint32_t n = 0, b = 0, k = 0, preLen = 0;
         if (slotId < a.nslots) {
-            b = slotId / cpb; k = slotId % cpb;
-            preLen = a.blk_pre_len[b];
-            if (a.blk_status[b] == 0 && (uint64_t)k * KNZ_ANS_CHUNK < preLen) {
-                n = min((uint32_t)KNZ_ANS_CHUNK, preLen - k * KNZ_ANS_CHUNK);
-                mode = ((a.blk_mode[b] & 0x80) || preLen <= 32) ? 1 : 3;
-            }
+            const uint32_t b = slotId / cpb, k = slotId % cpb;
+            const uint32_t preLen = a.blk_pre_len[b];
+            if (a.blk_status[b] == 0 && (uint64_t)k * KNZ_ANS_CHUNK < preLen) mode = ((a.blk_mode[b] & 0x80) || preLen <= 32) ? 1 : 3;
         }
         if (mode == 3) {
-            for (int i = lane; i < 256; i += 64) s_freq[i] = 0;
-            wave_sync();
-            if (lane == 0) {                                      // decodeHeader :605-710
+            {                                                      // decodeHeader :605-710
                 KnzStreamReader r;
                 r.init(a.stream, a.nbytes, a.chunk_bit[slotId]);
                 const uint32_t lr = 8 + r.read(3);
@@ -327,11 +326,24 @@ __global__ __launch_bounds__(64) void knz_ans0_decode_kernel(Ans0DecArgs a) {
                         }
                     }
                 }
-                s_cnt = count;
-                s_mode[cg] = m;
+                mode = m;
             }
-            wave_sync();
-            mode = s_mode[cg];
+        }
+        s_mode[cg] = mode;
+    }
+    wave_sync();
+
+    for (int cg = 0; cg < KNZ_ANS0_DEC_CHUNKS; cg++) {
+        const uint16_t* s_freq = s_freqs[cg];
+        const uint8_t* s_alpha = s_alphas[cg];
+        const uint32_t slotId = blockIdx.x * KNZ_ANS0_DEC_CHUNKS + cg;
+        const int mode = s_mode[cg];
+        uint32_t n = 0, b = 0, k = 0;
+        if (mode != 0) {
+            b = slotId / cpb; k = slotId % cpb;
+            n = min((uint32_t)KNZ_ANS_CHUNK, a.blk_pre_len[b] - k * KNZ_ANS_CHUNK);
+        }
+        {
             if (mode == 3) {
                 // cumulated frequencies (symbol order) with a wave scan over 4 symbols per lane, then the tables
                 uint32_t f4[4], tot = 0;
@@ -348,10 +360,7 @@ __global__ __launch_bounds__(64) void knz_ans0_decode_kernel(Ans0DecArgs a) {
                 if (lane == 0) s_state[cg][0] = s_alpha[0];
             }
             wave_sync();
-        } else if (lane == 0) {
-            s_mode[cg] = mode;
         }
-        wave_sync();
         // raw / single-symbol chunks are finished here by the whole wave
         if (mode == 1 || mode == 2) {
             uint8_t* dst = a.out + a.blk_out_off[b] + (size_t)k * KNZ_ANS_CHUNK;
