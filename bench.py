@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--config", default="huffman", choices=sorted(CONFIGS))
     ap.add_argument("--size", type=int, default=0, help="override the per-GPU corpus size (debug)")
     ap.add_argument("--block-size", type=int, default=0, help="override the block size (debug)")
+    ap.add_argument("--transform", default="", help="override the transform sequence of the config, e.g. LZP or BWT+SRT+ZRLT (debug)")
+    ap.add_argument("--entropy", default="", help="override the entropy codec of the config (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -122,6 +124,7 @@ def main():
         lib = None
     from kanzi_go_amd import dist as kd
     transform, entropy, bs, cfg_idx = CONFIGS[args.config]
+    transform, entropy = args.transform or transform, args.entropy or entropy
     bs = args.block_size or bs
 
     base_size = args.size or bench_corpus.SILESIA_SIZE
@@ -242,8 +245,8 @@ def main():
         per_launch = {k: v / K_ for k, v in stage.items()}
         n_local, c_local = n_my, (result.get("seg_bits", C_bytes * 8) + 7) // 8 if world > 1 else C_bytes
         kern = {
-            {"HUFFMAN": "knz_huf_hist+lengths+encode_kernels", "ANS0": "knz_ans0_stats+encode_kernels", "ANS1": "knz_ans1_hist+stats+merge+encode_kernels", "FPAQ": "knz_fpaq_encode_kernel"}[entropy]: (per_launch["enc_entropy"], n_local + c_local),
-            {"HUFFMAN": "knz_huf_walk_decode_kernel", "ANS0": "knz_ans0_decode_kernel", "ANS1": "knz_ans1_dec_tables+decode_kernels", "FPAQ": "knz_fpaq_decode_kernel"}[entropy]: (per_launch["dec_entropy"], n_local + c_local),
+            {"HUFFMAN": "knz_huf_hist+lengths+encode_kernels", "ANS0": "knz_ans0_stats+encode_kernels", "ANS1": "knz_ans1_hist+stats+merge+encode_kernels", "FPAQ": "knz_fpaq_encode_kernel", "NONE": "knz_raw_units_kernel"}[entropy]: (per_launch["enc_entropy"], n_local + c_local),
+            {"HUFFMAN": "knz_huf_walk_decode_kernel", "ANS0": "knz_ans0_decode_kernel", "ANS1": "knz_ans1_dec_tables+decode_kernels", "FPAQ": "knz_fpaq_decode_kernel", "NONE": "knz_huf_decode_kernel (raw copy)"}[entropy]: (per_launch["dec_entropy"], n_local + c_local),
             ("knz_dec_block_headers_kernel" if entropy == "HUFFMAN" else "knz_dec_walk_blocks_kernel"): (per_launch["dec_walk"], c_local),
             "forward transform stage kernels (" + transform + ")": (per_launch["enc_transform"], 2 * n_local),
             "inverse transform stage kernels (" + transform + ")": (per_launch["dec_transform"], 2 * n_local),

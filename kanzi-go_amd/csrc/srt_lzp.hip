@@ -350,7 +350,24 @@ __device__ __forceinline__ int knz_lzp_find_match(const uint8_t* src, int x, int
     return 8 * nwords;
 }
 
+// bytes [p0 - 8, p0 + 136) of the block staged in LDS by the wave (one coalesced load per lane and 64 bytes): the window's own
+// bytes, the 4 context bytes in front of every lane and the 8 bytes at +56 that a prediction has to match first
+#define KNZ_LZP_WIN_BACK 8
+#define KNZ_LZP_WIN_BYTES 144
+__device__ __forceinline__ void knz_lzp_stage(const uint8_t* src, int count, int p0, uint8_t* s_w, int lane) {
+    wave_sync_lds();
+    for (int i = lane; i < KNZ_LZP_WIN_BYTES; i += 64) { const int g = p0 - KNZ_LZP_WIN_BACK + i; s_w[i] = (g >= 0 && g < count) ? src[g] : (uint8_t)0; }
+    wave_sync();
+}
+__device__ __forceinline__ uint64_t knz_lds_le64(const uint8_t* p) {
+    uint64_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) v |= (uint64_t)p[j] << (8 * j);
+    return v;
+}
+
 __global__ __launch_bounds__(64) void knz_lzp_forward_kernel(LzArgs a) {
+    __shared__ uint8_t s_w[KNZ_LZP_WIN_BYTES];
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (!a.active[b]) return;
@@ -371,15 +388,31 @@ __global__ __launch_bounds__(64) void knz_lzp_forward_kernel(LzArgs a) {
         const int navail = min(64, (inMain ? mainEnd : srcEnd) - srcIdx);
         const bool valid = lane < navail;
         const int q = srcIdx + lane;
-        const uint32_t cl = knz_lzp_lane_ctx(src, (uint64_t)srcIdx, ctx, valid ? lane : 0);
+        knz_lzp_stage(src, count, srcIdx, s_w, lane);
+        const uint8_t* wq = s_w + KNZ_LZP_WIN_BACK + lane;              // my position inside the staged bytes
+        // context of my position if everything in front of me in this window is a literal (:1029): the four bytes in front of
+        // me from the fifth lane on, the running context shifted by my predecessors' bytes before that
+        uint32_t cl;
+        if (lane >= 4) cl = ((uint32_t)wq[-4] << 24) | ((uint32_t)wq[-3] << 16) | ((uint32_t)wq[-2] << 8) | (uint32_t)wq[-1];
+        else { cl = ctx; for (int j = 0; j < lane; j++) cl = (cl << 8) | s_w[KNZ_LZP_WIN_BACK + j]; }
         const uint32_t h = knz_lzp_hash(cl);
         const int tref = valid ? hashes[h] : 0;
-        const uint32_t byte = valid ? src[q] : 0u;
+        const uint32_t byte = valid ? (uint32_t)wq[0] : 0u;
         // positions of this window with my hash: the latest one in front of me is my prediction (:1017-1018)
         int dup = -1;
         for (int j = 0; j + 1 < navail; j++) { const uint32_t hj = wave_readlane(h, (uint32_t)j); if (valid && lane > j && h == hj) dup = j; }
         const int ref = dup >= 0 ? srcIdx + dup : tref;
-        const bool cand = inMain && valid && ref != 0 && knz_le64(src + q + KNZ_LZP_MIN_MATCH - 8) == knz_le64(src + ref + KNZ_LZP_MIN_MATCH - 8);
+        bool cand = false;
+        if (inMain && valid && ref != 0) cand = knz_lds_le64(wq + KNZ_LZP_MIN_MATCH - 8) == knz_le64(src + ref + KNZ_LZP_MIN_MATCH - 8);
+        // the reference then measures the prediction and treats anything under 64 bytes as a literal (:1022-1041): settle that
+        // here, per lane, so that only a prediction that really holds ends the window (tables of fixed-width records match at
+        // +56 again and again without matching in front of it, and a window that ends is a serial step)
+        if (cand) {
+            uint64_t diff = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) diff |= knz_lds_le64(wq + 8 * k) ^ knz_le64(src + ref + 8 * k);
+            cand = diff == 0;
+        }
         const uint64_t cm = wave_ballot(cand);
         const int nlit = cm ? (int)(__ffsll((unsigned long long)cm) - 1) : navail;
         const bool lit = lane < nlit;
@@ -389,13 +422,12 @@ __global__ __launch_bounds__(64) void knz_lzp_forward_kernel(LzArgs a) {
         const uint32_t off = incl - wdt;
         if (wave_ballot(lit && dstIdx + (int)off >= dstEnd) != 0) { skip = true; break; }   // the loop would stop there: no compression
         if (lit) { dst[dstIdx + off] = (uint8_t)byte; if (esc) dst[dstIdx + off + 1] = 0xFF; atomicMax(&hashes[h], q); }
-        // context behind the literals
         const uint32_t cnext = (cl << 8) | byte;                        // context after my byte
         if (nlit > 0) ctx = wave_readlane(cnext, (uint32_t)(nlit - 1));
         dstIdx += (int)wave_bcast(incl, 63);
         srcIdx += nlit;
         wave_sync();                                                    // the table entries are in place before the next look-up
-        if (nlit < navail) {                                            // a prediction may hold here: the reference's loop body, once
+        if (nlit < navail) {                                            // a prediction holds here (>= 64 bytes): the reference's loop body, once
             if (dstIdx >= dstEnd) { skip = true; break; }
             const uint32_t h0 = wave_readlane(h, (uint32_t)nlit);
             const int ref0 = (int)wave_readlane((uint32_t)ref, (uint32_t)nlit);

@@ -129,6 +129,25 @@ def test_config4_8m_blocks(be):
     c.close()
 
 
+@pytest.mark.parametrize("cfg", [("BWT+SRT+ZRLT", "ANS0"), ("LZP", "HUFFMAN"), ("LZX", "NONE")])
+def test_4m_blocks_next_row_transforms(be, cfg):
+    """SURVEY 8f4 transforms at the BASELINE block size: 4 MiB blocks of S-silesia (two full blocks and a ragged one), device
+    stream == oracle stream and device round trip. ("LZX", "NONE") is the reference's -l 1 preset."""
+    import bench_corpus
+    import oracle_lib as O
+    data = bench_corpus.s_silesia()[: 2 * (4 << 20) + 123457].tobytes()
+    c = P.K.Codec(cfg[0], cfg[1], 4 << 20, lib=be.lib)
+    src, ks = be.to_dev(data)
+    cap = len(data) * 2 + (1 << 20)
+    dst, kd = be.empty(cap)
+    nb = c.dev_compress(src, len(data), dst, cap)
+    assert be.to_host(kd, nb) == O.compress(data, cfg[0], cfg[1], 4 << 20, 0, jobs=os.cpu_count() or 1)
+    back, kb = be.empty(len(data) + 4096)
+    assert c.dev_decompress(dst, nb, back, len(data) + 4096) == len(data)
+    assert be.to_host(kb, len(data)) == data
+    c.close()
+
+
 def test_huffman_decoder_paths(be):
     P.check_huffman_shapes(be)
 
