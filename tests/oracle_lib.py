@@ -181,6 +181,8 @@ def decode_block(payload, ttype, etype, block_size, checksum_bits=0):
 def compress(data, transform="NONE", entropy="NONE", block_size=4 << 20, checksum_bits=0, jobs=1, header_size=None):
     a, p = _u8(data)
     cap = len(a) + len(a) // 4 + 65536
+    if block_size < (1 << 18):                      # order-1 headers on small blocks can outweigh the data
+        cap = 2 * len(a) + 262144 * (len(a) // block_size + 2)
     out = np.zeros(cap, dtype=np.uint8)
     n = C.c_uint64()
     hs = len(a) if header_size is None else header_size

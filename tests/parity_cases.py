@@ -407,6 +407,97 @@ def check_huffman_split_walk(be):
         del os.environ["KNZ_HUF_SPLIT_WALK"]
 
 
+def _fuzz_data(r, n):
+    kind = int(r.integers(0, 8))
+    if kind == 0:
+        return r.integers(0, 256, n, dtype=np.uint8).tobytes()
+    if kind == 1:
+        return corpus(n, int(r.integers(0, 1 << 30)))
+    if kind == 2:                                    # runs
+        out = bytearray()
+        while len(out) < n:
+            out += bytes([int(r.integers(0, 256))]) * int(r.integers(1, 200))
+        return bytes(out[:n])
+    if kind == 3:                                    # small alphabet, skewed
+        return np.minimum(r.geometric(0.3, n), 255).astype(np.uint8).tobytes()
+    if kind == 4:                                    # one symbol / two symbols
+        v = r.integers(0, 256, 2, dtype=np.uint8)
+        return (np.where(r.random(n) < 0.02, v[0], v[1])).astype(np.uint8).tobytes()
+    if kind == 5:                                    # periodic records with a few edits (LZ / LZP territory)
+        rec = r.integers(0, 256, int(r.integers(8, 300)), dtype=np.uint8)
+        a = np.tile(rec, n // len(rec) + 1)[:n].copy()
+        idx = r.integers(0, max(n, 1), max(n // 97, 1))
+        a[idx] = r.integers(0, 256, len(idx), dtype=np.uint8)
+        return a.tobytes()
+    if kind == 6:                                    # mostly zeros with 0xFC / 0xFE / 0xFF sprinkled in (ZRLT / LZP escapes)
+        a = np.zeros(n, dtype=np.uint8)
+        idx = r.integers(0, max(n, 1), max(n // 13, 1))
+        a[idx] = r.choice(np.array([0xFC, 0xFE, 0xFF, 1, 2, 0x80], dtype=np.uint8), len(idx))
+        return a.tobytes()
+    return (np.arange(n) * int(r.integers(1, 7)) >> int(r.integers(0, 5))).astype(np.uint8).tobytes()
+
+
+def check_fuzz(be, cases, seed, max_n, heavy_max_n=None):
+    """Seeded differential test: random transform sequences x entropy codecs x block sizes x checksum sizes x data shapes,
+    device stream == oracle stream, the device decodes the oracle's stream, the oracle decodes the device's."""
+    r = np.random.default_rng(seed)
+    tnames = ["NONE", "BWT", "RANK", "MTFT", "ZRLT", "LZ", "LZX", "LZP", "SRT"]
+    enames = ["NONE", "HUFFMAN", "ANS0", "ANS1", "FPAQ"]
+    heavy = {"BWT", "RANK", "MTFT", "SRT"}          # slow on the emulator (cross-lane heavy): smaller inputs there
+    done = 0
+    for case in range(cases):
+        nt = int(r.integers(1, 4))
+        seq = [tnames[int(i)] for i in r.integers(0, len(tnames), nt)]
+        transform = "+".join(seq)
+        entropy = enames[int(r.integers(0, len(enames)))]
+        bs = int(r.choice([1024, 4096, 1 << 14, 1 << 16, 1 << 18]))
+        lim = heavy_max_n if (heavy_max_n and heavy & set(seq)) else max_n
+        n = int(r.integers(1, lim))
+        if r.random() < 0.2:
+            n = int(r.choice([1, 2, 15, 16, 31, 32, 33, bs - 1, bs, bs + 1, 2 * bs + 16]))
+            n = max(1, min(n, lim))
+        ck = int(r.choice([0, 0, 32, 64]))
+        data = _fuzz_data(r, n)
+        tag = (case, transform, entropy, bs, n, ck)
+        try:
+            exp = O.compress(data, transform, entropy, bs, ck)
+        except O.OracleError as e:                   # inputs the reference itself fails on (Go panic => ERR_PROCESS_BLOCK)
+            c = K.Codec(transform, entropy, bs, checksum_bits=ck, lib=be.lib)
+            src, ks = be.to_dev(data)
+            dst, kd = be.empty(2 * n + 262144 * (n // bs + 2))
+            with pytest_raises_knz(e.code):
+                c.dev_compress(src, n, dst, 2 * n + 262144 * (n // bs + 2))
+            c.close()
+            continue
+        c = K.Codec(transform, entropy, bs, checksum_bits=ck, lib=be.lib)
+        src, ks = be.to_dev(data)
+        cap = 2 * n + 262144 * (n // bs + 2)
+        dst, kd = be.empty(cap)
+        nb = c.dev_compress(src, n, dst, cap)
+        got = be.to_host(kd, nb)
+        assert got == exp, tag
+        sp, ksp = be.to_dev(exp, 4)
+        out, ko = be.empty(n + 64)
+        assert c.dev_decompress(sp, len(exp), out, n + 64) == n, tag
+        assert be.to_host(ko, n) == data, tag
+        c.close()
+        done += 1
+    assert done >= cases * 3 // 4
+
+
+class pytest_raises_knz:
+    def __init__(self, code):
+        self.code = code
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        assert et is not None and issubclass(et, K.KnzError), "the device accepted an input the reference fails on"
+        assert ev.code == self.code, (ev.code, self.code)
+        return True
+
+
 def check_corrupt_streams(be, trials=12):
     """Bit flips in valid streams: the device decoder must come back (an error code or some output), never hang or touch
     memory outside its buffers, for every codec on the path. When the oracle decodes the damaged stream without an error,

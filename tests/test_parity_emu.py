@@ -33,6 +33,7 @@ def test_entropy_objects_bit_exact(be, etype, sched, monkeypatch):
     ("BWT+RANK+ZRLT", "ANS1", 1024, 1000), ("BWT+RANK+ZRLT", "ANS1", 1024, 12),
     ("NONE", "FPAQ", 1 << 16, 300000), ("NONE", "FPAQ", 1024, 1000), ("NONE", "FPAQ", 1024, 10), ("BWT+RANK+ZRLT", "FPAQ", 1 << 13, 20000),
     ("LZ", "ANS0", 1 << 16, 300000), ("LZ", "HUFFMAN", 1 << 18, 300000), ("LZX", "HUFFMAN", 1 << 16, 150000), ("LZ", "ANS0", 1024, 1000), ("LZ", "ANS0", 1024, 20),
+    ("BWT+ZRLT", "NONE", 1024, 1024 * 1030 + 5),      # > 1023 blocks: the suffix sort runs in groups
     ("BWT+SRT+ZRLT", "ANS0", 1 << 14, 40000), ("LZP", "HUFFMAN", 1 << 16, 200000), ("SRT", "NONE", 1024, 1000), ("LZP+SRT", "ANS0", 1 << 15, 70000),
 ])
 def test_stream_bit_exact(be, cfg):
@@ -82,6 +83,11 @@ def test_ans1_table_decoder(be):
 
 def test_huffman_split_walk(be):
     P.check_huffman_split_walk(be)
+
+
+@pytest.mark.timeout(900)
+def test_differential_fuzz(be):
+    P.check_fuzz(be, cases=150, seed=20260924, max_n=60000, heavy_max_n=6000)
 
 
 @pytest.mark.timeout(600)

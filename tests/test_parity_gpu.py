@@ -34,6 +34,7 @@ def test_entropy_objects_bit_exact(be, etype):
     ("NONE", "FPAQ", 8 << 20, (8 << 20) + 12345),     # crosses the 4 MiB sub-chunk boundary: coder state persists (FPAQCodec.go:162-168)
     ("LZ", "ANS0", 1 << 16, 300000), ("LZ", "HUFFMAN", 1 << 18, 300000), ("LZX", "HUFFMAN", 1 << 16, 150000), ("LZ", "ANS0", 1024, 1000),
     ("LZ", "ANS0", 1024, 20),
+    ("BWT+ZRLT", "NONE", 1024, 1024 * 1030 + 5),      # > 1023 blocks: the suffix sort runs in groups
     ("BWT+SRT+ZRLT", "ANS0", 1 << 14, 40000), ("LZP", "HUFFMAN", 1 << 16, 200000), ("SRT", "NONE", 1024, 1000), ("LZP+SRT", "ANS0", 1 << 15, 70000), ("LZ", "ANS0", 4 << 20, (4 << 20) + 600000),      # 4 MiB block: 24-bit window (LZCodec.go:289-296)
 ])
 def test_stream_bit_exact(be, cfg):
@@ -162,6 +163,11 @@ def test_ans1_table_decoder(be):
 
 def test_huffman_split_walk(be):
     P.check_huffman_split_walk(be)
+
+
+@pytest.mark.timeout(900)
+def test_differential_fuzz(be):
+    P.check_fuzz(be, cases=300, seed=20260924, max_n=600000)
 
 
 @pytest.mark.timeout(300)
