@@ -480,6 +480,15 @@ def check_fuzz(be, cases, seed, max_n, heavy_max_n=None):
         out, ko = be.empty(n + 64)
         assert c.dev_decompress(sp, len(exp), out, n + 64) == n, tag
         assert be.to_host(ko, n) == data, tag
+        if case % 5 == 0 and ck == 0:                # the same input through the host-pointer batch hook (block-local bit strings)
+            bb = K.BlockBatch(c)
+            blocks = [data[i:i + bs] for i in range(0, n, bs)]
+            res = bb.encode(blocks)
+            tt, et = O.transform_type(transform), O.entropy_type(entropy)
+            for blk, (bits, written, mode, post, skip) in zip(blocks, res):
+                o = O.encode_block(blk, tt, et)
+                assert (written, bits, mode, post, skip) == (o["written"], o["bits"], o["mode"], o["post_len"], o["skip_flags"]), tag
+            assert bb.decode([x[0] for x in res]) == blocks, tag
         c.close()
         done += 1
     assert done >= cases * 3 // 4
