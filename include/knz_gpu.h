@@ -30,6 +30,10 @@ enum {
     KNZ_SKIP = -1
 };
 
+/* knz_cfg.flags: KNZ_FLAG_SKIP_BLOCKS = the CLI's -s / ctx["skipBlocks"] (v2/io/CompressedStream.go:778-800): blocks that start
+ * with the magic number of a compressed format or whose order-0 entropy is >= 973/1024 are emitted as copy blocks */
+enum { KNZ_FLAG_SKIP_BLOCKS = 1 };
+
 /* transform ids, v2/transform/Factory.go:31-53 (6 bits each, first transform in bits 47..42) */
 enum { KNZ_T_NONE = 0, KNZ_T_BWT = 1, KNZ_T_LZ = 3, KNZ_T_ZRLT = 6, KNZ_T_MTFT = 7, KNZ_T_RANK = 8, KNZ_T_SRT = 13, KNZ_T_LZP = 14, KNZ_T_LZX = 16 };
 /* entropy ids, v2/entropy/EntropyCodecFactory.go:26-42 */
@@ -43,7 +47,7 @@ typedef struct {
     uint32_t checksum_bits;  /* 0, 32 or 64 (Writer hasher32/hasher64)                        */
     uint32_t bs_version;     /* ctx["bsVersion"]; only 6 is produced/accepted                 */
     int32_t  device;         /* HIP device ordinal, -1 = current device                       */
-    uint32_t flags;          /* reserved, 0                                                   */
+    uint32_t flags;          /* KNZ_FLAG_* bits                                               */
 } knz_cfg;
 
 /* One block of a batch: what one encodingTask/decodingTask owns (CompressedStream.go:189-214,1020-1045). */

@@ -119,9 +119,10 @@ def _u8(a):
 class Codec:
     """One GPU batch scheduler handle (knz_open): what an io.Writer/io.Reader owns in the drop-in."""
 
-    def __init__(self, transform="NONE", entropy="NONE", block_size=4 << 20, checksum_bits=0, device=-1, lib=None):
+    def __init__(self, transform="NONE", entropy="NONE", block_size=4 << 20, checksum_bits=0, device=-1, lib=None, skip_blocks=False):
+        """skip_blocks = the CLI's -s / ctx["skipBlocks"] (KNZ_FLAG_SKIP_BLOCKS): incompressible blocks become copy blocks."""
         self.L = load_library(lib)
-        self.cfg = _Cfg(transform_type(transform), entropy_type(entropy), block_size, checksum_bits, 6, device, 0)
+        self.cfg = _Cfg(transform_type(transform), entropy_type(entropy), block_size, checksum_bits, 6, device, 1 if skip_blocks else 0)
         self.h = C.c_void_p()
         rc = self.L.knz_open(C.byref(self.cfg), C.byref(self.h))
         if rc:

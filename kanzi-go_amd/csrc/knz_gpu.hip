@@ -12,6 +12,7 @@
 #include "lz.hip"
 #include "srt_lzp.hip"
 #include "xxhash.hip"
+#include "skip.hip"
 #include "prims.h"
 #include "layout.hip"
 #include <algorithm>
@@ -226,7 +227,7 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
         h->blk_status.reserve(4 * (nblocks + 1)) || h->unit_bits.reserve(4 * nslots * KNZ_UNITS_PER_CHUNK) || h->unit_src.reserve(4 * nslots * KNZ_UNITS_PER_CHUNK) ||
         h->scratch.reserve(nslots * (size_t)slotStride + 64) || h->ans_tab.reserve(cfg.entropy == KNZ_E_ANS0 ? nslots * 2048 + nslots * 4 : 16) || h->chunk_rel.reserve(8 * nslots) ||
         h->blk_written.reserve(8 * (nblocks + 1)) || h->blk_hdr.reserve(4 * 6 * (nblocks + 1)) ||
-        h->blk_dst_bit.reserve(8 * (nblocks + 1)) || h->total_bits.reserve(64))
+        h->blk_dst_bit.reserve(8 * (nblocks + 1)) || h->total_bits.reserve(64) || h->blk_copy.reserve(nblocks + 16))
         return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
 
     // block tables: absolute device addresses; blocks <= 15 bytes are copy blocks (CompressedStream.go:773-776)
@@ -234,12 +235,13 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     {
         std::vector<uint64_t> off(nblocks);
         std::vector<uint32_t> len(nblocks);
-        std::vector<uint8_t> skip(nblocks), active(nblocks), side(nblocks, 0);
+        std::vector<uint8_t> skip(nblocks), active(nblocks), side(nblocks, 0), copyv(nblocks);
         const bool noneOnly = cfg.transform == 0;
         for (uint32_t b = 0; b < nblocks; b++) {
             off[b] = (uint64_t)eb.d_src + (uint64_t)b * bs;
             len[b] = (uint32_t)std::min<uint64_t>(bs, eb.n - (uint64_t)b * bs);
             const bool copy = len[b] <= 15 && !eb.payload_only;
+            copyv[b] = copy ? 1 : 0;
             active[b] = (copy || noneOnly) ? 0 : 1;
             skip[b] = (copy || noneOnly) ? 0x7F : 0xFF;       // NullTransform always applies: slot 0 cleared
         }
@@ -252,6 +254,7 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             if (eb.payload_only) for (auto& v : srclen) v = std::max<uint32_t>(v, 16);   // a bare EntropyEncoder has no copy-block rule
             HIP_OK(hipMemcpyAsync(h->blk_src_len.p, srclen.data(), 4 * (size_t)nblocks, hipMemcpyHostToDevice, st));
             HIP_OK(hipMemcpyAsync(h->blk_skip.p, skip.data(), nblocks, hipMemcpyHostToDevice, st));
+            HIP_OK(hipMemcpyAsync(h->blk_copy.p, copyv.data(), nblocks, hipMemcpyHostToDevice, st));
             if (!noneOnly) {
                 HIP_OK(hipMemcpyAsync(xb.active, active.data(), nblocks, hipMemcpyHostToDevice, st));
                 HIP_OK(hipMemcpyAsync(xb.side, side.data(), nblocks, hipMemcpyHostToDevice, st));
@@ -259,6 +262,13 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             HIP_OK(hipMemsetAsync(h->blk_status.p, 0, 4 * (size_t)nblocks, st));
             HIP_OK(hipStreamSynchronize(st)); // the host vectors go out of scope
         }
+    }
+    const bool skipOpt = (cfg.flags & KNZ_FLAG_SKIP_BLOCKS) != 0 && !eb.payload_only && nblocks != 0;
+    if (skipOpt) {                                                       // -s: incompressible blocks become copy blocks (:778-800)
+        SkipArgs ka;
+        ka.nblocks = nblocks; ka.blk_off = h->blk_off.as<uint64_t>(); ka.blk_len = h->blk_len.as<uint32_t>();
+        ka.blk_copy = h->blk_copy.as<uint8_t>(); ka.blk_skip = h->blk_skip.as<uint8_t>(); ka.active = cfg.transform != 0 ? xb.active : nullptr;
+        hipLaunchKernelGGL(knz_skip_detect_kernel, dim3(nblocks), dim3(256), 0, st, ka);
     }
     hipEventRecord(h->ev[0], st);
     if (nblocks && cfg.checksum_bits != 0) {        // checksum of the untransformed block (encodingTask.encode :760-767)
@@ -327,9 +337,16 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
         }
     }
     hipEventRecord(h->ev[2], st);
+    if (skipOpt && cfg.entropy != KNZ_E_NONE) {
+        CopyUnitsArgs ca;
+        ca.chunks_per_block = cpb; ca.chunk_size = chunkSize; ca.blk_copy = h->blk_copy.as<uint8_t>(); ca.blk_off = h->blk_off.as<uint64_t>();
+        ca.blk_len = h->blk_len.as<uint32_t>(); ca.scratch = h->scratch.as<uint8_t>(); ca.slot_stride = slotStride;
+        ca.unit_bits = h->unit_bits.as<uint32_t>(); ca.unit_src = h->unit_src.as<uint32_t>(); ca.blk_status = h->blk_status.as<int32_t>();
+        hipLaunchKernelGGL(knz_copy_units_kernel, dim3(nblocks * cpb), dim3(256), 0, st, ca);
+    }
     LayoutArgs la;
     la.nblocks = nblocks; la.chunks_per_block = cpb; la.unit_bits = h->unit_bits.as<uint32_t>();
-    la.blk_len = h->blk_len.as<uint32_t>(); la.blk_src_len = h->blk_src_len.as<uint32_t>(); la.blk_skip = h->blk_skip.as<uint8_t>();
+    la.blk_len = h->blk_len.as<uint32_t>(); la.blk_src_len = h->blk_src_len.as<uint32_t>(); la.blk_skip = h->blk_skip.as<uint8_t>(); la.blk_copy = h->blk_copy.as<uint8_t>();
     la.blk_cksum = h->blk_cksum.as<uint64_t>(); la.checksum_bits = cfg.checksum_bits; la.n_transforms = seq_len(cfg.transform);
     la.chunk_size = chunkSize; la.payload_only = eb.payload_only; la.chunk_rel = h->chunk_rel.as<uint64_t>(); la.blk_written = h->blk_written.as<uint64_t>();
     la.blk_hdr = h->blk_hdr.as<uint32_t>();

@@ -15,6 +15,7 @@ struct LayoutArgs {
     const uint32_t* unit_bits;      // [nblocks*CPB*5]
     const uint32_t* blk_len;        // [nblocks] post-transform length
     const uint32_t* blk_src_len;    // [nblocks] original block length
+    const uint8_t* blk_copy;        // [nblocks] copy block (<= 15 bytes or skipped by -s); null = derive from the length
     const uint8_t* blk_skip;        // [nblocks] ByteTransformSequence skip flags
     const uint64_t* blk_cksum;      // [nblocks] (when checksum_bits != 0)
     uint32_t checksum_bits;
@@ -29,11 +30,11 @@ struct LayoutArgs {
 
 // Block header fields as encode() writes them (:866-887): returns the number of header bits and packs them,
 // MSB first, into hdr[0..3] (up to 8+8+32+64 = 112 bits).
-__device__ __forceinline__ uint32_t knz_block_header(uint32_t srcLen, uint32_t postLen, uint32_t skipFlags,
+__device__ __forceinline__ uint32_t knz_block_header(bool copyBlock, uint32_t postLen, uint32_t skipFlags,
                                                      uint32_t ntransforms, uint32_t cksumBits, uint64_t cksum,
                                                      uint32_t* hdr, uint32_t* modeOut) {
     uint32_t mode = 0;
-    if (srcLen <= 15) mode |= 0x80;                          // _SMALL_BLOCK_SIZE copy block (:773-776)
+    if (copyBlock) mode |= 0x80;                             // _SMALL_BLOCK_SIZE copy block (:773-776) or skipped by -s (:795-799)
     uint32_t dataSize = 1;
     if (postLen >= 256) dataSize = ((31u - (uint32_t)__builtin_clz(postLen)) >> 3) + 1;
     mode |= ((dataSize - 1) & 3) << 5;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void knz_layout_blocks_kernel(LayoutArgs a) {
     const uint32_t postLen = a.blk_len[b];
     const uint32_t nchunks = (postLen + a.chunk_size - 1) / a.chunk_size;
     uint32_t hdr[4], mode;
-    uint32_t hdrBits = knz_block_header(a.blk_src_len[b], postLen, a.blk_skip[b], a.n_transforms, a.checksum_bits,
+    uint32_t hdrBits = knz_block_header(a.blk_copy ? a.blk_copy[b] != 0 : a.blk_src_len[b] <= 15, postLen, a.blk_skip[b], a.n_transforms, a.checksum_bits,
                                         a.checksum_bits ? a.blk_cksum[b] : 0, hdr, &mode);
     if (a.payload_only) hdrBits = 0;
     if (tid == 0) s_carry = hdrBits;

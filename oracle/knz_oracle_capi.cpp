@@ -120,6 +120,27 @@ int knzo_compress(const uint8_t* src, uint64_t n, uint64_t transformType, uint32
     KNZO_CATCH
 }
 
+// same with option flags (1 = skip incompressible blocks, the CLI's -s)
+int knzo_compress2(const uint8_t* src, uint64_t n, uint64_t transformType, uint32_t entropyType, uint64_t blockSize,
+                   int checksumBits, int jobs, int64_t headerInputSize, int flags, uint8_t* dst, uint64_t cap, uint64_t* out_n) {
+    KNZO_TRY
+    std::vector<uint8_t> out;
+    compressStream(src, (size_t)n, transformType, entropyType, (size_t)blockSize, checksumBits, jobs, headerInputSize, out, flags);
+    *out_n = out.size();
+    if (out.size() > cap) throw KnzError(ERR_WRITE_FILE, "output buffer too small");
+    memcpy(dst, out.data(), out.size());
+    return 0;
+    KNZO_CATCH
+}
+
+uint32_t knzo_magic_type(const uint8_t* src, uint64_t n) { return getMagicType(src, (size_t)n); }
+int knzo_entropy1024(const uint8_t* src, uint64_t n) {
+    int histo[256] = {0};
+    for (uint64_t i = 0; i < n; i++) histo[src[i]]++;
+    return computeFirstOrderEntropy1024((size_t)n, histo);
+}
+uint32_t knzo_log2_scaled_1024(uint32_t x) { return log2ScaledBy1024(x); }
+
 int knzo_decompress(const uint8_t* src, uint64_t n, int jobs, uint8_t* dst, uint64_t cap, uint64_t* out_n) {
     KNZO_TRY
     std::vector<uint8_t> out;

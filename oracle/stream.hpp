@@ -12,6 +12,7 @@
 #include "huffman.hpp"
 #include "transforms.hpp"
 #include <atomic>
+#include <cmath>
 #include <thread>
 
 namespace knzo {
@@ -237,6 +238,58 @@ static inline void entropyDecode(BitReader& ibs, uint32_t type, uint8_t* block, 
     }
 }
 
+// ---- `-s` / ctx["skipBlocks"] (CompressedStream.go:778-800): blocks that look incompressible become copy blocks -------------
+// internal/Magic.go:83-126 GetMagicType, :130-170 IsDataCompressed
+static inline uint32_t getMagicType(const uint8_t* src, size_t n) {
+    if (n < 4) return 0;
+    const uint32_t key = ((uint32_t)src[0] << 24) | ((uint32_t)src[1] << 16) | ((uint32_t)src[2] << 8) | src[3];
+    if ((key & ~0x0Fu) == 0xFFD8FFE0u) return key;                       // JPG
+    if ((key >> 8) == 0x425A68u || (key >> 8) == 0x494433u) return key >> 8;   // BZIP2, MP3 ID3
+    static const uint32_t keys32[18] = {0x47494638u, 0x25504446u, 0x504B0304u, 0x377ABCAFu, 0x89504E47u, 0x7F454C46u, 0xFEEDFACEu, 0xCEFAEDFEu,
+                                        0xFEEDFACFu, 0xCFFAEDFEu, 0x28B52FFDu, 0x81CFB2CEu, 0x4D534346u, 0x52494646u, 0x664C6143u, 0xFD377A58u,
+                                        0x4B414E5Au, 0x52617221u};
+    for (uint32_t k : keys32) if (key == k) return key;
+    const uint32_t key16 = key >> 16;
+    if (key16 == 0x1F8Bu || key16 == 0x424Du || key16 == 0x4D5Au) return key16;      // GZIP, BMP, WIN
+    if (key16 == 0x5034u || key16 == 0x5035u || key16 == 0x5036u) {                  // PBM, PGM, PPM (binary)
+        const uint32_t sub = (key >> 8) & 0xFF;
+        if (sub == 0x07 || sub == 0x0A || sub == 0x0D || sub == 0x20) return key16;
+    }
+    return 0;
+}
+static inline bool isDataCompressed(uint32_t magic) {
+    switch (magic) {
+        case 0xFFD8FFE0u: case 0x47494638u: case 0x89504E47u: case 0x377ABCAFu: case 0x28B52FFDu: case 0x81CFB2CEu: case 0x4D534346u:
+        case 0x504B0304u: case 0x1F8Bu: case 0x425A68u: case 0x664C6143u: case 0x494433u: case 0xFD377A58u: case 0x4B414E5Au: case 0x52617221u:
+            return true;                 // JPG (exact value only, as in the reference's switch), GIF, PNG, LZMA, ZSTD, BROTLI, CAB, ZIP, GZIP, BZIP2, FLAC, MP3, XZ, KNZ, RAR
+        default: return false;
+    }
+}
+// internal/Global.go:174-191 Log2ScaledBy1024 ; the table is 4096*log2(x) rounded, x = 0..256 (:59-88)
+static inline uint32_t log2ScaledBy1024(uint32_t x) {
+    static uint32_t table[257];
+    static bool init = false;
+    if (!init) { table[0] = 0; for (int i = 1; i <= 256; i++) table[i] = (uint32_t)std::floor(4096.0 * std::log2((double)i) + 0.5); init = true; }
+    if (x < 256) return (table[x] + 2) >> 2;
+    const uint32_t lg = log2NoCheck(x);
+    if ((x & (x - 1)) == 0) return lg << 10;
+    return ((lg - 7) * 1024) + ((table[x >> (lg - 7)] + 2) >> 2);
+}
+// internal/Global.go:196-216
+static inline int computeFirstOrderEntropy1024(size_t blockLen, const int* histo) {
+    if (blockLen == 0) return 0;
+    uint64_t sum = 0;
+    const uint32_t logLength1024 = log2ScaledBy1024((uint32_t)blockLen);
+    for (int i = 0; i < 256; i++) {
+        if (histo[i] == 0) continue;
+        const uint32_t log1024 = log2ScaledBy1024((uint32_t)histo[i]);
+        sum += ((uint64_t)histo[i] * (uint64_t)(logLength1024 - log1024)) >> 3;
+    }
+    return (int)(sum / (uint64_t)blockLen);
+}
+static const int INCOMPRESSIBLE_THRESHOLD = 973;   // entropy/EntropyUtils.go:26
+enum : int { KNZO_FLAG_SKIP_BLOCKS = 1 };
+
 // ---- one block: CompressedStream.go:729-914 (up to obs.Close()) -------------------------------
 struct BlockResult {
     std::vector<uint8_t> bits; // block-local stream, zero padded to a byte
@@ -249,7 +302,7 @@ struct BlockResult {
 static const uint32_t KNZ_SEED = 0x4B414E5A;
 
 static inline void encodeBlock(const uint8_t* data, size_t blockLength, uint64_t transformType, uint32_t entropyType,
-                               int checksumBits, BlockResult& res) {
+                               int checksumBits, BlockResult& res, int flags = 0) {
     uint8_t mode = 0;
     uint64_t checksum = 0;
     if (checksumBits == 32) checksum = xxhash32(data, blockLength, KNZ_SEED);
@@ -258,6 +311,15 @@ static inline void encodeBlock(const uint8_t* data, size_t blockLength, uint64_t
         transformType = T_NONE;
         entropyType = E_NONE;
         mode |= 0x80;
+    } else if (flags & KNZO_FLAG_SKIP_BLOCKS) { // :778-800
+        bool skip = false;
+        if (blockLength >= 8) skip = isDataCompressed(getMagicType(data, blockLength));
+        if (!skip) {
+            int histo[256] = {0};
+            for (size_t i = 0; i < blockLength; i++) histo[data[i]]++;
+            skip = computeFirstOrderEntropy1024(blockLength, histo) >= INCOMPRESSIBLE_THRESHOLD;
+        }
+        if (skip) { transformType = T_NONE; entropyType = E_NONE; mode |= 0x80; }
     }
     Sequence t(transformType);
     size_t requiredSize = t.maxEncodedLen(blockLength);
@@ -399,7 +461,7 @@ static inline void appendBlock(BitWriter& obs, const BlockResult& r) {
 
 static inline void compressStream(const uint8_t* src, size_t n, uint64_t transformType, uint32_t entropyType,
                                   size_t blockSize, int checksumBits, int jobs, int64_t headerInputSize,
-                                  std::vector<uint8_t>& out) {
+                                  std::vector<uint8_t>& out, int flags = 0) {
     if (blockSize < 1024 || blockSize > ((size_t)1 << 30) || (blockSize & 15)) throw KnzError(ERR_BLOCK_SIZE, "Invalid block size");
     size_t nblocks = (n + blockSize - 1) / blockSize;
     std::vector<BlockResult> results(nblocks);
@@ -411,7 +473,7 @@ static inline void compressStream(const uint8_t* src, size_t n, uint64_t transfo
             size_t b = next.fetch_add(1);
             if (b >= nblocks || errCode.load()) return;
             size_t off = b * blockSize, len = std::min(blockSize, n - off);
-            try { encodeBlock(src + off, len, transformType, entropyType, checksumBits, results[b]); }
+            try { encodeBlock(src + off, len, transformType, entropyType, checksumBits, results[b], flags); }
             catch (const KnzError& e) { int z = 0; if (errCode.compare_exchange_strong(z, e.code)) errMsg = e.what(); return; }
         }
     };

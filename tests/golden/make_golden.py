@@ -21,6 +21,20 @@ def expgolomb_tables():
     return {"unsigned": nums[:256], "signed": nums[256:]}
 
 
+def log2_4096_table():
+    src = open(os.path.join(REF, "internal/Global.go")).read()
+    body = src[src.index("LOG2_4096 = [...]uint32{"):]
+    body = body[: body.index("}")]
+    nums = [int(x) for x in re.findall(r"\b(\d+),", body)]
+    assert len(nums) == 257, len(nums)
+    return nums
+
+
+def magic_values():
+    src = open(os.path.join(REF, "internal/Magic.go")).read()
+    return {m.group(1): int(m.group(2), 16) for m in re.finditer(r"(\w+_MAGIC\w*)\s*=\s*(0x[0-9A-Fa-f]+)", src)}
+
+
 def main():
     g = {
         "source": "flanglet/kanzi-go v2 (bitstream v6)",
@@ -30,6 +44,10 @@ def main():
         # Entropy_test.go:54-67 values; expected length = 1 + number of 7-bit groups above the first
         "varint_values": [0, 1, 127, 128, 255, 16384, (1 << 21) - 1, 1 << 21, (1 << 28) - 1, 1 << 28, 0xFFFFFFFF],
         # CompressedStream.go:42-54
+        # internal/Global.go:59-88 (4096*log2(x), x = 0..256) and entropy/EntropyUtils.go:26
+        "log2_4096": log2_4096_table(), "incompressible_threshold": 973,
+        # internal/Magic.go:22-58
+        "magic": magic_values(),
         "stream": {"magic": 0x4B414E5A, "version": 6, "hash_seed": 0x4B414E5A, "header_hash": 0x1E35A7BD,
                    "header_seed_mul": 0x01030507},
     }

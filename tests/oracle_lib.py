@@ -64,6 +64,13 @@ def lib():
                                         C.POINTER(C.c_uint64)]
         L.knzo_compress.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.c_int64,
                                     u8p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.knzo_compress2.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int,
+                                     u8p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.knzo_magic_type.argtypes = [u8p, C.c_uint64]
+        L.knzo_magic_type.restype = C.c_uint32
+        L.knzo_entropy1024.argtypes = [u8p, C.c_uint64]
+        L.knzo_log2_scaled_1024.argtypes = [C.c_uint32]
+        L.knzo_log2_scaled_1024.restype = C.c_uint32
         L.knzo_decompress.argtypes = [u8p, C.c_uint64, C.c_int, u8p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.knzo_varint.argtypes = [C.c_uint32, u8p]
         L.knzo_varint_read.argtypes = [u8p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -178,7 +185,7 @@ def decode_block(payload, ttype, etype, block_size, checksum_bits=0):
     return out[: n.value].tobytes()
 
 
-def compress(data, transform="NONE", entropy="NONE", block_size=4 << 20, checksum_bits=0, jobs=1, header_size=None):
+def compress(data, transform="NONE", entropy="NONE", block_size=4 << 20, checksum_bits=0, jobs=1, header_size=None, skip_blocks=False):
     a, p = _u8(data)
     cap = len(a) + len(a) // 4 + 65536
     if block_size < (1 << 18):                      # order-1 headers on small blocks can outweigh the data
@@ -188,8 +195,8 @@ def compress(data, transform="NONE", entropy="NONE", block_size=4 << 20, checksu
     hs = len(a) if header_size is None else header_size
     tt = transform_type(transform) if isinstance(transform, str) else transform
     et = entropy_type(entropy) if isinstance(entropy, str) else entropy
-    _chk(lib().knzo_compress(p, len(a), tt, et, block_size, checksum_bits, jobs, hs,
-                             out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n)))
+    _chk(lib().knzo_compress2(p, len(a), tt, et, block_size, checksum_bits, jobs, hs, 1 if skip_blocks else 0,
+                              out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n)))
     return out[: n.value].tobytes()
 
 

@@ -407,6 +407,34 @@ def check_huffman_split_walk(be):
         del os.environ["KNZ_HUF_SPLIT_WALK"]
 
 
+def check_skip_blocks(be):
+    """-s / ctx["skipBlocks"]: random blocks (entropy >= 973/1024) and blocks that start with a compressed-format magic number
+    become copy blocks; the stream equals the oracle's for every entropy codec and decodes back."""
+    r = np.random.default_rng(77)
+    bs = 1 << 16
+    text = corpus(bs, 5)
+    rnd = r.integers(0, 256, bs, dtype=np.uint8).tobytes()
+    gz = bytes([0x1F, 0x8B, 8, 0]) + corpus(bs - 4, 6)               # compressible, but says gzip
+    jpg_e1 = bytes([0xFF, 0xD8, 0xFF, 0xE1]) + corpus(bs - 4, 7)      # recognised as JPG, not in the compressed list: stays
+    almost = (r.integers(0, 256, bs, dtype=np.uint8) & 0x7F).tobytes()   # 7 bits per byte: under the threshold
+    data = text + rnd + gz + text + jpg_e1 + almost + rnd[:12345]
+    for transform, entropy in (("NONE", "HUFFMAN"), ("NONE", "ANS0"), ("NONE", "ANS1"), ("NONE", "FPAQ"), ("NONE", "NONE"),
+                               ("BWT+RANK+ZRLT", "ANS0"), ("LZ", "HUFFMAN")):
+        for ck in (0, 32):
+            exp = O.compress(data, transform, entropy, bs, ck, skip_blocks=True)
+            assert exp != O.compress(data, transform, entropy, bs, ck) or (transform, entropy) == ("NONE", "NONE")
+            c = K.Codec(transform, entropy, bs, checksum_bits=ck, lib=be.lib, skip_blocks=True)
+            src, ks = be.to_dev(data)
+            cap = 2 * len(data) + (1 << 20)
+            dst, kd = be.empty(cap)
+            nb = c.dev_compress(src, len(data), dst, cap)
+            assert be.to_host(kd, nb) == exp, (transform, entropy, ck)
+            out, ko = be.empty(len(data) + 64)
+            assert c.dev_decompress(dst, nb, out, len(data) + 64) == len(data)
+            assert be.to_host(ko, len(data)) == data
+            c.close()
+
+
 def _fuzz_data(r, n):
     kind = int(r.integers(0, 8))
     if kind == 0:

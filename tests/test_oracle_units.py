@@ -201,6 +201,42 @@ def test_rank_and_mtf_known_vectors():
     assert O.transform_forward(O.T_RANK, bytes([3, 3, 3, 0])) == bytes([3, 0, 0, 1])
 
 
+def test_skip_blocks_constants_and_rules():
+    # the 4096*log2 table both sides rebuild from the formula equals the reference's (internal/Global.go:59-88, extracted by
+    # tests/golden/make_golden.py); Log2ScaledBy1024 and the magic rules follow internal/Global.go:174-191, Magic.go:83-170
+    import json, math, os, re
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_constants.json")))
+    tab = g["log2_4096"]
+    assert tab == [0] + [int(math.floor(4096 * math.log2(x) + 0.5)) for x in range(1, 257)]
+    dev = open(os.path.join(os.path.dirname(__file__), "..", "kanzi-go_amd", "csrc", "skip.hip")).read()
+    body = dev[dev.index("KNZ_LOG2_4096[257] = {"):]
+    body = body[: body.index("};")]
+    assert [int(x) for x in re.findall(r"\b(\d+),", body)] == tab           # the device's literal table
+    L = O.lib()
+    for x in (1, 2, 3, 100, 255, 256, 257, 4096, 4097, 65535, 1 << 20, (1 << 22) + 12345):
+        lg = x.bit_length() - 1
+        exp = (tab[x] + 2) >> 2 if x < 256 else (lg << 10 if x & (x - 1) == 0 else (lg - 7) * 1024 + ((tab[x >> (lg - 7)] + 2) >> 2))
+        assert L.knzo_log2_scaled_1024(x) == exp
+    assert g["incompressible_threshold"] == 973
+    m = g["magic"]
+
+    def magic(b):
+        a, p = O._u8(bytes(b) + bytes(12))
+        return L.knzo_magic_type(p, len(a))
+    assert magic(m["GZIP_MAGIC"].to_bytes(2, "big") + b"ab") == m["GZIP_MAGIC"]
+    assert magic(m["ZIP_MAGIC"].to_bytes(4, "big")) == m["ZIP_MAGIC"]
+    assert magic(m["BZIP2_MAGIC"].to_bytes(3, "big") + b"9") == m["BZIP2_MAGIC"]
+    assert magic((m["JPG_MAGIC"] | 1).to_bytes(4, "big")) == m["JPG_MAGIC"] | 1
+    assert magic(b"P5\x0a1") == m["PGM_MAGIC"] and magic(b"P5ab") == 0
+    assert magic(b"text") == 0
+    # order-0 entropy of uniform random bytes is ~8 bits (>= 973/1024 of it), of text far below
+    r = np.random.default_rng(3).integers(0, 256, 100000, dtype=np.uint8).tobytes()
+    a, p = O._u8(r)
+    assert L.knzo_entropy1024(p, len(a)) >= 973
+    a, p = O._u8(b"the quick brown fox " * 4000)
+    assert L.knzo_entropy1024(p, len(a)) < 600
+
+
 def test_srt_known_vector():
     # SRT.go:49-132 by hand for "AAB" + "A": header = 256 one-byte varints (freq[A] = 3, freq[B] = 1), buckets ordered by
     # decreasing frequency (A: 3 entries, then B: 1). Ranks: A is the first symbol seen (rank 0), its run partner 0; B is the

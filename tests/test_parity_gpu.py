@@ -165,6 +165,10 @@ def test_huffman_split_walk(be):
     P.check_huffman_split_walk(be)
 
 
+def test_skip_blocks_option(be):
+    P.check_skip_blocks(be)
+
+
 @pytest.mark.timeout(900)
 def test_differential_fuzz(be):
     P.check_fuzz(be, cases=300, seed=20260924, max_n=600000)
