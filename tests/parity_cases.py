@@ -407,6 +407,42 @@ def check_huffman_split_walk(be):
         del os.environ["KNZ_HUF_SPLIT_WALK"]
 
 
+def check_concurrent_handles(be, threads=8, rounds=3):
+    """the library is thread-safe for concurrent calls on different handles (one handle per goroutine / Writer).
+    Several host threads, each with its own handle and its own configuration, compress and decompress at the same time."""
+    import threading
+    cfgs = [("NONE", "HUFFMAN", 1 << 16), ("NONE", "ANS0", 1 << 16), ("BWT+RANK+ZRLT", "ANS1", 1 << 15), ("LZ", "HUFFMAN", 1 << 16),
+            ("NONE", "HUFFMAN", 4096), ("LZP", "ANS0", 1 << 16), ("ZRLT", "NONE", 1 << 14), ("BWT+SRT+ZRLT", "FPAQ", 1 << 14)]
+    errors = []
+
+    def work(i):
+        try:
+            transform, entropy, bs = cfgs[i % len(cfgs)]
+            n = 200000 + 7777 * i
+            data = corpus(n, 100 + i)
+            exp = O.compress(data, transform, entropy, bs)
+            c = K.Codec(transform, entropy, bs, lib=be.lib)
+            src, ks = be.to_dev(data)
+            cap = 2 * n + 262144 * (n // bs + 2)
+            dst, kd = be.empty(cap)
+            out, ko = be.empty(n + 64)
+            for _ in range(rounds):
+                nb = c.dev_compress(src, n, dst, cap)
+                assert be.to_host(kd, nb) == exp, (i, "stream")
+                assert c.dev_decompress(dst, nb, out, n + 64) == n
+                assert be.to_host(ko, n) == data, (i, "round trip")
+            c.close()
+        except Exception as e:                       # noqa: BLE001 - reported below with the thread number
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
 def check_skip_blocks(be, light=False):
     """-s / ctx["skipBlocks"]: random blocks (entropy >= 973/1024) and blocks that start with a compressed-format magic number
     become copy blocks; the stream equals the oracle's for every entropy codec and decodes back."""

@@ -165,6 +165,10 @@ def test_huffman_split_walk(be):
     P.check_huffman_split_walk(be)
 
 
+def test_concurrent_handles(be):
+    P.check_concurrent_handles(be)
+
+
 def test_skip_blocks_option(be):
     P.check_skip_blocks(be)
 
