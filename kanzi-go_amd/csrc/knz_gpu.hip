@@ -11,6 +11,7 @@
 #include "bwt.hip"
 #include "lz.hip"
 #include "srt_lzp.hip"
+#include "utf.hip"
 #include "xxhash.hip"
 #include "skip.hip"
 #include "prims.h"
@@ -87,7 +88,7 @@ uint32_t knz_build_stream_header(const knz_cfg& cfg, int64_t inputSize, uint32_t
 static bool transform_on_device(uint64_t t) {                    // packed sequence
     for (int s = 42; s >= 0; s -= 6) {
         const uint32_t id = (uint32_t)((t >> s) & 63);
-        if (!(id == KNZ_T_NONE || id == KNZ_T_BWT || id == KNZ_T_RANK || id == KNZ_T_MTFT || id == KNZ_T_ZRLT || id == KNZ_T_LZ || id == KNZ_T_LZX || id == KNZ_T_SRT || id == KNZ_T_LZP)) return false;
+        if (!(id == KNZ_T_NONE || id == KNZ_T_BWT || id == KNZ_T_RANK || id == KNZ_T_MTFT || id == KNZ_T_ZRLT || id == KNZ_T_LZ || id == KNZ_T_LZX || id == KNZ_T_SRT || id == KNZ_T_LZP || id == KNZ_T_UTF)) return false;
     }
     return true;
 }
@@ -112,6 +113,7 @@ extern "C" uint32_t knz_max_encoded_len(uint64_t transform, uint32_t n) {
         if (t == KNZ_T_BWT || t == KNZ_T_RANK || t == KNZ_T_MTFT) nxt = req + 33;
         else if (t == KNZ_T_LZ || t == KNZ_T_LZX || t == KNZ_T_LZP) nxt = req <= 1024 ? req + 16 : req + req / 64;
         else if (t == KNZ_T_SRT) nxt = req + 4 * 256;
+        else if (t == KNZ_T_UTF) nxt = req + 8192;
         if (nxt > req) req = nxt;
     }
     return (uint32_t)std::min<uint64_t>(req, 0xFFFFFFFFu);
@@ -280,6 +282,14 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     if (nblocks && cfg.transform != 0) {
         xb.cur_ptr = h->blk_off.as<uint64_t>(); xb.cur_len = h->blk_len.as<uint32_t>(); xb.skip = h->blk_skip.as<uint8_t>();
         xb.blk_status = h->blk_status.as<int32_t>();
+        bool hasUtf = false;
+        for (int sft = 42; sft >= 0; sft -= 6) hasUtf = hasUtf || ((cfg.transform >> sft) & 63) == KNZ_T_UTF;
+        if (hasUtf) {                                                    // ctx["dataType"] from the magic number of the untransformed block (:811-819)
+            if (h->blk_dt.reserve(nblocks + 16)) return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
+            hipLaunchKernelGGL(knz_block_datatype_kernel, dim3((nblocks + 63) / 64), dim3(64), 0, st, nblocks, (const uint64_t*)h->blk_off.as<uint64_t>(),
+                               (const uint32_t*)h->blk_len.as<uint32_t>(), h->blk_dt.as<uint8_t>());
+            xb.blk_dt = h->blk_dt.as<uint8_t>();
+        }
         int rc = forward_sequence(h, xb, cfg.transform, st);
         if (rc) return rc;
     }

@@ -1,0 +1,331 @@
+// UTF codec of kanzi bitstream v6 on gfx950: UTF-8 code points are replaced by 1- or 2-byte ranks (by decreasing frequency)
+// behind a map of the code points. Replaces UTFCodec.Forward / Inverse / validateUTF / packUTF / unpackUTF1
+// (v2/transform/UTFCodec.go:84-265, 268-383, 393-519, 521-546, 578-609).
+//
+// Unlike the list and dictionary transforms this one is data parallel once a block is known to be well-formed: a code point
+// starts at every byte that is not a continuation byte. One wave per block (the batch has tens of blocks), every pass strides
+// the block 64 positions at a time:
+//   1. validation = the reference's statistics (validateUTF: no byte that never occurs in UTF-8, every lead byte followed by
+//      a second byte of its legal range, at least 1/8 continuation bytes) plus the checks of its main loop (third / fourth
+//      bytes, no stray continuation byte), all of them local to a position, and, in the same pass, the histogram of the
+//      packed code points in a 2^22-entry table with the list of distinct code points built from the first touch;
+//   2. ranks of the (at most 32767) code points by (frequency, code point) by counting, aliases written back into the table;
+//   3. emission: per row of 64 positions the alias widths are prefix-summed and the bytes stored.
+// The inverse finds the alias boundaries (a byte >= 128 takes the next byte with it, whatever that is) with a wave scan over
+// the two-state automaton, prefix-sums the code point lengths and stores.
+// A UTF stage behind another UTF stage that applied (ctx["dataType"] == DT_UTF8: the reference skips validateUTF then) takes
+// the reference's sequential walk on lane 0 to mark the code point starts; that never happens in a useful sequence.
+#include "bits.h"
+
+#define KNZ_UTF_MIN_BLOCK 1024
+#define KNZ_UTF_MAX_SYMS 32768
+#define KNZ_UTF_MAP_LOG 22
+
+struct UtfArgs {
+    uint32_t nblocks;
+    const uint64_t* in_ptr; const uint32_t* in_len;
+    const uint64_t* out_ptr; uint32_t out_cap;
+    uint32_t* out_len; int32_t* ok; const uint8_t* active;
+    int32_t* alias_map;          // [nblocks << 22], zeroed by the host (forward)
+    uint32_t* symlist;           // [nblocks * 32768] distinct code points in order of first touch (forward)
+    uint32_t* ranks;             // [nblocks * 32768] sort position of symlist[j] (forward)
+    uint64_t* inv_map;           // [nblocks * 32768] bytes of the code point | length << 32 (inverse)
+    uint8_t* chain_bits;         // [nblocks * bits_stride] code point starts of the sequential walk (forward, dataType == UTF8 only)
+    uint64_t bits_stride;
+    uint8_t* blk_dt;             // [nblocks] ctx["dataType"]: 0 undefined, 1 set by the magic number (not UTF), 2 UTF8; may be null
+};
+
+__device__ __forceinline__ uint32_t knz_utf_size(uint32_t b) {          // _UTF_SIZES :31-48
+    return b < 0x80 ? 1u : (b < 0xC2 ? 0u : (b < 0xE0 ? 2u : (b < 0xF0 ? 3u : (b < 0xF5 ? 4u : 0u))));
+}
+// second byte legal behind lead byte a (validateUTF's pair rules :459-499; a is a lead byte of a 2..4 byte sequence)
+__device__ __forceinline__ bool knz_utf_pair_ok(uint32_t a, uint32_t b) {
+    if (a == 0xE0) return b >= 0xA0 && b <= 0xBF;
+    if (a == 0xED) return b >= 0x80 && b <= 0x9F;
+    if (a == 0xF0) return b >= 0x90 && b <= 0xBF;
+    if (a == 0xF4) return b >= 0x80 && b <= 0x8F;
+    return b >= 0x80 && b <= 0xBF;                                       // C2..DF, E1..EC, EE, EF, F1..F3
+}
+__device__ __forceinline__ uint32_t knz_utf_pack(uint32_t s, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {   // packUTF
+    if (s == 1) return b0;
+    if (s == 2) return (1u << 19) | (b0 << 8) | b1;
+    if (s == 3) return (2u << 19) | ((b0 & 0x0F) << 12) | ((b1 & 0x3F) << 6) | (b2 & 0x3F);
+    return (4u << 19) | ((b0 & 0x07) << 18) | ((b1 & 0x3F) << 12) | ((b2 & 0x3F) << 6) | (b3 & 0x3F);
+}
+
+__global__ __launch_bounds__(64) void knz_utf_forward_kernel(UtfArgs a) {
+    __shared__ uint32_t s_n;
+    __shared__ uint64_t s_keys[1024];
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (!a.active[b]) return;
+    const int count = (int)a.in_len[b];
+    const uint8_t* src = (const uint8_t*)a.in_ptr[b];
+    uint8_t* dst = (uint8_t*)a.out_ptr[b];
+    const uint32_t dt = a.blk_dt ? a.blk_dt[b] : 0u;
+    if (count == 0) { if (lane == 0) { a.ok[b] = 1; a.out_len[b] = 0; } return; }
+    // :93-114: block size, output size, ctx["dataType"]
+    if (count < KNZ_UTF_MIN_BLOCK || (uint64_t)a.out_cap < (uint64_t)count + 8192 || dt == 1) { if (lane == 0) { a.ok[b] = 0; a.out_len[b] = 0; } return; }
+    int32_t* map = a.alias_map + ((size_t)b << KNZ_UTF_MAP_LOG);
+    uint32_t* syms = a.symlist + (size_t)b * KNZ_UTF_MAX_SYMS;
+    uint32_t* ranks = a.ranks + (size_t)b * KNZ_UTF_MAX_SYMS;
+    uint8_t* cbits = a.chain_bits + (size_t)b * a.bits_stride;
+    const bool chainMode = dt == 2;                                      // mustValidate == false
+    int start = 0;
+    if (src[1] == 0xEF && src[2] == 0xBB && src[3] == 0xBF) start = 3;   // BigEndian.Uint32(src) & 0x00FFFFFF == 0xEFBBBF (:118)
+    else while (start < 4 && knz_utf_size(src[start]) == 0) start++;
+    const int end = count - 4;                                           // code points start in [start, end)
+    if (lane == 0) s_n = 0;
+    bool bad = false;
+    if (chainMode) {
+        // the reference's walk (:141-166), lane 0; marks the starts. (Only reachable with UTF twice in one sequence.)
+        for (uint64_t i = lane; i < a.bits_stride; i += 64) cbits[i] = 0;
+        wave_sync();
+        __threadfence();
+        int fail = 0;
+        if (lane == 0) {
+            for (int i = start; i < end;) {
+                const uint32_t s = knz_utf_size(src[i]);
+                if (s == 0 || (s == 3 && (src[i + 2] & 0xC0) != 0x80) || (s == 4 && ((src[i + 2] & 0xC0) != 0x80 || (src[i + 3] & 0xC0) != 0x80))) { fail = 1; break; }
+                cbits[i >> 3] |= (uint8_t)(1u << (i & 7));
+                i += (int)s;
+            }
+        }
+        wave_sync();
+        __threadfence();
+        bad = wave_bcast((uint32_t)fail, 0) != 0;
+    }
+    wave_sync();
+    // ---- pass 1: validation + histogram --------------------------------------------------------------------------------
+    uint32_t cont = 0;                                                   // bytes in 80..BF inside [start, end) (sum2)
+    int lastLead = -1;
+    if (!bad) {
+        for (int p0 = start; p0 < end; p0 += 64) {
+            const int p = p0 + lane;
+            if (p < end) {
+                const uint32_t b0 = src[p], b1 = src[p + 1], b2 = src[p + 2], b3 = src[p + 3];
+                const uint32_t s = knz_utf_size(b0);
+                bool isSym;
+                if (chainMode) isSym = (cbits[p >> 3] >> (p & 7)) & 1;
+                else {
+                    isSym = s != 0;
+                    if (b0 == 0xC0 || b0 == 0xC1 || b0 >= 0xF5) bad = true;                    // 1-byte rules
+                    if (b0 >= 0x80 && b0 <= 0xBF) cont++;
+                    if (s >= 2 && p + 1 < end && !knz_utf_pair_ok(b0, b1)) bad = true;           // 2-byte rules: pairs inside the region only
+                    if (s >= 3 && (b2 & 0xC0) != 0x80) bad = true;                              // main loop (:146-149)
+                    if (s == 4 && (b3 & 0xC0) != 0x80) bad = true;
+                    if (s == 0) {
+                        // a byte that starts nothing must belong to the sequence of a lead byte at most 3 positions in front of it
+                        bool covered = false;
+                        for (int d = 1; d <= 3 && p - d >= start; d++) if (knz_utf_size(src[p - d]) > (uint32_t)d) { covered = true; break; }
+                        if (!covered) bad = true;
+                    }
+                }
+                if (isSym) {
+                    const uint32_t val = knz_utf_pack(s, b0, b1, b2, b3);
+                    if (atomicAdd(&map[val], 1) == 0) {
+                        const uint32_t idx = atomicAdd(&s_n, 1u);
+                        if (idx < KNZ_UTF_MAX_SYMS) syms[idx] = val;
+                    }
+                    lastLead = p;
+                }
+            }
+        }
+    }
+    wave_sync();
+    __threadfence();
+    const uint32_t n = s_n;
+    const uint32_t contAll = wave_reduce_add(cont);
+    if (wave_ballot(bad) != 0) bad = true;
+    if (!chainMode && contAll < (uint32_t)((end - start) / 8)) bad = true;   // ad-hoc threshold (:518)
+    const int maxTarget = count - count / 10;
+    if (bad || n == 0 || n >= KNZ_UTF_MAX_SYMS || 3 * (int)n + 6 >= maxTarget) { if (lane == 0) { a.ok[b] = 0; a.out_len[b] = 0; } return; }
+    // where the walk stops: behind the last code point that starts in front of count - 4
+    int lastP = lastLead;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = (int)wave_shfl((uint32_t)lastP, lane ^ d); lastP = o > lastP ? o : lastP; }
+    const int srcStop = lastP + (int)knz_utf_size(src[lastP]);
+    // ---- pass 2: ranks by (frequency, code point), increasing (:186-193); symbol of sort position r gets index n - 1 - r ------
+    unsigned long long est = 0;
+    for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        const uint32_t sj = j < n ? syms[j] : 0u;
+        const uint32_t fj = j < n ? (uint32_t)map[sj] : 0u;
+        const uint64_t kj = ((uint64_t)fj << 32) | sj;
+        uint32_t r = 0;
+        for (uint32_t k0 = 0; k0 < n; k0 += 1024) {                      // the keys pass through LDS 1024 at a time
+            const uint32_t m = min(1024u, n - k0);
+            wave_sync_lds();
+            for (uint32_t k = lane; k < m; k += 64) { const uint32_t sk = syms[k0 + k]; s_keys[k] = ((uint64_t)(uint32_t)map[sk] << 32) | sk; }
+            wave_sync();
+            for (uint32_t k = 0; k < m; k++) r += s_keys[k] < kj ? 1u : 0u;
+        }
+        if (j < n) {
+            const uint32_t i = n - 1 - r;
+            ranks[j] = i;
+            est += (unsigned long long)fj * (i < 128 ? 1u : 2u);
+            uint8_t* m = dst + 4 + 3 * (size_t)i;                       // the map (:206-211)
+            m[0] = (uint8_t)(sj >> 16); m[1] = (uint8_t)(sj >> 8); m[2] = (uint8_t)sj;
+        }
+    }
+    {
+        const uint32_t lo = wave_reduce_add((uint32_t)est), hi = wave_reduce_add((uint32_t)(est >> 32));   // (lo cannot carry out: < 2^31 bytes)
+        est = ((unsigned long long)hi << 32) + lo;
+    }
+    if (est + 10 >= (unsigned long long)maxTarget) { if (lane == 0) { a.ok[b] = 0; a.out_len[b] = 0; } return; }   // estimate (:200,:212-223)
+    wave_sync();
+    for (uint32_t j = lane; j < n; j += 64) {                            // aliases replace the frequencies (:214-219)
+        const uint32_t i = ranks[j];
+        map[syms[j]] = i < 128 ? (int32_t)i : (int32_t)(0x10080u | ((i << 1) & 0xFF00u) | (i & 0x7Fu));
+    }
+    wave_sync();
+    __threadfence();
+    // ---- pass 3: emission ------------------------------------------------------------------------------------------------
+    int dstIdx = 4 + 3 * (int)n;
+    if (lane < start) dst[dstIdx + lane] = src[lane];
+    dstIdx += start;
+    for (int p0 = start; p0 < end; p0 += 64) {
+        const int p = p0 + lane;
+        uint32_t w = 0, alias = 0;
+        if (p < end) {
+            const uint32_t b0 = src[p];
+            const uint32_t s = knz_utf_size(b0);
+            const bool isSym = chainMode ? (((cbits[p >> 3] >> (p & 7)) & 1) != 0) : s != 0;
+            if (isSym) {
+                alias = (uint32_t)map[knz_utf_pack(s, b0, src[p + 1], src[p + 2], src[p + 3])];
+                w = 1 + (alias >> 16);
+            }
+        }
+        const uint32_t incl = wave_scan_incl(w);
+        if (w) { uint8_t* o = dst + dstIdx + (incl - w); o[0] = (uint8_t)alias; if (w == 2) o[1] = (uint8_t)(alias >> 8); }
+        dstIdx += (int)wave_bcast(incl, 63);
+    }
+    if (lane == 0) { dst[0] = (uint8_t)start; dst[1] = (uint8_t)(srcStop - end); dst[2] = (uint8_t)(n >> 8); dst[3] = (uint8_t)n; }
+    const int tail = count - srcStop;                                    // last (possibly truncated) bytes (:255-259)
+    if (lane < tail) dst[dstIdx + lane] = src[srcStop + lane];
+    dstIdx += tail;
+    const bool skip = dstIdx >= maxTarget;
+    if (lane == 0) {
+        a.ok[b] = skip ? 0 : 1; a.out_len[b] = skip ? 0 : (uint32_t)dstIdx;
+        if (!skip && a.blk_dt) a.blk_dt[b] = 2;                          // ctx["dataType"] = DT_UTF8 (:131-133: set once the block validated)
+    }
+}
+
+__global__ __launch_bounds__(64) void knz_utf_inverse_kernel(UtfArgs a) {
+    __shared__ int s_err;
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (!a.active[b]) return;
+    const long long count = (long long)a.in_len[b];
+    const uint8_t* src = (const uint8_t*)a.in_ptr[b];
+    uint8_t* dst = (uint8_t*)a.out_ptr[b];
+    const long long cap = (long long)a.out_cap;
+    if (count == 0) { if (lane == 0) { a.ok[b] = 1; a.out_len[b] = 0; } return; }
+    bool bad = count < 4;
+    int start = 0, adjust = 0, n = 0;
+    if (!bad) {
+        start = src[0] & 3; adjust = src[1] & 3; n = ((int)src[2] << 8) + src[3];
+        if (n == 0 || n >= KNZ_UTF_MAX_SYMS || 4 + 3 * (long long)n > count) bad = true;        // :289-291
+    }
+    if (bad) { if (lane == 0) { a.ok[b] = -KNZ_ERR_PROCESS_BLOCK; a.out_len[b] = 0; } return; }
+    uint64_t* inv = a.inv_map + (size_t)b * KNZ_UTF_MAX_SYMS;
+    if (lane == 0) s_err = 0;
+    wave_sync();
+    for (int i = lane; i < KNZ_UTF_MAX_SYMS; i += 64) {                  // unpackUTF1 (:578-609); entries past n have length 0
+        uint64_t e = 0;
+        if (i < n) {
+            const uint8_t* q = src + 4 + 3 * (size_t)i;
+            const uint32_t in = ((uint32_t)q[0] << 16) | ((uint32_t)q[1] << 8) | q[2];
+            const uint32_t sz = in >> 19;
+            uint32_t v = 0, len = 0;
+            if (sz == 0) { v = in & 0xFF; len = 1; }
+            else if (sz == 1) { v = ((in >> 8) & 0xFF) | ((in & 0xFF) << 8); len = 2; }
+            else if (sz == 2) { v = (((in >> 12) & 0x0F) | 0xE0) | ((((in >> 6) & 0x3F) | 0x80) << 8) | (((in & 0x3F) | 0x80) << 16); len = 3; }
+            else if (sz >= 4) { v = (((in >> 18) & 0x07) | 0xF0) | ((((in >> 12) & 0x3F) | 0x80) << 8) | ((((in >> 6) & 0x3F) | 0x80) << 16) | (((in & 0x3F) | 0x80) << 24); len = 4; }
+            else s_err = 1;                                              // sz == 3: invalid alias (:322-324)
+            e = (uint64_t)v | ((uint64_t)len << 32);
+        }
+        inv[i] = e;
+    }
+    wave_sync();
+    __threadfence();
+    long long srcIdx = 4 + 3 * (long long)n;
+    const long long srcEnd = count - 4 + adjust;
+    const long long dstEnd = cap - 4;
+    if (s_err || dstEnd < 0 || srcEnd < srcIdx || srcEnd > count || srcIdx + start > count) { if (lane == 0) { a.ok[b] = -KNZ_ERR_PROCESS_BLOCK; a.out_len[b] = 0; } return; }
+    long long dstIdx = 0;
+    if (lane < start) dst[lane] = src[srcIdx + lane];
+    srcIdx += start; dstIdx += start;
+    // aliases: state 0 = at an alias, 1 = second byte of a two-byte alias. f = (next state from 0) | (next state from 1) << 1
+    uint32_t carry = 0;                                                  // state in front of the row
+    bool fail = srcIdx > srcEnd;
+    for (long long p0 = srcIdx; p0 < srcEnd && !fail; p0 += 64) {
+        const long long p = p0 + lane;
+        const bool in = p < srcEnd;
+        const uint32_t b0 = in ? src[p] : 0u;
+        // inclusive scan of the composed transition functions (state -> state after my byte); bytes behind srcEnd are identity
+        uint32_t f = in ? (b0 >= 128 ? 1u : 0u) : 2u;                    // from 0: to (b0 >= 128), from 1: to 0 ; identity = 0b10
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t g = wave_shfl(f, lane - d);                   // the function of the lanes in front of me
+            if (lane >= d) f = ((f >> (g & 1)) & 1) | (((f >> ((g >> 1) & 1)) & 1) << 1);   // f o g
+        }
+        const uint32_t fprev = wave_shfl(f, lane - 1);
+        const uint32_t stIn = lane == 0 ? carry : ((fprev >> carry) & 1);   // my state before my byte
+        const uint32_t stLast = (wave_bcast(f, 63) >> carry) & 1;
+        const bool isAlias = in && stIn == 0;
+        uint32_t alias = b0, len = 0;
+        uint64_t e = 0;
+        if (isAlias) {
+            if (b0 >= 128) {
+                if (p + 1 >= srcEnd) fail = true;                        // :353-355
+                else alias = ((uint32_t)src[p + 1] << 7) + (b0 & 0x7F);
+            }
+            if (!fail) { e = inv[alias]; len = (uint32_t)(e >> 32); }
+        }
+        const uint32_t incl = wave_scan_incl(len);
+        const long long at = dstIdx + (incl - len);
+        if (isAlias && !fail) {
+            if (at >= dstEnd) fail = true;                               // the loop stops at dstEnd with input left (:347, :366)
+            else for (uint32_t q = 0; q < len; q++) dst[at + q] = (uint8_t)(e >> (8 * q));
+        }
+        if (wave_ballot(fail) != 0) fail = true;
+        dstIdx += (long long)wave_bcast(incl, 63);
+        carry = stLast;
+    }
+    if (!fail && carry != 0) fail = true;                                // a two-byte alias cut by srcEnd
+    if (!fail && dstIdx > cap - count + srcEnd) fail = true;             // :366
+    if (fail) { if (lane == 0) { a.ok[b] = -KNZ_ERR_PROCESS_BLOCK; a.out_len[b] = 0; } return; }
+    const long long tail = count - srcEnd;                               // <= 4
+    if (lane < tail) dst[dstIdx + lane] = src[srcEnd + lane];
+    dstIdx += tail;
+    if (lane == 0) { a.ok[b] = 1; a.out_len[b] = (uint32_t)dstIdx; }
+}
+
+// ctx["dataType"] of every block from its magic number (v2/io/CompressedStream.go:811-819, internal/Magic.go:83-222):
+// 1 = BIN / MULTIMEDIA / EXE (a UTF stage declines), 0 = undefined
+__global__ void knz_block_datatype_kernel(uint32_t nblocks, const uint64_t* blk_off, const uint32_t* blk_len, uint8_t* blk_dt) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    uint32_t dt = 0;
+    if (blk_len[b] >= 4) {
+        const uint8_t* s = (const uint8_t*)blk_off[b];
+        const uint32_t key = ((uint32_t)s[0] << 24) | ((uint32_t)s[1] << 16) | ((uint32_t)s[2] << 8) | s[3];
+        const uint32_t k24 = key >> 8, k16 = key >> 16, sub = (key >> 8) & 0xFF;
+        bool known32 = false;
+        switch (key) {                                                   // the 32-bit magics GetMagicType knows; PDF / KNZ-like ones that set no type included
+            case 0x47494638u: case 0x504B0304u: case 0x377ABCAFu: case 0x89504E47u: case 0x7F454C46u: case 0xFEEDFACEu: case 0xCEFAEDFEu:
+            case 0xFEEDFACFu: case 0xCFFAEDFEu: case 0x28B52FFDu: case 0x81CFB2CEu: case 0x4D534346u: case 0x52494646u: case 0x664C6143u:
+            case 0xFD377A58u: case 0x4B414E5Au: case 0x52617221u: dt = 1; known32 = true; break;
+            case 0x25504446u: known32 = true; break;                     // PDF: recognised, none of the three classes
+            default: break;
+        }
+        if ((key & ~0x0Fu) == 0xFFD8FFE0u) dt = key == 0xFFD8FFE0u ? 1u : 0u;        // JPG: the class tests compare with the E0 form only
+        else if (k24 == 0x425A68u || k24 == 0x494433u) dt = 1;                       // BZIP2, MP3
+        else if (!known32) {
+            if (k16 == 0x1F8Bu || k16 == 0x424Du || k16 == 0x4D5Au) dt = 1;          // GZIP, BMP, WIN
+            else if ((k16 == 0x5034u || k16 == 0x5035u || k16 == 0x5036u) && (sub == 0x07 || sub == 0x0A || sub == 0x0D || sub == 0x20)) dt = 1;
+        }
+    }
+    blk_dt[b] = (uint8_t)dt;
+}

@@ -49,6 +49,7 @@ int knzo_entropy_decode(uint32_t type, const uint8_t* bits, uint64_t nbytes, uin
 // rc -1 = transform declined (Forward error => skipped by the sequence)
 int knzo_transform_forward(uint64_t t, const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap, uint64_t* out_n) {
     KNZO_TRY
+    tlsDataType = DT_UNDEFINED;                       // a transform object on its own has no ctx["dataType"]
     *out_n = transformForward1(t, src, (size_t)n, dst, (size_t)cap);
     return 0;
     KNZO_CATCH

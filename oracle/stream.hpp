@@ -18,7 +18,7 @@
 namespace knzo {
 
 // transform ids (Factory.go:31-53)
-enum : uint64_t { T_NONE = 0, T_BWT = 1, T_LZ = 3, T_ZRLT = 6, T_MTFT = 7, T_RANK = 8, T_SRT = 13, T_LZP = 14, T_LZX = 16 };
+enum : uint64_t { T_NONE = 0, T_BWT = 1, T_LZ = 3, T_ZRLT = 6, T_MTFT = 7, T_RANK = 8, T_SRT = 13, T_LZP = 14, T_LZX = 16, T_UTF = 17 };
 // entropy ids (EntropyCodecFactory.go:26-42)
 enum : uint32_t { E_NONE = 0, E_HUFFMAN = 1, E_FPAQ = 2, E_ANS0 = 5, E_ANS1 = 8 };
 
@@ -75,13 +75,14 @@ static inline uint64_t xxhash64(const uint8_t* data, size_t len, uint64_t seed) 
 
 // ---- single transform dispatch (Factory.go:97-185 newToken) ---------------------------------
 static inline bool transformSupported(uint64_t t) {
-    return t == T_NONE || t == T_BWT || t == T_LZ || t == T_LZX || t == T_ZRLT || t == T_MTFT || t == T_RANK || t == T_SRT || t == T_LZP;
+    return t == T_NONE || t == T_BWT || t == T_LZ || t == T_LZX || t == T_ZRLT || t == T_MTFT || t == T_RANK || t == T_SRT || t == T_LZP || t == T_UTF;
 }
 static inline size_t transformMaxEncodedLen(uint64_t t, size_t n) {
     switch (t) {
         case T_BWT: case T_RANK: case T_MTFT: return n + BWT_MAX_HEADER_SIZE;
         case T_LZ: case T_LZX: case T_LZP: return lzMaxEncodedLen(n);
         case T_SRT: return n + SRT_MAX_HEADER_SIZE;
+        case T_UTF: return n + 8192;
         default: return n;
     }
 }
@@ -100,6 +101,7 @@ static inline size_t transformForward1(uint64_t t, const uint8_t* src, size_t n,
         case T_RANK: return SBRT(2).forward(src, n, dst, cap);
         case T_SRT: return srtForward(src, n, dst, cap);
         case T_LZP: return lzpForward(src, n, dst, cap);
+        case T_UTF: return utfForward(src, n, dst, cap);
         default: throw KnzError(ERR_CREATE_CODEC, "Unknown transform type");
     }
 }
@@ -116,6 +118,7 @@ static inline size_t transformInverse1(uint64_t t, const uint8_t* src, size_t n,
         case T_RANK: return SBRT(2).inverse(src, n, dst, cap);
         case T_SRT: return srtInverse(src, n, dst, cap);
         case T_LZP: return lzpInverse(src, n, dst, cap);
+        case T_UTF: return utfInverse(src, n, dst, cap);
         default: throw KnzError(ERR_INVALID_CODEC, "Unknown transform type");
     }
 }
@@ -257,6 +260,19 @@ static inline uint32_t getMagicType(const uint8_t* src, size_t n) {
     }
     return 0;
 }
+static inline bool isDataMultimedia(uint32_t magic) {   // Magic.go:174-200
+    switch (magic) {
+        case 0xFFD8FFE0u: case 0x47494638u: case 0x89504E47u: case 0x52494646u: case 0x664C6143u: case 0x494433u: case 0x424Du:
+        case 0x5034u: case 0x5035u: case 0x5036u: return true;     // JPG GIF PNG RIFF FLAC MP3 BMP PBM PGM PPM
+        default: return false;
+    }
+}
+static inline bool isDataExecutable(uint32_t magic) {   // Magic.go:204-222
+    switch (magic) {
+        case 0x7F454C46u: case 0x4D5Au: case 0xFEEDFACEu: case 0xCEFAEDFEu: case 0xFEEDFACFu: case 0xCFFAEDFEu: return true;   // ELF WIN MAC x4
+        default: return false;
+    }
+}
 static inline bool isDataCompressed(uint32_t magic) {
     switch (magic) {
         case 0xFFD8FFE0u: case 0x47494638u: case 0x89504E47u: case 0x377ABCAFu: case 0x28B52FFDu: case 0x81CFB2CEu: case 0x4D534346u:
@@ -320,6 +336,13 @@ static inline void encodeBlock(const uint8_t* data, size_t blockLength, uint64_t
             skip = computeFirstOrderEntropy1024(blockLength, histo) >= INCOMPRESSIBLE_THRESHOLD;
         }
         if (skip) { transformType = T_NONE; entropyType = E_NONE; mode |= 0x80; }
+    }
+    {   // ctx["dataType"] from the block's magic number (:811-819); read by the UTF codec only on this path
+        const uint32_t magic = getMagicType(data, blockLength);
+        tlsDataType = DT_UNDEFINED;
+        if (isDataCompressed(magic)) tlsDataType = DT_BIN;
+        else if (isDataMultimedia(magic)) tlsDataType = DT_MULTIMEDIA;
+        else if (isDataExecutable(magic)) tlsDataType = DT_EXE;
     }
     Sequence t(transformType);
     size_t requiredSize = t.maxEncodedLen(blockLength);

@@ -12,9 +12,11 @@
 //   v2/transform/LZCodec.go:193-236 emitLengthLZ/readLengthLZ ; :238-246 hash ; :249-591 Forward (LZ and LZX)
 //     :593-607 findMatchLZX ; :621-778 inverseV6 ; :935-941 MaxEncodedLen
 //   v2/transform/LZCodec.go:982-1088 LZPCodec.Forward ; :1091-1190 Inverse ; :1192-1207 findMatch ; :1210-1216 MaxEncodedLen
+//   v2/transform/UTFCodec.go:84-265 Forward ; :268-383 Inverse ; :393-519 validateUTF ; :521-609 packUTF / unpackUTF1
 //   v2/transform/SRT.go:49-132 Forward ; :134-167 preprocess ; :172-259 Inverse ; :261-275 encodeHeader ; :277-312 decodeHeader
 #pragma once
 #include "entropy_utils.hpp"
+#include <algorithm>
 
 namespace knzo {
 
@@ -858,6 +860,192 @@ static inline size_t srtInverse(const uint8_t* src, size_t n, uint8_t* dst, size
         }
     }
     return (size_t)len;
+}
+
+// ---------------------------------------------------------------------------------------------
+// UTF codec (UTFCodec.go): UTF-8 code points -> 1- or 2-byte ranks by decreasing frequency, behind a map of the code points.
+// ctx["dataType"] (internal/Global.go:26-40) travels in a thread-local here: encodeBlock sets it from the block's magic number
+// (io/CompressedStream.go:811-819), a transform object used on its own sees DT_UNDEFINED.
+enum : int { DT_UNDEFINED = 0, DT_BIN = 6, DT_EXE = 5, DT_MULTIMEDIA = 4, DT_UTF8 = 8 };   // (distinct values; only equality matters)
+static thread_local int tlsDataType = DT_UNDEFINED;
+static const int UTF_MIN_BLOCKSIZE = 1024;
+
+static inline int utfSize(uint8_t b) {                       // _UTF_SIZES :31-48
+    if (b < 0x80) return 1;
+    if (b < 0xC2) return 0;
+    if (b < 0xE0) return 2;
+    if (b < 0xF0) return 3;
+    if (b < 0xF5) return 4;
+    return 0;
+}
+
+static inline bool utfValidate(const uint8_t* block, int count) {   // validateUTF :393-519
+    std::vector<int> freqs0(256, 0);
+    std::vector<int> freqs1(65536, 0);
+    const int end4 = count & -4;
+    uint8_t prv = 0;
+    auto rule1 = [&]() { int sum = freqs0[0xC0] + freqs0[0xC1]; for (int k = 0xF5; k < 256; k++) sum += freqs0[k]; return sum == 0; };
+    for (int i = 0; i < end4; i += 4) {
+        const uint8_t c0 = block[i], c1 = block[i + 1], c2 = block[i + 2], c3 = block[i + 3];
+        freqs0[c0]++; freqs0[c1]++; freqs0[c2]++; freqs0[c3]++;
+        freqs1[(prv << 8) | c0]++; freqs1[(c0 << 8) | c1]++; freqs1[(c1 << 8) | c2]++; freqs1[(c2 << 8) | c3]++;
+        prv = c3;
+        if ((i & 0x0FFF) == 0 && !rule1()) return false;
+    }
+    if (end4 != count) {
+        for (int i = end4; i < count; i++) { const uint8_t cur = block[i]; freqs0[cur]++; freqs1[(prv << 8) | cur]++; prv = cur; }
+        if (!rule1()) return false;
+    }
+    int sum = 0, sum2 = 0;
+    for (int i = 0; i < 256; i++) {
+        if (i < 0xA0 || i > 0xBF) sum += freqs1[(0xE0 << 8) | i];
+        if (i < 0x80 || i > 0x9F) sum += freqs1[(0xED << 8) | i];
+        if (i < 0x90 || i > 0xBF) sum += freqs1[(0xF0 << 8) | i];
+        if (i < 0x80 || i > 0x8F) sum += freqs1[(0xF4 << 8) | i];
+        if (i < 0x80 || i > 0xBF) {
+            for (int j = 0xC2; j <= 0xDF; j++) sum += freqs1[(j << 8) | i];
+            for (int j = 0xE1; j <= 0xEC; j++) sum += freqs1[(j << 8) | i];
+            sum += freqs1[(0xF1 << 8) | i] + freqs1[(0xF2 << 8) | i] + freqs1[(0xF3 << 8) | i];
+            sum += freqs1[(0xEE << 8) | i] + freqs1[(0xEF << 8) | i];
+        } else sum2 += freqs0[i];
+        if (sum != 0) return false;
+    }
+    return sum2 >= count / 8;
+}
+
+static inline int utfPack(const uint8_t* in, uint32_t& out) {       // packUTF :521-546
+    const int s = utfSize(in[0]);
+    switch (s) {
+        case 1: out = in[0]; break;
+        case 2: out = (1u << 19) | ((uint32_t)in[0] << 8) | in[1]; break;
+        case 3: out = (2u << 19) | (((uint32_t)in[0] & 0x0F) << 12) | (((uint32_t)in[1] & 0x3F) << 6) | ((uint32_t)in[2] & 0x3F); break;
+        case 4: out = (4u << 19) | (((uint32_t)in[0] & 0x07) << 18) | (((uint32_t)in[1] & 0x3F) << 12) | (((uint32_t)in[2] & 0x3F) << 6) | ((uint32_t)in[3] & 0x3F); break;
+        default: out = 0; break;
+    }
+    return s;
+}
+
+static inline int utfUnpack1(uint32_t in, uint8_t* out) {           // unpackUTF1 :578-609 (bitstream version >= 4)
+    const uint32_t sz = in >> 19;
+    if (sz == 0) { out[0] = (uint8_t)in; return 1; }
+    if (sz == 1) { out[0] = (uint8_t)(in >> 8); out[1] = (uint8_t)in; return 2; }
+    if (sz == 2) { out[0] = (uint8_t)(((in >> 12) & 0x0F) | 0xE0); out[1] = (uint8_t)(((in >> 6) & 0x3F) | 0x80); out[2] = (uint8_t)((in & 0x3F) | 0x80); return 3; }
+    if (sz >= 4 && sz <= 7) {
+        out[0] = (uint8_t)(((in >> 18) & 0x07) | 0xF0); out[1] = (uint8_t)(((in >> 12) & 0x3F) | 0x80);
+        out[2] = (uint8_t)(((in >> 6) & 0x3F) | 0x80); out[3] = (uint8_t)((in & 0x3F) | 0x80);
+        return 4;
+    }
+    return 0;
+}
+
+static inline size_t utfForward(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap) {   // :84-265
+    if (n == 0 || dstCap == 0) return 0;
+    if (n < (size_t)UTF_MIN_BLOCKSIZE) throw SkipTransform("Input block is too small");
+    if (dstCap < n + 8192) throw SkipTransform("Output buffer is too small");
+    const int count = (int)n;
+    bool mustValidate = true;
+    {
+        const int dt = tlsDataType;
+        if (dt != DT_UNDEFINED && dt != DT_UTF8) throw SkipTransform("UTF forward transform skip: not UTF");
+        mustValidate = dt != DT_UTF8;
+    }
+    int start = 0;
+    const uint32_t be32 = ((uint32_t)src[0] << 24) | ((uint32_t)src[1] << 16) | ((uint32_t)src[2] << 8) | src[3];
+    if ((be32 & 0x00FFFFFFu) == 0x00EFBBBFu) start = 3;
+    else while (start < 4 && utfSize(src[start]) == 0) start++;
+    if (mustValidate && !utfValidate(src + start, count - 4 - start)) throw SkipTransform("UTF forward transform skip: not UTF");
+    tlsDataType = DT_UTF8;
+    std::vector<int32_t> aliasMap((size_t)1 << 22, 0);
+    struct Sd { int32_t sym, freq; };
+    std::vector<Sd> symb(32768);
+    int nsym = 0;
+    for (int i = start; i < count - 4;) {
+        uint32_t val;
+        const int s = utfPack(src + i, val);
+        bool res = s != 0;
+        res = res && (s != 3 || (src[i + 2] & 0xC0) == 0x80);
+        res = res && (s != 4 || ((((uint32_t)src[i + 2] << 8) | src[i + 3]) & 0xC0C0u) == 0x8080u);
+        if (aliasMap[val] == 0) {
+            if (nsym < 32768) symb[nsym].sym = (int32_t)val;      // (Go would panic past the array only after res turned false: n < 32768 is tested first)
+            nsym++;
+            res = res && nsym < 32768;
+        }
+        if (!res) throw SkipTransform("UTF forward transform skip: invalid or too complex");
+        aliasMap[val]++;
+        i += s;
+    }
+    if (nsym == 0) throw SkipTransform("UTF forward transform skip: not UTF");
+    const int maxTarget = count - count / 10;
+    if (3 * nsym + 6 >= maxTarget) throw SkipTransform("UTF forward transform skip: no improvement");
+    for (int i = 0; i < nsym; i++) symb[i].freq = aliasMap[symb[i].sym];
+    std::stable_sort(symb.begin(), symb.begin() + nsym, [](const Sd& a, const Sd& b) { return a.freq != b.freq ? a.freq < b.freq : a.sym < b.sym; });
+    int dstIdx = 2;
+    dst[dstIdx++] = (uint8_t)(nsym >> 8);
+    dst[dstIdx++] = (uint8_t)nsym;
+    int64_t estimate = dstIdx + 6;
+    for (int i = 0; i < nsym; i++) {
+        const int r = nsym - 1 - i;
+        const int32_t s = symb[r].sym;
+        dst[dstIdx] = (uint8_t)(s >> 16); dst[dstIdx + 1] = (uint8_t)(s >> 8); dst[dstIdx + 2] = (uint8_t)s;
+        dstIdx += 3;
+        if (i < 128) { estimate += symb[r].freq; aliasMap[s] = i; }
+        else { estimate += 2 * (int64_t)symb[r].freq; aliasMap[s] = 0x10080 | ((i << 1) & 0xFF00) | (i & 0x7F); }
+    }
+    if (estimate >= maxTarget) throw SkipTransform("UTF forward transform skip: no improvement");
+    for (int i = 0; i < start; i++) dst[dstIdx++] = src[i];
+    int srcIdx = start;
+    while (srcIdx < count - 4) {
+        uint32_t val;
+        srcIdx += utfPack(src + srcIdx, val);
+        const int32_t alias = aliasMap[val];
+        dst[dstIdx++] = (uint8_t)alias;
+        dst[dstIdx] = (uint8_t)(alias >> 8);
+        dstIdx += alias >> 16;
+    }
+    dst[0] = (uint8_t)start;
+    dst[1] = (uint8_t)(srcIdx - (count - 4));
+    while (srcIdx < count) dst[dstIdx++] = src[srcIdx++];
+    if (dstIdx >= maxTarget) throw SkipTransform("UTF forward transform skip: no improvement");
+    return (size_t)dstIdx;
+}
+
+static inline size_t utfInverse(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap) {   // :268-383
+    if (n == 0 || dstCap == 0) return 0;
+    if (n < 4) throw KnzError(ERR_PROCESS_BLOCK, "Input block is too small");
+    const int64_t count = (int64_t)n;
+    const int start = src[0] & 0x03, adjust = src[1] & 0x03;
+    const int nsym = ((int)src[2] << 8) + src[3];
+    if (nsym == 0 || nsym >= 32768 || 4 + 3 * (int64_t)nsym > count) throw KnzError(ERR_PROCESS_BLOCK, "UTF inverse transform: invalid map size");
+    struct Sym { uint8_t value[4]; uint8_t length; };
+    std::vector<Sym> m(32768, Sym{{0, 0, 0, 0}, 0});
+    int64_t srcIdx = 4;
+    for (int i = 0; i < nsym; i++) {
+        const uint32_t s = ((uint32_t)src[srcIdx] << 16) | ((uint32_t)src[srcIdx + 1] << 8) | src[srcIdx + 2];
+        const int sl = utfUnpack1(s, m[i].value);
+        if (sl == 0) throw KnzError(ERR_PROCESS_BLOCK, "UTF inverse transform failed: invalid UTF alias");
+        m[i].length = (uint8_t)sl;
+        srcIdx += 3;
+    }
+    const int64_t srcEnd = count - 4 + adjust;
+    int64_t dstIdx = 0;
+    const int64_t dstEnd = (int64_t)dstCap - 4;
+    if (dstEnd < 0) throw KnzError(ERR_PROCESS_BLOCK, "UTF inverse transform failed: invalid output block size");
+    if (srcEnd < srcIdx || srcEnd > count || srcIdx + start > count) throw KnzError(ERR_PROCESS_BLOCK, "UTF inverse transform failed: invalid data");
+    for (int i = 0; i < start; i++) { if (dstIdx >= (int64_t)dstCap) throw KnzError(ERR_PROCESS_BLOCK, "index out of range"); dst[dstIdx++] = src[srcIdx++]; }
+    while (srcIdx < srcEnd && dstIdx < dstEnd) {
+        int alias = src[srcIdx++];
+        if (alias >= 128) {
+            if (srcIdx >= srcEnd) throw KnzError(ERR_PROCESS_BLOCK, "UTF inverse transform failed: invalid data");
+            alias = ((int)src[srcIdx] << 7) + (alias & 0x7F);
+            srcIdx++;
+        }
+        const Sym& s = m[alias];
+        memcpy(dst + dstIdx, s.value, 4);                      // copy(dst[dstIdx:], s.value[:4]): dstIdx < dstEnd = len - 4
+        dstIdx += s.length;
+    }
+    if (srcIdx < srcEnd || dstIdx > (int64_t)dstCap - count + srcEnd) throw KnzError(ERR_PROCESS_BLOCK, "UTF inverse transform failed: invalid data");
+    for (int64_t i = srcEnd; i < count; i++) dst[dstIdx++] = src[srcIdx++];
+    return (size_t)dstIdx;
 }
 
 } // namespace knzo

@@ -16,9 +16,9 @@ _LIB = None
 
 # transform / entropy ids (v2/transform/Factory.go:31-53, v2/entropy/EntropyCodecFactory.go:26-42)
 T_NONE, T_BWT, T_LZ, T_ZRLT, T_MTFT, T_RANK, T_LZX = 0, 1, 3, 6, 7, 8, 16
-T_SRT, T_LZP = 13, 14
+T_SRT, T_LZP, T_UTF = 13, 14, 17
 E_NONE, E_HUFFMAN, E_FPAQ, E_ANS0, E_ANS1 = 0, 1, 2, 5, 8
-_TNAMES = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "LZP": 14, "LZX": 16}
+_TNAMES = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "LZP": 14, "LZX": 16, "UTF": 17}
 _ENAMES = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5, "ANS1": 8}
 
 

@@ -242,7 +242,47 @@ def _transform_inputs(zrlt=False):
     yield "binary", (rng.integers(0, 256, 50000, dtype=np.uint8) & rng.integers(0, 256, 50000, dtype=np.uint8) & rng.integers(0, 256, 50000, dtype=np.uint8)).tobytes()
 
 
-_TID = {"BWT": 1, "ZRLT": 6, "MTFT": 7, "RANK": 8, "LZ": 3, "LZX": 16, "SRT": 13, "LZP": 14}
+_TID = {"BWT": 1, "ZRLT": 6, "MTFT": 7, "RANK": 8, "LZ": 3, "LZX": 16, "SRT": 13, "LZP": 14, "UTF": 17}
+
+
+def utf_text(n, seed, kinds=(0, 1, 2, 3)):
+    """UTF-8 text: ASCII, Cyrillic (2 bytes), CJK (3 bytes), emoji (4 bytes) words."""
+    r = np.random.default_rng(seed)
+    pools = {0: list(range(0x20, 0x7F)), 1: list(range(0x400, 0x450)), 2: list(range(0x4E00, 0x4E00 + 3000)), 3: [0x1F600 + i for i in range(60)]}
+    out, total = [], 0
+    while total < n:
+        k = kinds[int(r.integers(0, len(kinds)))]
+        w = "".join(chr(pools[k][int(i)]) for i in r.integers(0, len(pools[k]), int(r.integers(1, 12))))
+        b = (w + " ").encode("utf-8")
+        out.append(b)
+        total += len(b)
+    return b"".join(out)[:n]
+
+
+def utf_inputs():
+    yield "mix", utf_text(50000, 1)
+    yield "cyr", utf_text(30000, 2, (0, 1, 1, 1))
+    yield "ascii", utf_text(20000, 3, (0,))                             # declined: under 1/8 continuation bytes
+    yield "cjk", utf_text(120000, 4, (2, 2, 0))
+    yield "bomlike", b"x\xef\xbb\xbf" + utf_text(5000, 5, (1,))          # the BOM test looks at bytes 1..3
+    yield "trunc1", utf_text(40000, 6, (1, 2))[1:]                      # starts inside a code point
+    yield "trunc2", utf_text(40000, 7, (2, 3))[2:-1]                    # ... and ends inside one
+    yield "small", utf_text(1024, 8, (1,))
+    yield "tiny", utf_text(1000, 9, (1,))                               # under the minimum block size
+    bad = bytearray(utf_text(30000, 10, (1, 2)))
+    bad[15000] = 0xC0
+    yield "badbyte", bytes(bad)
+    bad = bytearray(utf_text(30000, 11, (1, 2)))
+    bad[15001] = 0x41 if bad[15000] >= 0xC2 else bad[15001]            # (possibly) a lead byte without its continuation
+    yield "badpair", bytes(bad)
+    bad = bytearray(utf_text(30000, 12, (2,)))
+    for i in range(len(bad) - 3, 100, -1):
+        if bad[i] >= 0xE0:
+            bad[i + 2] = 0x20                                           # third byte of a 3-byte sequence
+            break
+    yield "badthird", bytes(bad)
+    yield "magic", bytes([0x1F, 0x8B]) + utf_text(30000, 13, (1,))      # gzip magic (only through the stream API)
+    yield "binary", np.random.default_rng(14).integers(0, 256, 20000, dtype=np.uint8).tobytes()
 
 
 def check_transform(be, tname, max_len=1 << 30):
@@ -251,7 +291,7 @@ def check_transform(be, tname, max_len=1 << 30):
     t = K.ByteTransform(c, tname)
     tid = _TID[tname]
     applied = 0
-    for name, data in transform_inputs(zrlt=(tname == "ZRLT"), max_len=max_len):
+    for name, data in (utf_inputs() if tname == "UTF" else transform_inputs(zrlt=(tname == "ZRLT"), max_len=max_len)):
         g = t.forward(data)
         o = O.transform_forward(tid, data)
         assert (g is None) == (o is None), (tname, name)
@@ -261,7 +301,7 @@ def check_transform(be, tname, max_len=1 << 30):
         applied += 1
         back = t.inverse(o, len(data) + max(512, len(data) >> 4))
         assert back == data, (tname, name)
-    assert applied >= 6
+    assert applied >= (5 if tname == "UTF" else 6)
     c.close()
 
 
@@ -407,6 +447,27 @@ def check_huffman_split_walk(be):
         del os.environ["KNZ_HUF_SPLIT_WALK"]
 
 
+def check_utf_streams(be):
+    """UTF stage inside streams: UTF-8 blocks, a block whose magic number sets ctx["dataType"] (the stage declines), UTF twice in
+    a sequence (the second stage runs without validateUTF: the sequential-walk form on the device), the -l 5 tail behind it."""
+    bs = 1 << 16
+    data = (utf_text(bs, 21, (1, 1, 0)) + bytes([0x1F, 0x8B]) + utf_text(bs - 2, 22, (1,)) + b"MZ" + utf_text(bs - 2, 23, (2,)) +
+            utf_text(bs, 24, (0,)) + utf_text(bs // 2 + 77, 25, (3, 1)))
+    for transform, entropy in (("UTF", "HUFFMAN"), ("UTF", "NONE"), ("UTF+UTF", "ANS0"), ("UTF+BWT+RANK+ZRLT", "ANS0"), ("UTF+LZ", "HUFFMAN")):
+        exp = O.compress(data, transform, entropy, bs)
+        c = K.Codec(transform, entropy, bs, lib=be.lib)
+        src, ks = be.to_dev(data)
+        cap = 2 * len(data) + (1 << 20)
+        dst, kd = be.empty(cap)
+        nb = c.dev_compress(src, len(data), dst, cap)
+        assert be.to_host(kd, nb) == exp, (transform, entropy)
+        out, ko = be.empty(len(data) + 64)
+        assert c.dev_decompress(dst, nb, out, len(data) + 64) == len(data)
+        assert be.to_host(ko, len(data)) == data
+        c.close()
+    assert len(O.compress(data, "UTF", "NONE", bs)) < len(data) - 30000       # the stage applied to the UTF-8 blocks
+
+
 def check_concurrent_handles(be, threads=8, rounds=3):
     """the library is thread-safe for concurrent calls on different handles (one handle per goroutine / Writer).
     Several host threads, each with its own handle and its own configuration, compress and decompress at the same time."""
@@ -472,7 +533,12 @@ def check_skip_blocks(be, light=False):
 
 
 def _fuzz_data(r, n):
-    kind = int(r.integers(0, 8))
+    kind = int(r.integers(0, 10))
+    if kind >= 8:                                    # UTF-8 text (Cyrillic / CJK / emoji / ASCII words), sometimes cut inside a code point
+        kinds = [(1,), (1, 1, 0), (2,), (3, 1), (0, 1, 2, 3)][int(r.integers(0, 5))]
+        t = utf_text(n + 3, int(r.integers(0, 1 << 30)), kinds)
+        o = int(r.integers(0, 3))
+        return t[o:o + n]
     if kind == 0:
         return r.integers(0, 256, n, dtype=np.uint8).tobytes()
     if kind == 1:
@@ -505,7 +571,7 @@ def check_fuzz(be, cases, seed, max_n, heavy_max_n=None):
     """Seeded differential test: random transform sequences x entropy codecs x block sizes x checksum sizes x data shapes,
     device stream == oracle stream, the device decodes the oracle's stream, the oracle decodes the device's."""
     r = np.random.default_rng(seed)
-    tnames = ["NONE", "BWT", "RANK", "MTFT", "ZRLT", "LZ", "LZX", "LZP", "SRT"]
+    tnames = ["NONE", "BWT", "RANK", "MTFT", "ZRLT", "LZ", "LZX", "LZP", "SRT", "UTF"]
     enames = ["NONE", "HUFFMAN", "ANS0", "ANS1", "FPAQ"]
     heavy = {"BWT", "RANK", "MTFT", "SRT"}          # slow on the emulator (cross-lane heavy): smaller inputs there
     done = 0

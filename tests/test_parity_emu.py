@@ -58,7 +58,7 @@ def test_multi_gpu_assemble(be, ranks):
     P.check_assemble(be, "ANS0", 1 << 16, 3 * (1 << 16) + 5, ranks)
 
 
-@pytest.mark.parametrize("tname", ["ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX", "SRT", "LZP"])
+@pytest.mark.parametrize("tname", ["ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX", "SRT", "LZP", "UTF"])
 def test_transform_objects_bit_exact(be, tname):
     # the register-resident SBRT list uses ~12 cross-lane operations per byte: keep the emulated inputs small
     P.check_transform(be, tname, max_len=4096 if tname in ("RANK", "MTFT") else (32768 if tname == "SRT" else 1 << 30))
@@ -83,6 +83,10 @@ def test_ans1_table_decoder(be):
 
 def test_huffman_split_walk(be):
     P.check_huffman_split_walk(be)
+
+
+def test_utf_streams(be):
+    P.check_utf_streams(be)
 
 
 def test_skip_blocks_option(be):

@@ -93,7 +93,7 @@ def test_stress_inputs(be):
     P.check_stream(be, "NONE", "HUFFMAN", 1 << 20, len(data))
 
 
-@pytest.mark.parametrize("tname", ["ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX", "SRT", "LZP"])
+@pytest.mark.parametrize("tname", ["ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX", "SRT", "LZP", "UTF"])
 def test_transform_objects_bit_exact(be, tname):
     P.check_transform(be, tname)
 
@@ -167,6 +167,10 @@ def test_huffman_split_walk(be):
 
 def test_concurrent_handles(be):
     P.check_concurrent_handles(be)
+
+
+def test_utf_streams(be):
+    P.check_utf_streams(be)
 
 
 def test_skip_blocks_option(be):
