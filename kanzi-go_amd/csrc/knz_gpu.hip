@@ -208,6 +208,27 @@ struct EncodeBatch {
     uint64_t total_bits;     // result
 };
 
+// block tables of an encode batch: absolute device addresses; blocks <= 15 bytes are copy blocks (CompressedStream.go:773-776)
+struct EncTablesArgs {
+    uint32_t nblocks; uint64_t src; uint64_t n; uint64_t bs; int payload_only; int none_only;
+    uint64_t* blk_off; uint32_t* blk_len; uint32_t* blk_src_len; uint8_t* blk_skip; uint8_t* blk_copy; int32_t* blk_status;
+    uint8_t* active; uint8_t* side;
+};
+__global__ void knz_enc_tables_kernel(EncTablesArgs a) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.nblocks) return;
+    const uint64_t rest = a.n - (uint64_t)b * a.bs;
+    const uint32_t len = (uint32_t)(rest < a.bs ? rest : a.bs);
+    const bool copy = len <= 15 && !a.payload_only;
+    a.blk_off[b] = a.src + (uint64_t)b * a.bs;
+    a.blk_len[b] = len;
+    a.blk_src_len[b] = a.payload_only ? (len > 16 ? len : 16u) : len;   // a bare EntropyEncoder has no copy-block rule
+    a.blk_copy[b] = copy ? 1 : 0;
+    a.blk_skip[b] = (copy || a.none_only) ? 0x7F : 0xFF;                // NullTransform always applies: slot 0 cleared
+    a.blk_status[b] = 0;
+    if (a.active) { a.active[b] = (copy || a.none_only) ? 0 : 1; a.side[b] = 0; }
+}
+
 static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     const knz_cfg& cfg = h->cfg;
     if (!transform_on_device(cfg.transform) || !entropy_on_device(cfg.entropy))
@@ -234,36 +255,16 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
 
     // block tables: absolute device addresses; blocks <= 15 bytes are copy blocks (CompressedStream.go:773-776)
     XfBatch xb;
-    {
-        std::vector<uint64_t> off(nblocks);
-        std::vector<uint32_t> len(nblocks);
-        std::vector<uint8_t> skip(nblocks), active(nblocks), side(nblocks, 0), copyv(nblocks);
+    if (nblocks) {   // block tables, filled on the device: no staging copies, no host synchronisation in front of the first kernel
         const bool noneOnly = cfg.transform == 0;
-        for (uint32_t b = 0; b < nblocks; b++) {
-            off[b] = (uint64_t)eb.d_src + (uint64_t)b * bs;
-            len[b] = (uint32_t)std::min<uint64_t>(bs, eb.n - (uint64_t)b * bs);
-            const bool copy = len[b] <= 15 && !eb.payload_only;
-            copyv[b] = copy ? 1 : 0;
-            active[b] = (copy || noneOnly) ? 0 : 1;
-            skip[b] = (copy || noneOnly) ? 0x7F : 0xFF;       // NullTransform always applies: slot 0 cleared
-        }
-        if (nblocks) {
-            const uint64_t stride = ((uint64_t)maxPost + 64 + 15) & ~(uint64_t)15;
-            if (!noneOnly && xf_alloc(h, xb, nblocks, stride)) return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
-            HIP_OK(hipMemcpyAsync(h->blk_off.p, off.data(), 8 * (size_t)nblocks, hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemcpyAsync(h->blk_len.p, len.data(), 4 * (size_t)nblocks, hipMemcpyHostToDevice, st));
-            std::vector<uint32_t> srclen(len);
-            if (eb.payload_only) for (auto& v : srclen) v = std::max<uint32_t>(v, 16);   // a bare EntropyEncoder has no copy-block rule
-            HIP_OK(hipMemcpyAsync(h->blk_src_len.p, srclen.data(), 4 * (size_t)nblocks, hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemcpyAsync(h->blk_skip.p, skip.data(), nblocks, hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemcpyAsync(h->blk_copy.p, copyv.data(), nblocks, hipMemcpyHostToDevice, st));
-            if (!noneOnly) {
-                HIP_OK(hipMemcpyAsync(xb.active, active.data(), nblocks, hipMemcpyHostToDevice, st));
-                HIP_OK(hipMemcpyAsync(xb.side, side.data(), nblocks, hipMemcpyHostToDevice, st));
-            }
-            HIP_OK(hipMemsetAsync(h->blk_status.p, 0, 4 * (size_t)nblocks, st));
-            HIP_OK(hipStreamSynchronize(st)); // the host vectors go out of scope
-        }
+        const uint64_t stride = ((uint64_t)maxPost + 64 + 15) & ~(uint64_t)15;
+        if (!noneOnly && xf_alloc(h, xb, nblocks, stride)) return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
+        EncTablesArgs ta;
+        ta.nblocks = nblocks; ta.src = (uint64_t)eb.d_src; ta.n = eb.n; ta.bs = bs; ta.payload_only = eb.payload_only; ta.none_only = noneOnly ? 1 : 0;
+        ta.blk_off = h->blk_off.as<uint64_t>(); ta.blk_len = h->blk_len.as<uint32_t>(); ta.blk_src_len = h->blk_src_len.as<uint32_t>();
+        ta.blk_skip = h->blk_skip.as<uint8_t>(); ta.blk_copy = h->blk_copy.as<uint8_t>(); ta.blk_status = h->blk_status.as<int32_t>();
+        ta.active = noneOnly ? nullptr : xb.active; ta.side = noneOnly ? nullptr : xb.side;
+        hipLaunchKernelGGL(knz_enc_tables_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, st, ta);
     }
     const bool skipOpt = (cfg.flags & KNZ_FLAG_SKIP_BLOCKS) != 0 && !eb.payload_only && nblocks != 0;
     if (skipOpt) {                                                       // -s: incompressible blocks become copy blocks (:778-800)
