@@ -161,6 +161,12 @@ struct WalkBlocksArgs {
     uint64_t* chunk_bit;          // [nblocks*CPB] bit position of each chunk's first bit
     int32_t* blk_status;          // [nblocks]
     uint64_t* blk_end_bit;        // [nblocks] bit position just past the entropy payload
+    // knz_dec_block_headers_kernel only, when the blocks decode straight to their place (no transform stage): the output placement
+    // and the checks the host would make between the walk and the decode (Reader.processBlock :1707-1710, capacity)
+    uint32_t check_out;           // 1: fill out_off and fold the checks into blk_status
+    uint64_t* out_off;            // [nblocks] out_base + b * out_stride
+    uint64_t out_base, out_stride, out_cap;
+    uint32_t stream_block_size;
 };
 
 // Skips one signed Exp-Golomb code (ExpGolombCodec.go:159-190): '1' or L zeros, 1, L+1 bits.

@@ -573,6 +573,11 @@ __global__ __launch_bounds__(64) void knz_dec_block_headers_kernel(WalkBlocksArg
     int32_t status = h.status;
     const uint32_t chunkSize = (a.entropy == KNZ_E_ANS1 || a.entropy == KNZ_E_FPAQ) ? (4u << 20) : (uint32_t)KNZ_HUF_CHUNK;
     if (status == 0 && (h.preLen + chunkSize - 1) / chunkSize > a.chunks_per_block) status = KNZ_ERR_BLOCK_SIZE;
+    if (a.check_out) {
+        if (status == 0 && (h.preLen > a.stream_block_size || (h.preLen > a.out_stride && b + 1 < a.nblocks))) status = KNZ_ERR_PROCESS_BLOCK;   // :1707-1710
+        if (status == 0 && (uint64_t)b * a.out_stride + h.preLen > a.out_cap) status = KNZ_ERR_WRITE_FILE;                                    // destination too small
+        if (threadIdx.x == 0) a.out_off[b] = a.out_base + (uint64_t)b * a.out_stride;
+    }
     if (threadIdx.x == 0) {
         a.blk_pre_len[b] = h.preLen;
         a.blk_mode[b] = (uint8_t)h.mode;
