@@ -256,7 +256,7 @@ def main():
         ach = alg / 1e9 / (dur_ms / 1e3) if dur_ms > 0 else 0.0
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/, see its _how)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_config2_v3.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_config2_v4.json")))
             if args.config == "huffman" and world == 1 and not args.size and dom in pm["kernels"]:
                 traffic = pm["kernels"][dom]["hbm_bytes_corrected"]
         except Exception:
