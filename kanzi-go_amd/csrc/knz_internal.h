@@ -30,6 +30,7 @@ struct Handle {
     DevBuf stage_in, stage_out;       // host-pointer entry points stage through these
     DevBuf dec_tables;                // decoder per-chunk positions
     DevBuf utf_map, utf_syms, utf_ranks, utf_inv, utf_bits, blk_dt;   // UTF codec: alias table / code points / ranks / inverse map / walk bitmap, ctx["dataType"] per block
+    DevBuf srt_tab, srt_tmp, srt_ptrs;                               // parallel SRT forward: per-block tables, MTFT ranks, pointer / dummy arrays
     DevBuf blk_copy;                                                 // [nblocks] 1 = copy block (<= 15 bytes, or skipped by -s)
     DevBuf huf_stfreq, huf_stsym, huf_stlen, huf_stcnt, huf_stmax;   // sorted chunk statistics between the Huffman encode kernels
     size_t huf_fallback_n = 0;        // chunks covered by huf_fallback in the last decode batch

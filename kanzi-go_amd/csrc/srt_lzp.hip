@@ -165,6 +165,141 @@ __global__ __launch_bounds__(64) void knz_srt_forward_kernel(XfArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// SRT forward without the chain. The rank SRT writes for a run head is the move-to-front rank of that position, and a
+// move-to-front rank does not depend on how the list started except at a symbol's first occurrence (seen symbols are always in
+// front of unseen ones): so the ranks are the MTFT ranks of the segment-parallel knz_sbrt_* kernels (mode 1), with the first
+// occurrence of the k-th new symbol replaced by k, and every byte that is not a run head has MTFT rank 0 anyway. What is left is
+// SRT's layout: a stable partition of the positions by symbol (bucket of c = its ranks in order), done per 8 KiB segment with
+// per-segment symbol counts, a scan over the segments and a match-any inside each row of 64 positions.
+struct SrtParArgs {
+    uint32_t nblocks, segs_per_block;
+    const uint64_t* in_ptr; const uint32_t* in_len; const uint64_t* out_ptr; uint32_t out_cap;
+    uint32_t* out_len; int32_t* ok; const uint8_t* active;
+    uint32_t* tab;                 // [nblocks * KNZ_SRT_TAB]: start[256], firstPos[256], firstRank[256], hs
+    const uint64_t* rank_ptr;      // [nblocks] MTFT ranks of every position (knz_sbrt_apply_kernel<1>)
+    int32_t* seg_cnt;              // [nblocks * segs_per_block * 256]
+};
+#define KNZ_SRT_TAB (3 * 256 + 4)
+
+__global__ __launch_bounds__(256) void knz_srt_stats_kernel(SrtParArgs a) {
+    __shared__ int s_freq[256];
+    __shared__ uint32_t s_first[256];
+    __shared__ uint32_t s_hoff[257];
+    const int c = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (!a.active[b]) return;
+    const uint32_t n = a.in_len[b];
+    const uint8_t* src = (const uint8_t*)a.in_ptr[b];
+    uint8_t* dst = (uint8_t*)a.out_ptr[b];
+    if (n == 0) { if (c == 0) { a.ok[b] = 1; a.out_len[b] = 0; } return; }
+    if ((uint64_t)a.out_cap < (uint64_t)n + KNZ_SRT_HEADER_MAX) { if (c == 0) { a.ok[b] = 0; a.out_len[b] = 0; } return; }   // SRT.go:58-60
+    s_freq[c] = 0; s_first[c] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t i = c; i < n; i += 256) { const uint32_t v = src[i]; atomicAdd(&s_freq[v], 1); atomicMin(&s_first[v], i); }
+    __syncthreads();
+    const int f = s_freq[c];
+    const uint32_t fp = s_first[c];
+    uint32_t before = 0, ra = 0;
+    for (int d = 0; d < 256; d++) {
+        const int fd = s_freq[d];
+        if (fd > 0 && (fd > f || (fd == f && d < c))) before += (uint32_t)fd;      // buckets by decreasing frequency, ties by symbol (:134-167)
+        if (fd > 0 && s_first[d] < fp) ra++;
+    }
+    uint32_t hl = 1;
+    for (uint32_t v = (uint32_t)f; v >= 128; v >>= 7) hl++;
+    s_hoff[c + 1] = hl;
+    __syncthreads();
+    if (c == 0) { s_hoff[0] = 0; for (int d = 1; d <= 256; d++) s_hoff[d] += s_hoff[d - 1]; }
+    __syncthreads();
+    {
+        uint32_t v = (uint32_t)f, o = s_hoff[c];                                  // encodeHeader :261-275
+        while (v >= 128) { dst[o++] = (uint8_t)(0x80 | (v & 0x7F)); v >>= 7; }
+        dst[o] = (uint8_t)v;
+    }
+    uint32_t* t = a.tab + (size_t)b * KNZ_SRT_TAB;
+    t[c] = before; t[256 + c] = fp; t[512 + c] = ra;
+    if (c == 0) { t[768] = s_hoff[256]; a.ok[b] = 1; a.out_len[b] = n + s_hoff[256]; }
+}
+
+__global__ __launch_bounds__(64) void knz_srt_seg_count_kernel(SrtParArgs a) {
+    __shared__ int s_cnt[256];
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x / a.segs_per_block, s = blockIdx.x % a.segs_per_block;
+    if (!a.active[b]) return;
+    const uint32_t n = a.in_len[b];
+    const uint32_t lo = s * KNZ_SEG;
+    int32_t* out = a.seg_cnt + (size_t)blockIdx.x * 256;
+    for (int i = lane; i < 256; i += 64) s_cnt[i] = 0;
+    wave_sync();
+    if (lo < n) {
+        const uint32_t hi = min(n, lo + KNZ_SEG);
+        const uint8_t* src = (const uint8_t*)a.in_ptr[b];
+        for (uint32_t i = lo + lane; i < hi; i += 64) atomicAdd(&s_cnt[src[i]], 1);
+    }
+    wave_sync();
+    for (int i = lane; i < 256; i += 64) out[i] = s_cnt[i];
+}
+
+__global__ __launch_bounds__(256) void knz_srt_seg_scan_kernel(SrtParArgs a) {
+    const uint32_t b = blockIdx.x;
+    if (!a.active[b]) return;
+    const int c = threadIdx.x;
+    const uint32_t nseg = (a.in_len[b] + KNZ_SEG - 1) / KNZ_SEG;
+    int run = 0;
+    for (uint32_t s = 0; s < nseg; s++) {
+        int32_t* p = a.seg_cnt + ((size_t)b * a.segs_per_block + s) * 256 + c;
+        const int v = *p;
+        *p = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(64) void knz_srt_scatter_kernel(SrtParArgs a) {
+    __shared__ uint32_t s_pos[256];                                               // next free entry of every bucket, for this segment
+    __shared__ uint32_t s_firstPos[256];
+    __shared__ uint8_t s_firstRank[256];
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x / a.segs_per_block, s = blockIdx.x % a.segs_per_block;
+    if (!a.active[b] || a.ok[b] != 1) return;
+    const uint32_t n = a.in_len[b];
+    const uint32_t lo = s * KNZ_SEG;
+    if (lo >= n) return;
+    const uint32_t hi = min(n, lo + KNZ_SEG);
+    const uint8_t* src = (const uint8_t*)a.in_ptr[b];
+    const uint8_t* rk = (const uint8_t*)a.rank_ptr[b];
+    const uint32_t* t = a.tab + (size_t)b * KNZ_SRT_TAB;
+    uint8_t* out = (uint8_t*)a.out_ptr[b] + t[768];
+    const int32_t* pre = a.seg_cnt + (size_t)blockIdx.x * 256;
+    for (int i = lane; i < 256; i += 64) { s_pos[i] = t[i] + (uint32_t)pre[i]; s_firstPos[i] = t[256 + i]; s_firstRank[i] = (uint8_t)t[512 + i]; }
+    wave_sync();
+    for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        const bool valid = i < hi;
+        const uint32_t c = valid ? src[i] : 0u;
+        uint32_t r = valid ? rk[i] : 0u;
+        if (valid && i == s_firstPos[c]) r = s_firstRank[c];                      // the k-th new symbol has rank k (:66-75)
+        // lanes of this row with my symbol
+        uint64_t peers = wave_ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+            const uint64_t bal = wave_ballot(((c >> bit) & 1) != 0);
+            peers &= ((c >> bit) & 1) ? bal : ~bal;
+        }
+        const uint32_t base = valid ? s_pos[c] : 0u;
+        const uint32_t before = (uint32_t)__popcll(peers & (((uint64_t)1 << lane) - 1));
+        if (valid) out[base + before] = (uint8_t)r;
+        wave_sync_lds();                                                          // every lane has read s_pos before it moves
+        if (valid && (peers >> lane) == 1) s_pos[c] = base + (uint32_t)__popcll(peers);   // the last lane of the group
+        wave_sync_lds();
+    }
+}
+
+__global__ void knz_fill_ptrs_kernel(uint32_t nblocks, uint64_t base, uint64_t stride, uint64_t* ptrs) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nblocks) ptrs[b] = base + (uint64_t)b * stride;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void knz_srt_inverse_kernel(XfArgs a) {
     __shared__ int s_freq[256];
     __shared__ uint8_t s_hdr[KNZ_SRT_HEADER_MAX];

@@ -447,6 +447,18 @@ def check_huffman_split_walk(be):
         del os.environ["KNZ_HUF_SPLIT_WALK"]
 
 
+def check_srt_chain_form(be):
+    """SRT forward has two forms: MTFT ranks + stable partition by symbol (default), or the reference's list walk by one wave
+    per block; KNZ_SRT_CHAIN forces the second."""
+    import os
+    os.environ["KNZ_SRT_CHAIN"] = "1"
+    try:
+        check_transform(be, "SRT", max_len=20000)
+        check_stream(be, "BWT+SRT+ZRLT", "ANS0", 1 << 14, 40000)
+    finally:
+        del os.environ["KNZ_SRT_CHAIN"]
+
+
 def check_utf_streams(be):
     """UTF stage inside streams: UTF-8 blocks, a block whose magic number sets ctx["dataType"] (the stage declines), UTF twice in
     a sequence (the second stage runs without validateUTF: the sequential-walk form on the device), the -l 5 tail behind it."""

@@ -85,6 +85,10 @@ def test_huffman_split_walk(be):
     P.check_huffman_split_walk(be)
 
 
+def test_srt_chain_form(be):
+    P.check_srt_chain_form(be)
+
+
 def test_utf_streams(be):
     P.check_utf_streams(be)
 
