@@ -247,16 +247,31 @@ struct Ans0DecArgs {
 
 #define KNZ_ANS0_DEC_CHUNKS 8
 
-__global__ __launch_bounds__(64) void knz_ans0_decode_kernel(Ans0DecArgs a) {
-    __shared__ uint8_t s_f2s[KNZ_ANS0_DEC_CHUNKS][4096];
-    __shared__ uint32_t s_sym[KNZ_ANS0_DEC_CHUNKS][256];      // freq | cumFreq << 16
-    __shared__ uint16_t s_pay[KNZ_ANS0_DEC_CHUNKS][256];       // renormalisation words of each chunk, ring
-    __shared__ uint8_t s_ob[KNZ_ANS0_DEC_CHUNKS][256];         // decoded bytes of each chunk, 64 steps at a time
-    __shared__ uint16_t s_freqs[KNZ_ANS0_DEC_CHUNKS][256];
-    __shared__ uint8_t s_alphas[KNZ_ANS0_DEC_CHUNKS][256];
-    __shared__ uint32_t s_state[KNZ_ANS0_DEC_CHUNKS][4];
-    __shared__ uint64_t s_paybit[KNZ_ANS0_DEC_CHUNKS];
-    __shared__ int s_mode[KNZ_ANS0_DEC_CHUNKS];               // 0 absent, 1 raw, 2 single symbol, 3 rANS, -1 error
+struct KnzAns0DecShared {
+    uint8_t s_f2s[KNZ_ANS0_DEC_CHUNKS][4096];
+    uint32_t s_sym[KNZ_ANS0_DEC_CHUNKS][256];      // freq | cumFreq << 16
+    uint16_t s_pay[KNZ_ANS0_DEC_CHUNKS][256];       // renormalisation words of each chunk, ring
+    uint8_t s_ob[KNZ_ANS0_DEC_CHUNKS][256];         // decoded bytes of each chunk, 64 steps at a time
+    uint16_t s_freqs[KNZ_ANS0_DEC_CHUNKS][256];
+    uint8_t s_alphas[KNZ_ANS0_DEC_CHUNKS][256];
+    uint32_t s_state[KNZ_ANS0_DEC_CHUNKS][4];
+    uint64_t s_paybit[KNZ_ANS0_DEC_CHUNKS];
+    uint64_t s_cbit[KNZ_ANS0_DEC_CHUNKS];           // first bit of each chunk (filled by the caller)
+    int s_mode[KNZ_ANS0_DEC_CHUNKS];                // 0 absent, 1 raw, 2 single symbol, 3 rANS, -1 error
+};
+
+// chunk slots slotBase .. slotBase + nvalid - 1 (<= 8, all of them below a.nslots) by one wave
+__device__ __forceinline__ void knz_ans0_decode_body(const Ans0DecArgs& a, const uint32_t slotBase, const uint32_t nvalid, KnzAns0DecShared& sh) {
+    uint8_t (&s_f2s)[KNZ_ANS0_DEC_CHUNKS][4096] = sh.s_f2s;
+    uint32_t (&s_sym)[KNZ_ANS0_DEC_CHUNKS][256] = sh.s_sym;
+    uint16_t (&s_pay)[KNZ_ANS0_DEC_CHUNKS][256] = sh.s_pay;
+    uint8_t (&s_ob)[KNZ_ANS0_DEC_CHUNKS][256] = sh.s_ob;
+    uint16_t (&s_freqs)[KNZ_ANS0_DEC_CHUNKS][256] = sh.s_freqs;
+    uint8_t (&s_alphas)[KNZ_ANS0_DEC_CHUNKS][256] = sh.s_alphas;
+    uint32_t (&s_state)[KNZ_ANS0_DEC_CHUNKS][4] = sh.s_state;
+    uint64_t (&s_paybit)[KNZ_ANS0_DEC_CHUNKS] = sh.s_paybit;
+    const uint64_t (&s_cbit)[KNZ_ANS0_DEC_CHUNKS] = sh.s_cbit;
+    int (&s_mode)[KNZ_ANS0_DEC_CHUNKS] = sh.s_mode;
 
     const int lane = threadIdx.x;
     const uint32_t cpb = a.chunks_per_block;
@@ -269,9 +284,9 @@ __global__ __launch_bounds__(64) void knz_ans0_decode_kernel(Ans0DecArgs a) {
         const int cg = lane;
         uint16_t* s_freq = s_freqs[cg];
         uint8_t* s_alpha = s_alphas[cg];
-        const uint32_t slotId = blockIdx.x * KNZ_ANS0_DEC_CHUNKS + cg;
+        const uint32_t slotId = slotBase + cg;
         int mode = 0;
-        if (slotId < a.nslots) {
+        if ((uint32_t)cg < nvalid) {
             const uint32_t b = slotId / cpb, k = slotId % cpb;
             const uint32_t preLen = a.blk_pre_len[b];
             if (a.blk_status[b] == 0 && (uint64_t)k * KNZ_ANS_CHUNK < preLen) mode = ((a.blk_mode[b] & 0x80) || preLen <= 32) ? 1 : 3;
@@ -279,7 +294,7 @@ __global__ __launch_bounds__(64) void knz_ans0_decode_kernel(Ans0DecArgs a) {
         if (mode == 3) {
             {                                                      // decodeHeader :605-710
                 KnzStreamReader r;
-                r.init(a.stream, a.nbytes, a.chunk_bit[slotId]);
+                r.init(a.stream, a.nbytes, s_cbit[cg]);
                 const uint32_t lr = 8 + r.read(3);
                 int count = 0;
                 int m = 3;
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(64) void knz_ans0_decode_kernel(Ans0DecArgs a) {
     for (int cg = 0; cg < KNZ_ANS0_DEC_CHUNKS; cg++) {
         const uint16_t* s_freq = s_freqs[cg];
         const uint8_t* s_alpha = s_alphas[cg];
-        const uint32_t slotId = blockIdx.x * KNZ_ANS0_DEC_CHUNKS + cg;
+        const uint32_t slotId = slotBase + cg;
         const int mode = s_mode[cg];
         uint32_t n = 0, b = 0, k = 0;
         if (mode != 0) {
@@ -366,7 +381,7 @@ __global__ __launch_bounds__(64) void knz_ans0_decode_kernel(Ans0DecArgs a) {
             uint8_t* dst = a.out + a.blk_out_off[b] + (size_t)k * KNZ_ANS_CHUNK;
             if (mode == 2) { const uint8_t v = (uint8_t)s_state[cg][0]; for (uint32_t i = lane; i < n; i += 64) dst[i] = v; }
             else {
-                const uint64_t cbit = a.chunk_bit[slotId];
+                const uint64_t cbit = s_cbit[cg];
                 for (uint32_t i = lane * 4; i < n; i += 256) {
                     const uint32_t w = knz_fetch32(a.stream, (int64_t)(cbit + 8ull * i), (int64_t)limit);
                     for (uint32_t j = 0; j < 4 && i + j < n; j++) dst[i + j] = (uint8_t)(w >> (24 - 8 * j));
@@ -381,8 +396,8 @@ __global__ __launch_bounds__(64) void knz_ans0_decode_kernel(Ans0DecArgs a) {
     // ---- the 8 x 4 states ------------------------------------------------------------------------------------------------
     const int g = lane >> 2, c = lane & 3;
     const bool lanes32 = lane < 4 * KNZ_ANS0_DEC_CHUNKS;
-    const uint32_t slotId = blockIdx.x * KNZ_ANS0_DEC_CHUNKS + (lanes32 ? g : 0);
-    bool live = lanes32 && slotId < a.nslots && s_mode[lanes32 ? g : 0] == 3;
+    const uint32_t slotId = slotBase + (lanes32 ? g : 0);
+    bool live = lanes32 && (uint32_t)g < nvalid && s_mode[lanes32 ? g : 0] == 3;
     uint32_t n = 0;
     uint8_t* dst = a.out;
     uint64_t paybit = 0;
@@ -456,4 +471,51 @@ __global__ __launch_bounds__(64) void knz_ans0_decode_kernel(Ans0DecArgs a) {
         for (uint32_t i = end4; i < n; i++)
             dst[i] = (uint8_t)(knz_fetch32(a.stream, (int64_t)(paybit + 16ull * cnt + 8ull * (i - end4)), (int64_t)limit) >> 24);
     }
+}
+
+__global__ __launch_bounds__(64) void knz_ans0_decode_kernel(Ans0DecArgs a) {
+    __shared__ KnzAns0DecShared sh;
+    const uint32_t slotBase = blockIdx.x * KNZ_ANS0_DEC_CHUNKS;
+    const uint32_t nvalid = slotBase < a.nslots ? min((uint32_t)KNZ_ANS0_DEC_CHUNKS, a.nslots - slotBase) : 0u;
+    if (threadIdx.x < KNZ_ANS0_DEC_CHUNKS) sh.s_cbit[threadIdx.x] = threadIdx.x < nvalid ? a.chunk_bit[slotBase + threadIdx.x] : 0;
+    wave_sync();
+    knz_ans0_decode_body(a, slotBase, nvalid, sh);
+}
+
+// Walk and decode in ONE launch, as for Huffman (knz_huf_walk_decode_kernel): workgroups [0, nblocks) walk (one wave each: the
+// rANS chunk headers are walked without the ring), workgroup nblocks + kg * nblocks + b decodes chunks 8 kg .. 8 kg + 7 of block
+// b; lanes 0..7 poll the positions of its chunks. The decode (4.7 ms on config 3's entropy half) is longer than the walk (2.4 ms)
+// here, so it is the walk that disappears.
+__global__ __launch_bounds__(64) void knz_ans0_walk_decode_kernel(WalkBlocksArgs wa, Ans0DecArgs da) {
+    __shared__ union KnzAns0WalkDecodeShared { KnzAns0DecShared d; KnzWalkShared w; } sh;
+    const uint32_t nblocks = wa.nblocks;
+    const int lane = threadIdx.x;
+    if (blockIdx.x < nblocks) {
+        if (lane < 4) sh.w.s_sync[lane] = 0;
+        __syncthreads();
+        knz_walk_block_body<true>(wa, blockIdx.x, sh.w);
+        return;
+    }
+    const uint32_t cpb = da.chunks_per_block;
+    const uint32_t id = blockIdx.x - nblocks;
+    const uint32_t kg = id / nblocks, b = id % nblocks;
+    const uint32_t k0 = kg * KNZ_ANS0_DEC_CHUNKS;
+    if (k0 >= cpb) return;
+    const uint32_t nvalid = min((uint32_t)KNZ_ANS0_DEC_CHUNKS, cpb - k0);
+    const uint32_t slotBase = b * cpb + k0;
+    if (lane < KNZ_ANS0_DEC_CHUNKS) {
+        uint64_t v = 0;
+        const bool present = (uint32_t)lane < nvalid && da.blk_status[b] == 0 && (uint64_t)(k0 + lane) * KNZ_ANS_CHUNK < da.blk_pre_len[b];
+        if (present) {
+            v = knz_poll64(&da.chunk_bit[slotBase + lane]);
+            for (uint32_t spins = 0; v == KNZ_CHUNK_NOT_READY && spins < (1u << 21); spins++) { wg_spin_pause(); v = knz_poll64(&da.chunk_bit[slotBase + lane]); }
+            if (v == KNZ_CHUNK_NOT_READY) da.blk_status[b] = KNZ_ERR_PROCESS_BLOCK;     // (never seen: the walkers are resident first)
+        }
+        sh.d.s_cbit[lane] = v;
+    }
+    wave_sync();
+    // a chunk whose walk failed (ERR mark) or never came is left out: its block carries the error
+    uint32_t ok = nvalid;
+    for (uint32_t c = 0; c < nvalid; c++) if (sh.d.s_cbit[c] >= KNZ_CHUNK_ERR) { ok = c; break; }
+    knz_ans0_decode_body(da, slotBase, ok, sh.d);
 }
