@@ -246,8 +246,8 @@ def main():
         n_local, c_local = n_my, (result.get("seg_bits", C_bytes * 8) + 7) // 8 if world > 1 else C_bytes
         kern = {
             {"HUFFMAN": "knz_huf_hist+lengths+encode_kernels", "ANS0": "knz_ans0_stats+encode_kernels", "ANS1": "knz_ans1_hist+stats+merge+encode_kernels", "FPAQ": "knz_fpaq_encode_kernel", "NONE": "knz_raw_units_kernel"}[entropy]: (per_launch["enc_entropy"], n_local + c_local),
-            {"HUFFMAN": "knz_huf_walk_decode_kernel", "ANS0": "knz_ans0_decode_kernel", "ANS1": "knz_ans1_dec_tables+decode_kernels", "FPAQ": "knz_fpaq_decode_kernel", "NONE": "knz_huf_decode_kernel (raw copy)"}[entropy]: (per_launch["dec_entropy"], n_local + c_local),
-            ("knz_dec_block_headers_kernel" if entropy == "HUFFMAN" else "knz_dec_walk_blocks_kernel"): (per_launch["dec_walk"], c_local),
+            {"HUFFMAN": "knz_huf_walk_decode_kernel", "ANS0": "knz_ans0_walk_decode_kernel", "ANS1": "knz_ans1_dec_tables+decode_kernels", "FPAQ": "knz_fpaq_decode_kernel", "NONE": "knz_huf_decode_kernel (raw copy)"}[entropy]: (per_launch["dec_entropy"], n_local + c_local),
+            ("knz_dec_block_headers_kernel" if entropy in ("HUFFMAN", "ANS0") else "knz_dec_walk_blocks_kernel"): (per_launch["dec_walk"], c_local),
             "forward transform stage kernels (" + transform + ")": (per_launch["enc_transform"], 2 * n_local),
             "inverse transform stage kernels (" + transform + ")": (per_launch["dec_transform"], 2 * n_local),
         }
