@@ -331,6 +331,79 @@ __global__ __launch_bounds__(64) void knz_sbrt_inverse_kernel(XfArgs a) {
     }
 }
 
+// MTFT inverse without the block-long chain. A move-to-front step permutes list POSITIONS in a way that does not depend on
+// what the list holds (rank r goes to the front, ranks 0..r-1 move down): the effect of a whole segment of ranks on the list
+// is a permutation that can be worked out from the ranks alone. So: (1) every segment runs its ranks over the identity list
+// and keeps the permutation it ends with, (2) one workgroup per block composes the permutations in order, which gives the
+// list at the start of every segment, (3) every segment decodes from its own start list. Two 8192-step chains per segment,
+// all segments at once, instead of one chain over the block. (RANK has no such form: where a symbol lands depends on the
+// access times stored with the list entries, which only the preceding ranks can tell.)
+__global__ __launch_bounds__(64) void knz_mtft_inv_perm_kernel(XfArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[KNZ_SEG];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[KNZ_SEG];
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x / a.segs_per_block, s = blockIdx.x % a.segs_per_block;
+    if (!a.active[b]) return;
+    const uint32_t n = a.in_len[b];
+    const uint32_t lo = s * KNZ_SEG;
+    if (lo >= n || n > a.out_cap) return;
+    const uint32_t cnt = min(n, lo + KNZ_SEG) - lo;
+    const uint8_t* src = (const uint8_t*)a.in_ptr[b];
+    for (uint32_t i = lane; i < cnt; i += 64) s_in[i] = src[lo + i];
+    wave_sync();
+    SbrtWave<1> w;
+    w.init_identity(lane);
+    w.template run_tile<false>(s_in, s_out, cnt, 1, lane);                         // (times start at 1: the fresh list holds q = 0)
+    uint8_t* perm = (uint8_t*)(a.seg_a + (size_t)blockIdx.x * 256);               // 256 bytes of the segment's 1 KiB slot
+#pragma unroll
+    for (int k = 0; k < 4; k++) perm[64 * k + lane] = (uint8_t)w.s[k];            // position j of the list now holds what was at perm[j]
+}
+
+__global__ __launch_bounds__(256) void knz_mtft_inv_compose_kernel(XfArgs a) {
+    __shared__ uint8_t s_cur[256], s_nxt[256];
+    const uint32_t b = blockIdx.x;
+    if (!a.active[b]) return;
+    const int j = threadIdx.x;
+    const uint32_t n = a.in_len[b];
+    if (n > a.out_cap) return;
+    const uint32_t nseg = (n + KNZ_SEG - 1) / KNZ_SEG;
+    s_cur[j] = (uint8_t)j;                                                          // SBRT starts from the identity list (:186-190)
+    __syncthreads();
+    for (uint32_t s = 0; s < nseg; s++) {
+        const uint8_t* perm = (const uint8_t*)(a.seg_a + ((size_t)b * a.segs_per_block + s) * 256);
+        uint8_t* start = (uint8_t*)(a.seg_b + ((size_t)b * a.segs_per_block + s) * 256);
+        start[j] = s_cur[j];
+        s_nxt[j] = s_cur[perm[j]];
+        __syncthreads();
+        s_cur[j] = s_nxt[j];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void knz_mtft_inv_apply_kernel(XfArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[KNZ_SEG];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[KNZ_SEG];
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x / a.segs_per_block, s = blockIdx.x % a.segs_per_block;
+    if (!a.active[b]) return;
+    const uint32_t n = a.in_len[b];
+    if (s == 0 && lane == 0) { a.out_len[b] = n; a.ok[b] = n <= a.out_cap ? 1 : -KNZ_ERR_PROCESS_BLOCK; }
+    const uint32_t lo = s * KNZ_SEG;
+    if (lo >= n || n > a.out_cap) return;
+    const uint32_t cnt = min(n, lo + KNZ_SEG) - lo;
+    const uint8_t* src = (const uint8_t*)a.in_ptr[b];
+    uint8_t* dst = (uint8_t*)a.out_ptr[b];
+    const uint8_t* start = (const uint8_t*)(a.seg_b + (size_t)blockIdx.x * 256);
+    for (uint32_t i = lane; i < cnt; i += 64) s_in[i] = src[lo + i];
+    SbrtWave<1> w;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { w.s[k] = start[64 * k + lane]; w.q[k] = 0; w.p[k] = 0; }
+    wave_sync();
+    w.template run_tile<false>(s_in, s_out, cnt, 1, lane);
+    wave_sync();
+    for (uint32_t i = lane; i < cnt; i += 64) dst[lo + i] = s_out[i];
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // ZRLT forward
 // 1) per segment: block-local index of the last non-zero byte (-1 if none)

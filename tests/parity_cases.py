@@ -447,6 +447,25 @@ def check_huffman_split_walk(be):
         del os.environ["KNZ_HUF_SPLIT_WALK"]
 
 
+def check_mtft_segments(be):
+    """MTFT inverse over several 8 KiB segments (per-segment permutations composed per block) and its one-wave form
+    (KNZ_MTFT_CHAIN)."""
+    import os
+    r = np.random.default_rng(9)
+    data = (np.minimum(r.geometric(0.15, 3 * 8192 + 17), 255).astype(np.uint8) ^ (np.arange(3 * 8192 + 17) >> 11).astype(np.uint8)).tobytes()
+    c = K.Codec("NONE", "NONE", 1 << 20, lib=be.lib)
+    t = K.ByteTransform(c, "MTFT")
+    f = t.forward(data)
+    assert f == O.transform_forward(_TID["MTFT"], data)
+    assert t.inverse(f, len(data) + 512) == data
+    os.environ["KNZ_MTFT_CHAIN"] = "1"
+    try:
+        assert t.inverse(f, len(data) + 512) == data
+    finally:
+        del os.environ["KNZ_MTFT_CHAIN"]
+    c.close()
+
+
 def check_srt_chain_form(be):
     """SRT forward has two forms: MTFT ranks + stable partition by symbol (default), or the reference's list walk by one wave
     per block; KNZ_SRT_CHAIN forces the second."""

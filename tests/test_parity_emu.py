@@ -85,6 +85,10 @@ def test_huffman_split_walk(be):
     P.check_huffman_split_walk(be)
 
 
+def test_mtft_segments(be):
+    P.check_mtft_segments(be)
+
+
 def test_srt_chain_form(be):
     P.check_srt_chain_form(be)
 

@@ -169,6 +169,10 @@ def test_concurrent_handles(be):
     P.check_concurrent_handles(be)
 
 
+def test_mtft_segments(be):
+    P.check_mtft_segments(be)
+
+
 def test_srt_chain_form(be):
     P.check_srt_chain_form(be)
 
