@@ -447,6 +447,27 @@ def check_huffman_split_walk(be):
         del os.environ["KNZ_HUF_SPLIT_WALK"]
 
 
+def check_golden_streams(be):
+    """The device writes the streams of tests/golden/oracle_streams.json (sha256 + length committed with the script that made
+    them) - the same inputs the oracle regression test uses, compared without running the oracle."""
+    import hashlib, json, os, sys
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, g)
+    import make_oracle_vectors as M
+    want = json.load(open(os.path.join(g, "oracle_streams.json")))["streams"]
+    for t, e, bs, n, ck, sk in M.CASES:
+        data = M.data_for(t, n)
+        c = K.Codec(t, e, bs, checksum_bits=ck, lib=be.lib, skip_blocks=sk)
+        src, ks = be.to_dev(data)
+        cap = 2 * n + 262144 * (n // bs + 2)
+        dst, kd = be.empty(cap)
+        nb = c.dev_compress(src, n, dst, cap)
+        got = be.to_host(kd, nb)
+        w = want[f"{t}|{e}|{bs}|{n}|{ck}|{int(sk)}"]
+        assert (len(got), hashlib.sha256(got).hexdigest()) == (w["len"], w["sha256"]), (t, e, bs, n, ck, sk)
+        c.close()
+
+
 def check_mtft_segments(be):
     """MTFT inverse over several 8 KiB segments (per-segment permutations composed per block) and its one-wave form
     (KNZ_MTFT_CHAIN)."""

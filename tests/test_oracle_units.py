@@ -201,6 +201,19 @@ def test_rank_and_mtf_known_vectors():
     assert O.transform_forward(O.T_RANK, bytes([3, 3, 3, 0])) == bytes([3, 0, 0, 1])
 
 
+def test_oracle_stream_regression_vectors():
+    # tests/golden/oracle_streams.json (made by tests/golden/make_oracle_vectors.py): the oracle still writes the streams it wrote
+    # when the vectors were committed, for every transform / entropy / checksum / -s combination on the path
+    import json, os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_oracle_vectors as M
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_streams.json")))["streams"]
+    got = M.vectors()
+    assert set(got) == set(want)
+    for k in want:
+        assert got[k] == want[k], k
+
+
 def test_skip_blocks_constants_and_rules():
     # the 4096*log2 table both sides rebuild from the formula equals the reference's (internal/Global.go:59-88, extracted by
     # tests/golden/make_golden.py); Log2ScaledBy1024 and the magic rules follow internal/Global.go:174-191, Magic.go:83-170

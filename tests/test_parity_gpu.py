@@ -169,6 +169,10 @@ def test_concurrent_handles(be):
     P.check_concurrent_handles(be)
 
 
+def test_golden_streams(be):
+    P.check_golden_streams(be)
+
+
 def test_mtft_segments(be):
     P.check_mtft_segments(be)
 
