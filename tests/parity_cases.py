@@ -41,7 +41,7 @@ class GpuBackend:
         import torch
         self.torch = torch
         assert torch.cuda.is_available(), "GPU tests need a GPU"
-        self.lib = K.library_path()
+        self.lib = K.build_library()      # in-tree libknz_gpu.so; (re)built with hipcc only when missing or older than its sources
         self.dev = torch.device("cuda:0")
 
     def empty(self, n, align=16):
