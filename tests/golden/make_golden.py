@@ -35,6 +35,16 @@ def magic_values():
     return {m.group(1): int(m.group(2), 16) for m in re.finditer(r"(\w+_MAGIC\w*)\s*=\s*(0x[0-9A-Fa-f]+)", src)}
 
 
+def text_codec_constants():
+    """TextCodec.go:26-51 and the static dictionary (:97-186): groundwork for the TEXT stage (not built yet)."""
+    src = open(os.path.join(REF, "transform/TextCodec.go")).read()
+    body = src[src.index("_TC_DICT_EN_1024 = []byte(`") + len("_TC_DICT_EN_1024 = []byte(`"):]
+    body = body[: body.index("`)")]
+    words = "".join(ch for ch in body if ch.isalpha())            # createDictionary drops everything that is not a letter (:456-463)
+    consts = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"(_TC_[A-Z0-9_]+)\s*=\s*(0x[0-9A-Fa-f]+|\d+)\b", src)}
+    return {"static_dictionary_letters": words, "constants": consts}
+
+
 def main():
     g = {
         "source": "flanglet/kanzi-go v2 (bitstream v6)",
@@ -48,6 +58,7 @@ def main():
         "log2_4096": log2_4096_table(), "incompressible_threshold": 973,
         # internal/Magic.go:22-58
         "magic": magic_values(),
+        "text_codec": text_codec_constants(),
         "stream": {"magic": 0x4B414E5A, "version": 6, "hash_seed": 0x4B414E5A, "header_hash": 0x1E35A7BD,
                    "header_seed_mul": 0x01030507},
     }
