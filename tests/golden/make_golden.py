@@ -41,7 +41,11 @@ def text_codec_constants():
     body = src[src.index("_TC_DICT_EN_1024 = []byte(`") + len("_TC_DICT_EN_1024 = []byte(`"):]
     body = body[: body.index("`)")]
     words = "".join(ch for ch in body if ch.isalpha())            # createDictionary drops everything that is not a letter (:456-463)
-    consts = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"(_TC_[A-Z0-9_]+)\s*=\s*(0x[0-9A-Fa-f]+|\d+)\b", src)}
+    consts = {}
+    for m in re.finditer(r"(_TC_[A-Z0-9_]+)\s*=\s*([^/\n]+)", src[: src.index("type dictEntry")]):
+        expr = re.sub(r"\b(byte|int32)\(([^)]*)\)", r"\2", m.group(2).strip())       # byte(0x0F) -> 0x0F ; int32(-2073254261) -> -2073254261
+        expr = re.sub(r"_TC_[A-Z0-9_]+", lambda k: str(consts[k.group(0)]), expr)
+        consts[m.group(1)] = int(eval(expr, {"__builtins__": {}}))                  # plain integer arithmetic of the const block
     return {"static_dictionary_letters": words, "constants": consts}
 
 
