@@ -8,6 +8,7 @@
 #include "ans1.hip"
 #include "fpaq.hip"
 #include "transforms.hip"
+#include "rank_inv.hip"
 #include "bwt.hip"
 #include "lz.hip"
 #include "srt_lzp.hip"
@@ -24,6 +25,23 @@
     do {                                                                                     \
         hipError_t e__ = (expr);                                                             \
         if (e__ != hipSuccess) return knz_set_error(h, KNZ_ERR_UNKNOWN, hipGetErrorString(e__)); \
+    } while (0)
+
+static int probe_begin(Handle* h, hipStream_t st, const char* name) {
+    if (h->nprobes >= KNZ_MAX_PROBES) return -1;
+    KernelProbe& p = h->probes[h->nprobes];
+    if (!p.a && (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess)) return -1;
+    p.name = name;
+    hipEventRecord(p.a, st);
+    return h->nprobes++;
+}
+static void probe_end(Handle* h, hipStream_t st, int id) { if (id >= 0) hipEventRecord(h->probes[id].b, st); }
+// launch with a probe: `h` and `st` are in scope at every call site
+#define KNZ_LAUNCH_PROBED(kern, ...)                         \
+    do {                                                      \
+        const int pid__ = probe_begin(h, st, #kern);          \
+        hipLaunchKernelGGL(kern, __VA_ARGS__);                \
+        probe_end(h, st, pid__);                              \
     } while (0)
 
 int knz_set_error(Handle* h, int code, const char* msg) {
@@ -155,6 +173,7 @@ extern "C" int knz_close(void* handle) {
     if (!h) return KNZ_OK;
     if (h->pinned) hipHostFree(h->pinned);
     for (int i = 0; i <= KNZ_STAGE_COUNT; i++) hipEventDestroy(h->ev[i]);
+    for (int i = 0; i < KNZ_MAX_PROBES; i++) if (h->probes[i].a) { hipEventDestroy(h->probes[i].a); hipEventDestroy(h->probes[i].b); }
     delete h;
     return KNZ_OK;
 }
@@ -170,6 +189,22 @@ extern "C" int knz_last_timing(void* handle, float* stage_ms, int cap) {
     }
     int n = std::min(cap, (int)KNZ_STAGE_COUNT);
     for (int i = 0; i < n; i++) stage_ms[i] = h->stage_ms[i];
+    return n;
+}
+
+extern "C" int knz_last_kernel_times(void* handle, char* names, int names_cap, float* ms, int cap) {
+    Handle* h = (Handle*)handle;
+    if (!h || !names || !ms || names_cap <= 0) return 0;
+    int n = 0, pos = 0;
+    names[0] = 0;
+    for (int i = 0; i < h->nprobes && n < cap; i++) {
+        const KernelProbe& p = h->probes[i];
+        const int len = (int)strlen(p.name);
+        if (pos + len + 2 > names_cap) break;
+        if (hipEventSynchronize(p.b) != hipSuccess || hipEventElapsedTime(&ms[n], p.a, p.b) != hipSuccess) ms[n] = 0.f;
+        memcpy(names + pos, p.name, len); pos += len; names[pos++] = '\n'; names[pos] = 0;
+        n++;
+    }
     return n;
 }
 
@@ -231,6 +266,7 @@ __global__ void knz_enc_tables_kernel(EncTablesArgs a) {
 
 static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     const knz_cfg& cfg = h->cfg;
+    h->nprobes = 0;
     if (!transform_on_device(cfg.transform) || !entropy_on_device(cfg.entropy))
         return knz_set_error(h, KNZ_ERR_INVALID_CODEC, "transform/entropy combination has no device implementation in this build");
     if (eb.n == 0) {
@@ -308,9 +344,9 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
                     return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
                 a.st_freq = h->huf_stfreq.as<uint16_t>(); a.st_sym = h->huf_stsym.as<uint8_t>(); a.st_len = h->huf_stlen.as<uint8_t>();
                 a.st_count = h->huf_stcnt.as<uint16_t>(); a.st_maxlen = h->huf_stmax.as<uint8_t>(); a.nchunks = nc;
-                hipLaunchKernelGGL(knz_huf_hist_kernel, dim3(nc), dim3(256), 0, st, a);
-                hipLaunchKernelGGL(knz_huf_lengths_kernel, dim3(groups), dim3(64), 0, st, a);
-                hipLaunchKernelGGL(knz_huf_encode_kernel, dim3(nc), dim3(256), 0, st, a);
+                KNZ_LAUNCH_PROBED(knz_huf_hist_kernel, dim3(nc), dim3(256), 0, st, a);
+                KNZ_LAUNCH_PROBED(knz_huf_lengths_kernel, dim3(groups), dim3(64), 0, st, a);
+                KNZ_LAUNCH_PROBED(knz_huf_encode_kernel, dim3(nc), dim3(256), 0, st, a);
             }
             else hipLaunchKernelGGL(knz_raw_units_kernel, dim3(nblocks * cpb), dim3(256), 0, st, a);
         } else if (cfg.entropy == KNZ_E_FPAQ) {
@@ -318,7 +354,7 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             a.blk_off = h->blk_off.as<uint64_t>(); a.blk_len = h->blk_len.as<uint32_t>(); a.blk_src_len = h->blk_src_len.as<uint32_t>();
             a.chunks_per_block = cpb; a.scratch = h->scratch.as<uint8_t>(); a.unit_bits = h->unit_bits.as<uint32_t>();
             a.unit_src = h->unit_src.as<uint32_t>(); a.blk_status = h->blk_status.as<int32_t>();
-            hipLaunchKernelGGL(knz_fpaq_encode_kernel, dim3(nblocks), dim3(64), 0, st, a);
+            KNZ_LAUNCH_PROBED(knz_fpaq_encode_kernel, dim3(nblocks), dim3(64), 0, st, a);
         } else if (cfg.entropy == KNZ_E_ANS1) {
             const uint32_t ns = nblocks * cpb;
             if (h->a1_freqs.reserve((size_t)ns * 65536 * 4) || h->a1_tab.reserve((size_t)ns * 65536 * 8) ||
@@ -331,11 +367,11 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             a.freqs = h->a1_freqs.as<uint32_t>(); a.tab = h->a1_tab.as<uint2>(); a.ctx_hdr = h->a1_ctxhdr.as<uint8_t>();
             a.ctx_bits = h->a1_ctxbits.as<uint32_t>(); a.blk_status = h->blk_status.as<int32_t>();
             hipMemsetAsync(h->a1_freqs.p, 0, (size_t)ns * 65536 * 4, st);
-            hipLaunchKernelGGL(knz_ans1_hist_kernel, dim3(ns * KNZ_ANS1_HIST_WGS * KNZ_ANS1_HIST_SLICES), dim3(256), 0, st, a);
+            KNZ_LAUNCH_PROBED(knz_ans1_hist_kernel, dim3(ns * KNZ_ANS1_HIST_WGS * KNZ_ANS1_HIST_SLICES), dim3(256), 0, st, a);
             hipLaunchKernelGGL(knz_ans1_stats_kernel, dim3(ns * 256), dim3(64), 0, st, a);
             hipLaunchKernelGGL(knz_ans1_merge_kernel, dim3(ns), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(knz_ans1_expand_kernel, dim3(ns, 128), dim3(256), 0, st, a, h->a1_ent.as<uint4>());
-            hipLaunchKernelGGL(knz_ans1_encode_kernel, dim3(ns), dim3(64), 0, st, a, (const uint4*)h->a1_ent.as<uint4>());
+            KNZ_LAUNCH_PROBED(knz_ans1_expand_kernel, dim3(ns, 128), dim3(256), 0, st, a, h->a1_ent.as<uint4>());
+            KNZ_LAUNCH_PROBED(knz_ans1_encode_kernel, dim3(ns), dim3(64), 0, st, a, (const uint4*)h->a1_ent.as<uint4>());
         } else if (cfg.entropy == KNZ_E_ANS0) {
             Ans0Args a;
             a.data = nullptr; a.blk_off = h->blk_off.as<uint64_t>(); a.blk_len = h->blk_len.as<uint32_t>();
@@ -344,7 +380,7 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             a.blk_status = h->blk_status.as<int32_t>();
             const uint32_t ns = nblocks * cpb;
             hipLaunchKernelGGL(knz_ans0_stats_kernel, dim3(ns), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(knz_ans0_encode_kernel, dim3((ns + KNZ_ANS0_CHUNKS_PER_WG - 1) / KNZ_ANS0_CHUNKS_PER_WG), dim3(128), 0, st, a, ns);
+            KNZ_LAUNCH_PROBED(knz_ans0_encode_kernel, dim3((ns + KNZ_ANS0_CHUNKS_PER_WG - 1) / KNZ_ANS0_CHUNKS_PER_WG), dim3(128), 0, st, a, ns);
         }
     }
     hipEventRecord(h->ev[2], st);
@@ -384,7 +420,7 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     ga.unit_src = h->unit_src.as<uint32_t>();
     ga.chunk_rel = h->chunk_rel.as<uint64_t>(); ga.blk_dst_bit = h->blk_dst_bit.as<uint64_t>(); ga.dst_words = (uint32_t*)eb.d_dst;
     ga.total_bits = h->total_bits.as<uint64_t>();
-    if (nblocks) hipLaunchKernelGGL(knz_gather_kernel, dim3(nblocks * cpb, (cfg.entropy == KNZ_E_ANS1 || cfg.entropy == KNZ_E_FPAQ) ? 64 : 1), dim3(256), 0, st, ga);
+    if (nblocks) KNZ_LAUNCH_PROBED(knz_gather_kernel, dim3(nblocks * cpb, (cfg.entropy == KNZ_E_ANS1 || cfg.entropy == KNZ_E_FPAQ) ? 64 : 1), dim3(256), 0, st, ga);
     hipEventRecord(h->ev[4], st);
     h->ev_valid = true;
 

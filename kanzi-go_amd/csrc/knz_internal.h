@@ -18,8 +18,14 @@ struct DevBuf {
     template <typename T> T* as() const { return (T*)p; }
 };
 
+// HIP-event pair around one launch of a kernel that can dominate a batch (bench.py's roofline line reads these)
+#define KNZ_MAX_PROBES 48
+struct KernelProbe { const char* name = nullptr; hipEvent_t a = nullptr, b = nullptr; };
+
 struct Handle {
     knz_cfg cfg;
+    KernelProbe probes[KNZ_MAX_PROBES];
+    int nprobes = 0;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;

@@ -1,0 +1,362 @@
+// Inverse RANK / MTFT as ONE chain per block (SBRT.Inverse, v2/transform/SBRT.go:180-226), rebuilt around the two things that
+// bound a lone wave on gfx950: the number of instructions per symbol and the number of VALU <-> SALU hand-overs on the
+// loop-carried path (each one costs a pipeline drain: ~15 cycles per instruction were measured on the round-1 form, whose
+// step went v_readlane -> SALU -> v_cmp -> s_bcnt -> VALU masks -> 6 v_cndmask).
+//
+// The list stays in registers (rank l of the first 64 in lane l) and stays sorted by q. For an access of rank r at time i
+//     qc = (i + p[r]) >> 1                                  (SBRT.go:211, mode RANK; MTFT: qc = i)
+// every lane can decide on its own what it holds afterwards, WITHOUT the landing rank j ever being computed:
+//     q[l]   >  qc           -> lane keeps its entry                      (l <  j)
+//     q[l-1] >  qc >= q[l]   -> lane takes the accessed entry             (l == j)
+//     otherwise, l <= r      -> lane takes the entry of lane l-1          (j <  l <= r)
+// i.e. two v_cmp against the uniform qc (one on q, one on the lane-1 copy of q that a DPP move keeps up to date) and two
+// v_cndmask per register. One hand-over to the scalar unit (v_readlane of the accessed entry -> qc) and one back per step, no
+// popcount, no lane masks built from j. Symbol and last access time share a register (p << 8 | sym) while times fit
+// (blocks <= 8 MiB: the BASELINE block size of this pipeline); larger blocks use a three-register form of the same step.
+//
+// Input ranks are fetched with scalar loads (s_load_dwordx4: the address is wave-uniform and the bytes are read-only for this
+// kernel), 16 ranks per instruction and one group ahead of the chain; words of four zero ranks (the bulk behind a BWT) cost
+// one scalar compare. Decoded symbols are packed four to a word in SGPRs, parked in lane (word & 63) of one VGPR and stored
+// 256 bytes at a time. Ranks >= 64 (rare behind a BWT) take the four-register path of the round-1 kernel.
+#pragma once
+
+// FLAGS (variants kept for measurement): bit 0: an isolated rank 0 takes a branch to a shorter step;
+// bit 1: lanes above r are kept by a per-lane threshold (v_cmp + v_cndmask) instead of an EXEC mask around the selects
+
+template <int MODE, bool PACKED, int FLAGS>
+struct RankChain {
+    // registers k = 0..3 hold ranks 64k .. 64k+63. PACKED: e = p << 8 | sym ; else e = sym and p separately
+    uint32_t e[4], p[4];
+    int q[4];
+    uint32_t ep, pp;      // lane-1 copies of register 0 (lane 0: don't care)
+    int qp;               // lane-1 copy of q[0], lane 0: INT_MAX ("there is always something above rank 0")
+    int lane;
+
+    __device__ __forceinline__ void refresh() {
+        ep = wave_shr1(e[0]);
+        if (!PACKED) pp = wave_shr1(p[0]);
+        qp = (int)wave_shr1_old((uint32_t)q[0], 0x7FFFFFFFu);
+    }
+    __device__ __forceinline__ void init_identity(int l) {
+        lane = l;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { e[k] = 64u * (uint32_t)k + (uint32_t)l; p[k] = 0; q[k] = 0; }   // p = 0: packed e is the symbol itself
+        refresh();
+    }
+    static __device__ __forceinline__ int qf(uint32_t i, uint32_t pc) { return MODE == 1 ? (int)i : (int)((i + pc) >> 1); }
+
+    // rank r <= 63 at time i; returns the symbol
+    __device__ __forceinline__ uint32_t step_low(uint32_t r, uint32_t i) {
+        const uint32_t se = wave_readlane(e[0], r);
+        uint32_t sym, snew, spn = i;
+        int qc;
+        if (PACKED) { sym = se & 0xFFu; qc = MODE == 1 ? (int)i : (int)(((i << 8) + se) >> 9); snew = (i << 8) | sym; }   // (i<<8) + (p<<8|sym) < 2^32 for i, p < 2^23
+        else { sym = se; qc = qf(i, wave_readlane(p[0], r)); snew = sym; }
+        if (FLAGS & 2) {
+            const int qcl = (uint32_t)lane > r ? -1 : qc;                          // q >= 0: lanes above r always keep
+            const bool keep = q[0] > qcl, ins = qp > qc;
+            e[0] = keep ? e[0] : (ins ? snew : ep);
+            if (!PACKED) p[0] = keep ? p[0] : (ins ? spn : pp);
+            q[0] = keep ? q[0] : (ins ? qc : qp);
+        } else if ((uint32_t)lane <= r) {
+            const bool keep = q[0] > qc, ins = qp > qc;
+            e[0] = keep ? e[0] : (ins ? snew : ep);
+            if (!PACKED) p[0] = keep ? p[0] : (ins ? spn : pp);
+            q[0] = keep ? q[0] : (ins ? qc : qp);
+        }
+        refresh();
+        return sym;
+    }
+    // rank 0 (the symbol stays on top: nothing above it)
+    __device__ __forceinline__ uint32_t step_top(uint32_t i) {
+        const uint32_t se = wave_readlane(e[0], 0);
+        uint32_t sym;
+        int qc;
+        if (PACKED) { sym = se & 0xFFu; qc = MODE == 1 ? (int)i : (int)(((i << 8) + se) >> 9); e[0] = wave_writelane0(e[0], (i << 8) | sym); }
+        else { sym = se; qc = qf(i, wave_readlane(p[0], 0)); p[0] = wave_writelane0(p[0], i); }
+        q[0] = (int)wave_writelane0((uint32_t)q[0], (uint32_t)qc);
+        refresh();
+        return sym;
+    }
+    // `count` >= 2 consecutive ranks 0, the last one at time i
+    __device__ __forceinline__ uint32_t run_top(uint32_t i, uint32_t count) {
+        const uint32_t se = wave_readlane(e[0], 0);
+        const uint32_t sym = PACKED ? (se & 0xFFu) : se;
+        if (PACKED) e[0] = wave_writelane0(e[0], (i << 8) | sym); else p[0] = wave_writelane0(p[0], i);
+        q[0] = (int)wave_writelane0((uint32_t)q[0], (uint32_t)qf(i, i - 1));
+        refresh();
+        return sym;
+    }
+    // rare: rank 64..255. Landing rank by popcount over the four registers, one-lane shifts with the carry between registers.
+    __device__ __forceinline__ uint32_t step_high(uint32_t r, uint32_t i) {
+        const uint32_t kr = r >> 6, l = r & 63;
+        const uint32_t se = kr == 1 ? wave_readlane(e[1], l) : (kr == 2 ? wave_readlane(e[2], l) : wave_readlane(e[3], l));
+        uint32_t sym, snew, pc;
+        if (PACKED) { sym = se & 0xFFu; pc = se >> 8; snew = (i << 8) | sym; }
+        else { sym = se; snew = se; pc = kr == 1 ? wave_readlane(p[1], l) : (kr == 2 ? wave_readlane(p[2], l) : wave_readlane(p[3], l)); }
+        const int qc = qf(i, pc);
+        uint32_t j = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) j += (uint32_t)__popcll(wave_ballot(q[k] > qc));
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {                                            // high registers first: register k-1 is still old
+            const uint32_t x = 64u * (uint32_t)k + (uint32_t)lane;
+            const bool moved = x - j - 1u < r - j;
+            const bool ins = x == j;
+            uint32_t es = wave_shr1(e[k]), ps = wave_shr1(p[k]), qs = wave_shr1((uint32_t)q[k]);
+            if (k > 0) {
+                const uint32_t e63 = wave_bcast(e[k > 0 ? k - 1 : 0], 63), p63 = wave_bcast(p[k > 0 ? k - 1 : 0], 63), q63 = wave_bcast((uint32_t)q[k > 0 ? k - 1 : 0], 63);
+                if (lane == 0) { es = e63; ps = p63; qs = q63; }
+            }
+            e[k] = ins ? snew : (moved ? es : e[k]);
+            if (!PACKED) p[k] = ins ? i : (moved ? ps : p[k]);
+            q[k] = ins ? qc : (moved ? (int)qs : q[k]);
+        }
+        refresh();
+        return sym;
+    }
+    __device__ __forceinline__ uint32_t step_any(uint32_t r, uint32_t i) {
+        if (r == 0) return step_top(i);
+        if (r < 64) return step_low(r, i);
+        return step_high(r, i);
+    }
+    // four ranks of one input word, first at time i; returns the four symbols. A word with a rank >= 64 in it (rare behind a
+    // BWT) goes through the general step, so that the unrolled part carries no trace of the four-register path.
+    __device__ __forceinline__ uint32_t word(uint32_t w, uint32_t i) {
+        if (w == 0) return run_top(i + 3, 4) * 0x01010101u;
+        uint32_t out = 0;
+        if (w & 0xC0C0C0C0u) {
+#pragma nounroll
+            for (uint32_t u = 0; u < 4; u++) out |= step_any((w >> (8 * u)) & 0xFFu, i + u) << (8 * u);
+            return out;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t r = (w >> (8 * u)) & 0xFFu;
+            out |= ((FLAGS & 1) && r == 0 ? step_top(i + (uint32_t)u) : step_low(r, i + (uint32_t)u)) << (8 * u);
+        }
+        return out;
+    }
+};
+
+template <int MODE, bool PACKED, int FLAGS>
+__device__ __forceinline__ void knz_rank_chain_block(const uint8_t* src, uint8_t* dst, uint32_t n, int lane) {
+    RankChain<MODE, PACKED, FLAGS> c;
+    c.init_identity(lane);
+    uint32_t i0 = 0;
+    if (((((uintptr_t)src) | ((uintptr_t)dst)) & 3) == 0) {                     // (the pipeline's own regions are 16-byte aligned)
+        const uint32_t nw = n >> 2;                                             // whole words
+        uint32_t outv = 0, k = 0;
+        knz_u32x4 nxt = {0, 0, 0, 0};
+        if (nw >= 4) nxt = wave_sload_u32x4(src);
+        while (k + 4 <= nw) {
+            knz_u32x4 cur = nxt;
+            if (k + 8 <= nw) nxt = wave_sload_u32x4(src + 4 * (size_t)(k + 4)); // one group ahead of the chain
+            const uint32_t sel = (uint32_t)lane - (k & 63);                     // k is a multiple of 4: the group stays inside one 64-word row
+            if ((cur.x | cur.y | cur.z | cur.w) == 0) {
+                const uint32_t o = c.run_top(4 * k + 15, 16) * 0x01010101u;
+                outv = sel < 4 ? o : outv;
+            } else {
+#pragma nounroll
+                for (uint32_t wi = 0; wi < 4; wi++) {
+                    const uint32_t o = c.word(cur.x, 4 * (k + wi));
+                    outv = sel == wi ? o : outv;
+                    cur.x = cur.y; cur.y = cur.z; cur.z = cur.w;
+                }
+            }
+            k += 4;
+            if ((k & 63) == 0) ((uint32_t*)dst)[k - 64 + lane] = outv;          // 256 decoded bytes, coalesced
+        }
+        if ((k & 63) != 0 && (uint32_t)lane < (k & 63)) ((uint32_t*)dst)[(k & ~63u) + lane] = outv;
+        i0 = 4 * k;
+    }
+    for (uint32_t i = i0; i < n; i++) {                                         // the last < 16 ranks (or unaligned buffers): byte by byte
+        const uint32_t s = c.step_any(wave_uniform(src[i]), i);
+        if (lane == 0) dst[i] = (uint8_t)s;
+    }
+}
+
+// ---- the same chain with the uniform arithmetic on the vector ALU -----------------------------------------------------
+// Measured on one wave of an MI355X (tools/gpu/lat_bench.hip, profiles/r02_lone_wave_latencies.md): every instruction of a
+// lone wave costs ~2.5 ns whatever unit it runs on (5.75 clocks at 2.39 GHz), an SGPR written by the VALU and read by the
+// SALU adds ~6 ns, a taken branch ~10 ns. So the step is built to be SHORT and to stay on the vector ALU: the entry comes
+// back from v_readlane in an SGPR and is consumed by VALU instructions only (qc = (i8 + e) >> 9 and the new entry
+// (e & 0xFF) | i8 as wave-uniform VGPRs, v_and_or_b32), lanes above r are protected by replacing their q with INT_MAX
+// before the compare (off the loop-carried path: r is known early), the lane-1 copy of q keeps its +inf in lane 0 by being
+// shifted in place (DPP without bound_ctrl leaves lane 0 alone), and the decoded byte leaves through one v_writelane with a
+// compile-time lane (16 symbols per VGPR, stored by 16 lanes). ~17 instructions per symbol, no VALU -> SALU hand-over.
+template <int MODE, bool PACKED>
+struct RankChainV {
+    uint32_t e[4], p[4];
+    int q[4];
+    uint32_t ep, pp, vff;
+    int qp, lane;
+
+    __device__ __forceinline__ void refresh() {
+        ep = wave_shr1(e[0]);
+        if (!PACKED) pp = wave_shr1(p[0]);
+        qp = (int)wave_shr1_keep0((uint32_t)qp, (uint32_t)q[0]);              // lane 0 keeps INT_MAX
+    }
+    __device__ __forceinline__ void init_identity(int l) {
+        lane = l;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { e[k] = 64u * (uint32_t)k + (uint32_t)l; p[k] = 0; q[k] = 0; }
+        qp = 0x7FFFFFFF;
+        vff = wave_in_vgpr(0xFFu);
+        refresh();
+    }
+    static __device__ __forceinline__ int qf(uint32_t i, uint32_t pc) { return MODE == 1 ? (int)i : (int)((i + pc) >> 1); }
+
+    // rank r <= 63; vi8 = (time << 8) and vi = time as wave-uniform VGPR values. Returns the entry (low byte = symbol).
+    __device__ __forceinline__ uint32_t step_low(uint32_t r, uint32_t vi8, uint32_t vi) {
+        const uint32_t se = wave_readlane(e[0], r);
+        int vqc;
+        uint32_t vnew;
+        if (PACKED) { vqc = MODE == 1 ? (int)(vi8 >> 8) : (int)((se + vi8) >> 9); vnew = (se & vff) | vi8; }   // (i<<8) + (p<<8|sym) < 2^32 for i, p < 2^23
+        else { vqc = MODE == 1 ? (int)vi : (int)((wave_readlane(p[0], r) + vi) >> 1); vnew = se; }
+        const int qx = (int)wave_in_vgpr((uint32_t)lane > r ? 0x7FFFFFFFu : (uint32_t)q[0]);   // lanes above r always keep (opaque: or-ing two lane masks would go through the SALU)
+        const bool keep = qx > vqc, ins = qp > vqc;
+        e[0] = keep ? e[0] : (ins ? vnew : ep);
+        if (!PACKED) p[0] = keep ? p[0] : (ins ? vi : pp);
+        q[0] = keep ? q[0] : min(vqc, qp);
+        refresh();
+        return se;
+    }
+    // `count` >= 1 consecutive ranks 0, the last one at time i (scalar): the symbol on top stays there
+    __device__ __forceinline__ uint32_t run_top(uint32_t i, uint32_t count) {
+        const uint32_t se = wave_readlane(e[0], 0);
+        const uint32_t sym = PACKED ? (se & 0xFFu) : se;
+        const uint32_t pc = count > 1 ? i - 1 : (PACKED ? se >> 8 : wave_readlane(p[0], 0));
+        if (PACKED) e[0] = wave_writelane0(e[0], (i << 8) | sym); else p[0] = wave_writelane0(p[0], i);
+        q[0] = (int)wave_writelane0((uint32_t)q[0], (uint32_t)qf(i, pc));
+        refresh();
+        return sym;
+    }
+    // rank 64..255 (high-entropy blocks: ~17 % of the ranks of S-silesia's executable-like member). The same select step, one
+    // register of 64 ranks after the other from the one that holds r down to register 0; the lane-1 copy of a register takes its
+    // lane 0 from lane 63 of the register below. Registers above r's are not touched.
+    template <int K>
+    __device__ __forceinline__ void high_reg(uint32_t r, int vqc, uint32_t vnew, uint32_t vi) {
+        uint32_t es = wave_shr1(e[K]), ps = PACKED ? 0u : wave_shr1(p[K]);
+        int qs = (int)wave_shr1((uint32_t)q[K]);
+        if (K > 0) {
+            es = wave_writelane0(es, wave_bcast(e[K > 0 ? K - 1 : 0], 63));
+            if (!PACKED) ps = wave_writelane0(ps, wave_bcast(p[K > 0 ? K - 1 : 0], 63));
+            qs = (int)wave_writelane0((uint32_t)qs, wave_bcast((uint32_t)q[K > 0 ? K - 1 : 0], 63));
+        } else qs = qp;                                                           // register 0: the maintained copy (lane 0 = +inf)
+        const int qx = (int)wave_in_vgpr(64u * K + (uint32_t)lane > r ? 0x7FFFFFFFu : (uint32_t)q[K]);
+        const bool keep = qx > vqc, ins = qs > vqc;
+        e[K] = keep ? e[K] : (ins ? vnew : es);
+        if (!PACKED) p[K] = keep ? p[K] : (ins ? vi : ps);
+        q[K] = keep ? q[K] : min(vqc, qs);
+    }
+    __device__ __forceinline__ uint32_t step_high(uint32_t r, uint32_t vi8, uint32_t vi) {
+        const uint32_t kr = r >> 6, l = r & 63;
+        uint32_t se, sp = 0;
+        if (kr == 1) { se = wave_readlane(e[1], l); if (!PACKED) sp = wave_readlane(p[1], l); }
+        else if (kr == 2) { se = wave_readlane(e[2], l); if (!PACKED) sp = wave_readlane(p[2], l); }
+        else { se = wave_readlane(e[3], l); if (!PACKED) sp = wave_readlane(p[3], l); }
+        int vqc;
+        uint32_t vnew;
+        if (PACKED) { vqc = MODE == 1 ? (int)(vi8 >> 8) : (int)((se + vi8) >> 9); vnew = (se & vff) | vi8; }
+        else { vqc = MODE == 1 ? (int)vi : (int)((sp + vi) >> 1); vnew = se; }
+        if (kr == 3) high_reg<3>(r, vqc, vnew, vi);
+        if (kr >= 2) high_reg<2>(r, vqc, vnew, vi);
+        high_reg<1>(r, vqc, vnew, vi);
+        high_reg<0>(r, vqc, vnew, vi);
+        refresh();
+        return se;
+    }
+    // any rank, scalar time (tails, unaligned sources)
+    __device__ __forceinline__ uint32_t step_any(uint32_t r, uint32_t i) {
+        const uint32_t vi8 = wave_in_vgpr(i << 8), vi = wave_in_vgpr(i);
+        return (r < 64 ? step_low(r, vi8, vi) : step_high(r, vi8, vi)) & (PACKED ? 0xFFu : 0xFFFFFFFFu);
+    }
+    // four ranks of one word of a group that holds ranks >= 64, first symbol at time i; returns the symbols in lanes 0..3
+    __device__ __forceinline__ uint32_t word_any(uint32_t w, uint32_t i) {
+        if (w == 0) return run_top(i + 3, 4);
+        const uint32_t vi8 = wave_in_vgpr(i << 8), vi = wave_in_vgpr(i);
+        uint32_t ow = 0;
+        const uint32_t r0 = w & 0xFFu, r1 = (w >> 8) & 0xFFu, r2 = (w >> 16) & 0xFFu, r3 = w >> 24;
+        ow = wave_writelane_c<0>(ow, r0 < 64 ? step_low(r0, vi8, vi) : step_high(r0, vi8, vi));
+        ow = wave_writelane_c<1>(ow, r1 < 64 ? step_low(r1, vi8 + 0x100u, vi + 1u) : step_high(r1, vi8 + 0x100u, vi + 1u));
+        ow = wave_writelane_c<2>(ow, r2 < 64 ? step_low(r2, vi8 + 0x200u, vi + 2u) : step_high(r2, vi8 + 0x200u, vi + 2u));
+        ow = wave_writelane_c<3>(ow, r3 < 64 ? step_low(r3, vi8 + 0x300u, vi + 3u) : step_high(r3, vi8 + 0x300u, vi + 3u));
+        return ow;
+    }
+    // word W (0..3) of a 16-symbol group whose ranks are all < 64, first symbol at time i; symbols go to lanes 4W .. 4W+3 of
+    // ob (low byte): no branch and no register traffic between the steps
+    template <int W>
+    __device__ __forceinline__ void word(uint32_t w, uint32_t i, uint32_t& ob) {
+        if (w == 0) {
+            const uint32_t s = run_top(i + 3, 4);
+            ob = wave_writelane_c<4 * W>(ob, s); ob = wave_writelane_c<4 * W + 1>(ob, s);
+            ob = wave_writelane_c<4 * W + 2>(ob, s); ob = wave_writelane_c<4 * W + 3>(ob, s);
+            return;
+        }
+        const uint32_t vi8 = wave_in_vgpr(i << 8), vi = PACKED && MODE != 1 ? 0u : wave_in_vgpr(i);
+        ob = wave_writelane_c<4 * W>(ob, step_low(w & 0xFFu, vi8, vi));
+        ob = wave_writelane_c<4 * W + 1>(ob, step_low((w >> 8) & 0xFFu, vi8 + 0x100u, vi + 1u));
+        ob = wave_writelane_c<4 * W + 2>(ob, step_low((w >> 16) & 0xFFu, vi8 + 0x200u, vi + 2u));
+        ob = wave_writelane_c<4 * W + 3>(ob, step_low(w >> 24, vi8 + 0x300u, vi + 3u));
+    }
+};
+
+template <int MODE, bool PACKED>
+__device__ __forceinline__ void knz_rank_chain_block_v(const uint8_t* src, uint8_t* dst, uint32_t n, int lane) {
+    RankChainV<MODE, PACKED> c;
+    c.init_identity(lane);
+    uint32_t i0 = 0;
+    if ((((uintptr_t)src) & 3) == 0) {                                          // (the pipeline's own regions are 16-byte aligned)
+        const uint32_t ng = n >> 4;                                             // whole groups of 16 ranks
+        knz_u32x4 nxt = {0, 0, 0, 0};
+        if (ng) nxt = wave_sload_u32x4(src);
+        for (uint32_t g = 0; g < ng; g++) {
+            const knz_u32x4 cur = nxt;
+            if (g + 1 < ng) nxt = wave_sload_u32x4(src + 16 * (size_t)(g + 1));  // one group ahead of the chain
+            const uint32_t i = 16 * g;
+            uint32_t ob = 0;
+            const uint32_t any = cur.x | cur.y | cur.z | cur.w;
+            if (any == 0) ob = c.run_top(i + 15, 16);
+            else if (any & 0xC0C0C0C0u) {                                        // ranks >= 64 in the group: one dispatch per symbol, word by word
+                knz_u32x4 t = cur;
+#pragma nounroll
+                for (uint32_t wi = 0; wi < 4; wi++) {
+                    const uint32_t ow = c.word_any(t.x, i + 4 * wi);
+                    if (lane < 4) dst[i + 4 * wi + lane] = (uint8_t)ow;           // (a zero word's symbol is wave-uniform: every lane has it)
+                    t.x = t.y; t.y = t.z; t.z = t.w;
+                }
+                continue;
+            } else {
+                c.template word<0>(cur.x, i, ob); c.template word<1>(cur.y, i + 4, ob);
+                c.template word<2>(cur.z, i + 8, ob); c.template word<3>(cur.w, i + 12, ob);
+            }
+            if (lane < 16) dst[i + lane] = (uint8_t)ob;
+        }
+        i0 = 16 * ng;
+    }
+    for (uint32_t i = i0; i < n; i++) {                                         // the last < 16 ranks (or an unaligned source): byte by byte
+        const uint32_t s = c.step_any(wave_uniform(src[i]), i);
+        if (lane == 0) dst[i] = (uint8_t)s;
+    }
+}
+
+template <int MODE, int FLAGS>
+__global__ __launch_bounds__(64) void knz_rank_inverse_chain_kernel(XfArgs a) {
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (!a.active[b]) return;
+    const uint32_t n = a.in_len[b];
+    if (lane == 0) { a.out_len[b] = n; a.ok[b] = n <= a.out_cap ? 1 : -KNZ_ERR_PROCESS_BLOCK; }
+    if (n > a.out_cap) return;
+    const uint8_t* src = (const uint8_t*)a.in_ptr[b];
+    uint8_t* dst = (uint8_t*)a.out_ptr[b];
+    const bool packed = n <= (1u << 23) && !(a.mode & 0x100);                  // (bit 8 of mode: tests force the three-register form)
+    if (FLAGS & 4) {
+        if (packed) knz_rank_chain_block_v<MODE, true>(src, dst, n, lane);
+        else knz_rank_chain_block_v<MODE, false>(src, dst, n, lane);
+    } else {
+        if (packed) knz_rank_chain_block<MODE, true, FLAGS>(src, dst, n, lane);
+        else knz_rank_chain_block<MODE, false, FLAGS>(src, dst, n, lane);
+    }
+}

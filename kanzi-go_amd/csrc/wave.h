@@ -38,6 +38,25 @@ __device__ __forceinline__ uint32_t wave_writelane0(uint32_t v, uint32_t val) {
     asm("v_writelane_b32 %0, %1, 0" : "+v"(v) : "s"(sv));
     return v;
 }
+// value of lane-1, lane 0 keeps `old` (DPP wave_shr:1 without bound_ctrl: a lane whose source is out of range is not written)
+__device__ __forceinline__ uint32_t wave_shr1_old(uint32_t v, uint32_t old) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xF, 0xF, false); }
+// value of lane-1 written over `cur` in place: lane 0 keeps what `cur` holds there (one DPP move, no constant to re-materialise)
+__device__ __forceinline__ uint32_t wave_shr1_keep0(uint32_t cur, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)cur, (int)v, 0x138, 0xF, 0xF, false); }
+// hides a (wave-uniform) value in a VGPR: arithmetic on it is issued to the vector ALU, so that an SGPR written by a
+// v_readlane is consumed without the VALU -> SALU hand-over (~6 ns for a lone wave on gfx950, tools/gpu/lat_bench.hip)
+__device__ __forceinline__ uint32_t wave_in_vgpr(uint32_t x) { asm("" : "+v"(x)); return x; }
+// v with lane L (compile-time) replaced by the wave-uniform value `val`
+template <int L> __device__ __forceinline__ uint32_t wave_writelane_c(uint32_t v, uint32_t val) {
+    const int sv = __builtin_amdgcn_readfirstlane((int)val);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(sv), "n"(L));
+    return v;
+}
+// Wave-uniform read-only loads through the scalar cache (s_load_dword / s_load_dwordx4): the address must be the same in every
+// lane, 4-byte aligned, and the bytes must not be written by the running kernel (constant address space).
+typedef uint32_t knz_u32x4 __attribute__((ext_vector_type(4)));
+typedef knz_u32x4 knz_u32x4_a4 __attribute__((aligned(4)));
+__device__ __forceinline__ uint32_t wave_sload_u32(const uint8_t* p) { return *(const __attribute__((address_space(4))) uint32_t*)(uintptr_t)p; }
+__device__ __forceinline__ knz_u32x4 wave_sload_u32x4(const uint8_t* p) { return *(const __attribute__((address_space(4))) knz_u32x4_a4*)(uintptr_t)p; }
 // tells the compiler that v is the same in every lane (moves it to an SGPR)
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // full-rate 24 x 24 -> 32 bit multiply (v_mul_u32_u24): both factors must be < 2^24
@@ -96,6 +115,13 @@ inline void wave_sync_lds() { hipemu::wave_barrier(); }
 inline uint32_t wave_shr1(uint32_t v) { const uint32_t r = wave_shfl(v, hipemu::lane() - 1); return hipemu::lane() == 0 ? 0u : r; }
 inline uint32_t wave_writelane0(uint32_t v, uint32_t val) { return hipemu::lane() == 0 ? val : v; }
 inline uint32_t wave_shl1(uint32_t v) { const uint32_t r = wave_shfl(v, hipemu::lane() + 1); return hipemu::lane() == 63 ? 0u : r; }
+inline uint32_t wave_shr1_old(uint32_t v, uint32_t old) { const uint32_t r = wave_shfl(v, hipemu::lane() - 1); return hipemu::lane() == 0 ? old : r; }
+inline uint32_t wave_shr1_keep0(uint32_t cur, uint32_t v) { const uint32_t r = wave_shfl(v, hipemu::lane() - 1); return hipemu::lane() == 0 ? cur : r; }
+inline uint32_t wave_in_vgpr(uint32_t x) { return x; }
+template <int L> inline uint32_t wave_writelane_c(uint32_t v, uint32_t val) { return hipemu::lane() == L ? val : v; }
+struct knz_u32x4 { uint32_t x, y, z, w; };
+inline uint32_t wave_sload_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+inline knz_u32x4 wave_sload_u32x4(const uint8_t* p) { knz_u32x4 v; __builtin_memcpy(&v, p, 16); return v; }
 #endif
 
 // inclusive prefix sum across the wave

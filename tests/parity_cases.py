@@ -305,6 +305,33 @@ def check_transform(be, tname, max_len=1 << 30):
     c.close()
 
 
+def check_rank_chain_variants(be, monkeypatch, max_len=1 << 30, bwt_len=150000):
+    """Inverse RANK chain (rank_inv.hip): every kept variant of the step x the packed / three-register forms (the latter is
+    what blocks > 8 MiB use), on inputs with ranks >= 64, all-zero words, ragged tails; against the oracle's forward."""
+    import os
+    c = K.Codec("NONE", "NONE", 1 << 20, lib=be.lib)
+    t = K.ByteTransform(c, "RANK")
+    rng = np.random.default_rng(77)
+    extra = [("tail%d" % k, (np.minimum(rng.geometric(0.3, 4099 + k), 200) - 1).astype(np.uint8).tobytes()) for k in range(4)]
+    extra.append(("bwtlike", O.transform_forward(_TID["BWT"], corpus(bwt_len))))
+    cases = [(nm, d) for nm, d in list(transform_inputs(max_len=max_len)) + extra if len(d) > 0]
+    fwd = [(nm, d, O.transform_forward(_TID["RANK"], d)) for nm, d in cases]
+    for variant in ("0", "3", "5"):
+        for unpacked in (False, True):
+            monkeypatch.setenv("KNZ_RANK_VARIANT", variant)
+            if unpacked:
+                monkeypatch.setenv("KNZ_RANK_UNPACKED", "1")
+            else:
+                monkeypatch.delenv("KNZ_RANK_UNPACKED", raising=False)
+            for nm, d, f in fwd:
+                if f is None:
+                    continue
+                assert t.inverse(f, len(d) + 512) == d, (variant, unpacked, nm)
+    monkeypatch.delenv("KNZ_RANK_VARIANT", raising=False)
+    monkeypatch.delenv("KNZ_RANK_UNPACKED", raising=False)
+    c.close()
+
+
 def _huffman_header_with_wrapped_delta(payload, nbits):
     """Re-encodes one negative code-length delta (-2..-11) of a Huffman chunk header with the 16-bit Exp-Golomb form whose
     magnitude wraps as int8 (ExpGolombCodec.go:159-190, readLengths casts to int8): a stream no kanzi encoder writes but
