@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
 """bench.py — encode+decode throughput of the MI355X-native Kanzi hot path (BASELINE.json metric).
 
-Workload (N=1): BASELINE.json configs[1] = `-t NONE -e HUFFMAN -b 4m` on S-silesia (211,957,760 synthetic bytes
-shaped like silesia.tar, bench_corpus.py). One step = compress the whole stream on the device (bit-exact .knz) and
-decompress it back, inputs resident in HBM. value = uncompressed MB (10^6 B) per second of a whole round trip;
-encode-only and decode-only rates are reported next to it.
+Workload (N=1, default): BASELINE.json configs[3] = `-t BWT+RANK+ZRLT -e ANS1 -b 8m` on S-silesia (211,957,760 synthetic
+bytes shaped like silesia.tar, bench_corpus.py; 26 blocks) — the configuration the north-star target is quoted on.
+One step = compress the whole stream on the device (bit-exact .knz) and decompress it back, inputs resident in HBM.
+value = uncompressed MB (10^6 B) per second of a whole round trip; encode-only and decode-only rates are reported next to
+it. The other BASELINE configs are reachable with --config (huffman = configs[1], lz / ans0 = configs[2], fpaq = configs[4]).
 
-N>1 (weak scaling: per-GPU work is fixed): the stream is N copies of S-silesia back to back (N x 211,957,760 B, one .knz
-stream); its blocks are sharded statically (contiguous ranges, ~51 blocks per rank) over the ranks; every rank
-encodes/decodes its own blocks, the compressed segments are gathered to rank 0 over RCCL and assembled bit-granularly
-there; the gather stays in flight while each rank decodes its own segment. value = all bytes of all ranks / step time.
+N>1: `--scaling strong` (default): the SAME job (one S-silesia stream) is split over the ranks: contiguous block ranges
+(26 blocks over 8 GPUs = 4,4,3,3,3,3,3,3), every rank encodes/decodes its own blocks, the compressed segments are
+gathered to rank 0 over RCCL with their exact sizes (grouped send/recv) and assembled bit-granularly there; the gather
+stays in flight while each rank decodes its own segment. value = bytes of the job / step time (max over ranks).
+`--scaling weak`: N copies of the corpus back to back in one stream (per-GPU work fixed).
+
+Also on the line (N=1): roofline of the dominant KERNEL (HIP-event time of its launches inside the library,
+`knz_last_kernel_times`; HBM traffic from two live rocprofv3 PMC passes of this same command when rocprofv3 is
+present), the PCIe-inclusive rate of the host-pointer batch hook the cgo shim calls (`host_hook_MBps`), and the CPU
+baseline (oracle = C++ restatement of the kanzi-go CPU path, bounded sample).
 
 KNZ_BENCH_EMU=1 is a TEST HARNESS switch (tests/test_bench_ranks.py): the same control flow on CPU tensors with the kernels
 compiled against tests/emu and gloo instead of RCCL, so that the N>1 step can be exercised without GPUs. It is not a
@@ -18,10 +25,15 @@ product path and its JSON says so.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import importlib.util
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -33,13 +45,49 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 CONFIGS = {
-    # name: (transform, entropy, block size, BASELINE.json config index)
-    "huffman": ("NONE", "HUFFMAN", 4 << 20, 1),
-    "ans0": ("NONE", "ANS0", 4 << 20, 2),       # entropy half of configs[2] (LZ front end: see DESIGN.md)
-    "lz": ("LZ", "ANS0", 4 << 20, 2),
-    "bwt": ("BWT+RANK+ZRLT", "ANS1", 8 << 20, 3),
-    "fpaq": ("BWT+RANK+ZRLT", "FPAQ", 32 << 20, 4),   # configs[4] codec on S-silesia-shaped data (enwik9-sized input: --size 1000000000)
+    # name: (transform, entropy, block size, BASELINE.json config index, corpus)
+    "huffman": ("NONE", "HUFFMAN", 4 << 20, 1, "silesia"),
+    "ans0": ("NONE", "ANS0", 4 << 20, 2, "silesia"),       # entropy half of configs[2]
+    "lz": ("LZ", "ANS0", 4 << 20, 2, "silesia"),
+    "bwt": ("BWT+RANK+ZRLT", "ANS1", 8 << 20, 3, "silesia"),
+    "fpaq": ("BWT+RANK+ZRLT", "FPAQ", 32 << 20, 4, "enwik"),   # configs[4]: S-enwik, 10^9 B with --size 1000000000 (default here: 2 x 10^8)
 }
+
+# what the reference publishes for the nearest shipped preset (other hardware; context only)
+PUBLISHED = {
+    "bwt": {"preset": "-l 5 = TEXT+UTF+BWT+RANK+ZRLT&ANS0, 4 MiB blocks", "encode_MBps": 225, "decode_MBps": 533,
+            "hardware": "AMD Ryzen 9950X, 16 jobs", "source": "kanzi-go README.md:79"},
+    "fpaq": {"preset": "-l 6 = TEXT+UTF+BWT+SRT+ZRLT&FPAQ, 8 MiB blocks", "encode_MBps": 169, "decode_MBps": 218,
+             "hardware": "AMD Ryzen 9950X, 16 jobs", "source": "kanzi-go README.md:81"},
+    "lz": {"preset": "-l 2 = DNA+LZ&HUFFMAN, 4 MiB blocks", "encode_MBps": 1547, "decode_MBps": 2409,
+           "hardware": "AMD Ryzen 9950X, 16 jobs", "source": "kanzi-go README.md:68"},
+}
+
+# algorithmic HBM bytes of one launch over a batch: n = bytes in front of the transforms, m = bytes behind them (entropy
+# coder input), c = compressed bytes (every stage reads its input once and writes its output once)
+KERNEL_BYTES = {
+    "knz_rank_inverse_chain_kernel": lambda n, m, c: 2 * n, "knz_sbrt_inverse_kernel": lambda n, m, c: 2 * n,
+    "knz_sbrt_apply_kernel": lambda n, m, c: 2 * n, "knz_bwt_inv_chains_kernel": lambda n, m, c: 2 * n,
+    "knz_bwt_inv_walk_kernel": lambda n, m, c: 2 * n, "knz_bwt_inv_emit_kernel": lambda n, m, c: 2 * n,
+    "knz_ans1_decode_lds_kernel": lambda n, m, c: c + m, "knz_ans1_decode_kernel": lambda n, m, c: c + m,
+    "knz_ans1_encode_kernel": lambda n, m, c: m + c, "knz_ans1_expand_kernel": lambda n, m, c: m, "knz_ans1_hist_kernel": lambda n, m, c: m,
+    "knz_fpaq_encode_kernel": lambda n, m, c: m + c, "knz_fpaq_decode_kernel": lambda n, m, c: c + m,
+    "knz_fpaq_probs_kernel": lambda n, m, c: m, "knz_fpaq_code_kernel": lambda n, m, c: m + c,
+    "knz_lz_forward_kernel": lambda n, m, c: n + m, "knz_lz_inverse_kernel": lambda n, m, c: m + n,
+    "knz_lz_parse_kernel": lambda n, m, c: n + m, "knz_lz_candidates_kernel": lambda n, m, c: n,
+    "knz_lzp_forward_kernel": lambda n, m, c: n + m, "knz_lzp_inverse_kernel": lambda n, m, c: m + n,
+    "knz_srt_inverse_kernel": lambda n, m, c: 2 * n,
+    "knz_huf_hist_kernel": lambda n, m, c: m, "knz_huf_lengths_kernel": lambda n, m, c: 768 * ((m + 16383) // 16384),
+    "knz_huf_encode_kernel": lambda n, m, c: m + c, "knz_huf_walk_decode_kernel": lambda n, m, c: c + m,
+    "knz_huf_decode_par_kernel": lambda n, m, c: c + m, "knz_ans0_encode_kernel": lambda n, m, c: m + c,
+    "knz_ans0_walk_decode_kernel": lambda n, m, c: c + m, "knz_ans0_decode_kernel": lambda n, m, c: c + m,
+    "knz_gather_kernel": lambda n, m, c: 2 * c, "knz_utf_forward_kernel": lambda n, m, c: 2 * n, "knz_utf_inverse_kernel": lambda n, m, c: 2 * n,
+}
+
+
+def kernel_key(name):
+    m = re.search(r"knz_\w+", name)
+    return m.group(0) if m else name
 
 
 def load_pkg():
@@ -55,43 +103,118 @@ def cpu_baseline(data, transform, entropy, bs, budget_s=20.0):
     """The oracle (C++ restatement of the kanzi-go CPU path, kind 'port') on the host cores, bounded sample."""
     import oracle_lib as O
     cores = os.cpu_count() or 1
-    sample = data
-    # probe on 32 MiB, then size the sample to ~budget_s of CPU work
-    probe = data[: min(len(data), 32 << 20)]
+    probe = data[: min(len(data), max(bs, 32 << 20))]
     t0 = time.perf_counter()
     c = O.compress(probe, transform, entropy, bs, 0, jobs=cores)
     O.decompress(c, len(probe) + 64, jobs=cores)
     dt = time.perf_counter() - t0
     rate = len(probe) / dt
     n = int(min(len(data), max(len(probe), rate * budget_s)))
-    n = max(bs, (n // bs) * bs)
+    n = max(bs, (n // bs) * bs) if n >= bs else n
     sample = data[:n]
+    nblk = (len(sample) + bs - 1) // bs
     t0 = time.perf_counter()
     c = O.compress(sample, transform, entropy, bs, 0, jobs=cores)
     t1 = time.perf_counter()
     back = O.decompress(c, len(sample) + 64, jobs=cores)
     t2 = time.perf_counter()
     assert back == sample.tobytes()
+    busy = min(cores, nblk)
+    bwt_label = O.bwt_kind() if hasattr(O, "bwt_kind") else "SA-IS (not the reference's divsufsort)"
     return {
-        "value": round(len(sample) / 1e6 / (t2 - t0), 2), "unit": "MB/s", "cores": cores, "kind": "port",
+        "value": round(len(sample) / 1e6 / (t2 - t0), 2), "unit": "MB/s", "cores": busy, "kind": "port",
         "encode_MBps": round(len(sample) / 1e6 / (t1 - t0), 2), "decode_MBps": round(len(sample) / 1e6 / (t2 - t1), 2),
-        "sample": f"first {len(sample)} bytes of S-silesia, {transform}/{entropy} -b {bs}, round trip, one block per thread",
-        "note": "C++ restatement of the kanzi-go CPU path (no Go toolchain in the image)",
+        "encode_MBps_per_thread": round(len(sample) / 1e6 / (t1 - t0) / busy, 2),
+        "sample": f"first {len(sample)} bytes of the corpus ({nblk} blocks), {transform}/{entropy} -b {bs}, round trip, one block per thread "
+                  f"({busy} of {cores} host threads busy)",
+        "note": "C++ restatement of the kanzi-go CPU path (the Go toolchain is absent from the image: not the Go binary)"
+                + (f"; forward BWT stage = {bwt_label}" if "BWT" in transform else ""),
     }
+
+
+def host_hook_rate(K, codec_args, data, bs):
+    """PCIe-inclusive rate of knz_encode_blocks / knz_decode_blocks (the calls the cgo shim of Writer.processBlock /
+    Reader.processBlock makes): blocks in pageable host memory in, block-local streams in host memory out. Second call timed."""
+    from kanzi_go_amd import api as A
+    c = K.Codec(*codec_args)
+    blocks = [data[i:i + bs] for i in range(0, len(data), bs)]
+
+    def batch(srcs, cap):
+        arr = (A._Block * len(srcs))()
+        keep = []
+        for i, b in enumerate(srcs):
+            a = np.ascontiguousarray(b)
+            o = np.zeros(cap, dtype=np.uint8)
+            keep.append((a, o))
+            arr[i].src = a.ctypes.data; arr[i].src_len = len(a); arr[i].dst = o.ctypes.data; arr[i].dst_cap = cap
+        return arr, keep
+
+    def timed(fn, arr, n):
+        c._chk(fn(c.h, arr, n))
+        t0 = time.perf_counter()
+        c._chk(fn(c.h, arr, n))
+        return time.perf_counter() - t0
+
+    arr, keep = batch(blocks, int(c.L.knz_max_encoded_len(c.cfg.transform, bs)) * 2 + 262144)
+    te = timed(c.L.knz_encode_blocks, arr, len(blocks))
+    payloads = [keep[i][1][: (arr[i].out_bits + 7) // 8].copy() for i in range(len(blocks))]
+    arr2, keep2 = batch(payloads, bs + max(512, bs >> 4))
+    td = timed(c.L.knz_decode_blocks, arr2, len(blocks))
+    ok = all(bytes(keep2[i][1][: arr2[i].out_bits]) == bytes(blocks[i]) for i in range(len(blocks)))
+    c.close()
+    n = len(data)
+    return {"encode": round(n / 1e6 / te, 1), "decode": round(n / 1e6 / td, 1), "round_trip": round(n / 1e6 / (te + td), 1), "ok": ok,
+            "what": "knz_encode_blocks + knz_decode_blocks, all blocks of the stream in pageable host memory (H2D and D2H inside the timed call)"}
+
+
+def pmc_traffic(argv_child, timeout_s=420):
+    """HBM bytes per launch for every knz_ kernel: two rocprofv3 passes of THIS command (--kernel-trace --pmc FETCH_SIZE, then
+    WRITE_SIZE: separate passes as MI355X_MICROARCH.md prescribes), rocpd databases read with tools/pmc_traffic.py.
+    gfx950 correction from the same guide: fetch bytes = 2 * FETCH_SIZE * 1024, WRITE_SIZE (KB) as is."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic as P
+    tmp = tempfile.mkdtemp(prefix="knz_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    res = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + argv_child
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s, cwd=tmp,
+                               env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")))
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if p.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): {p.stderr[-300:]}"
+            res[counter] = P.per_kernel(dbs[0], counter)
+        out = {}
+        for k in set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"]):
+            f, w = res["FETCH_SIZE"].get(k, 0.0), res["WRITE_SIZE"].get(k, 0.0)
+            key = kernel_key(k)
+            out[key] = out.get(key, 0) + int(2 * f * 1024 + w * 1024)
+        return out, "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command (2 steps each), per-launch averages"
+    except Exception as e:   # noqa: BLE001 (a profiler problem must not cost the bench line)
+        return None, f"rocprofv3 pass failed: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="huffman", choices=sorted(CONFIGS))
-    ap.add_argument("--size", type=int, default=0, help="override the per-GPU corpus size (debug)")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="bwt", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N>1: split one fixed job (strong) or one corpus copy per GPU (weak)")
+    ap.add_argument("--size", type=int, default=0, help="override the corpus size (debug; fpaq: 1000000000 = BASELINE configs[4])")
     ap.add_argument("--block-size", type=int, default=0, help="override the block size (debug)")
     ap.add_argument("--transform", default="", help="override the transform sequence of the config, e.g. LZP or BWT+SRT+ZRLT (debug)")
     ap.add_argument("--entropy", default="", help="override the entropy codec of the config (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes (roofline.traffic = null)")
+    ap.add_argument("--no-host-hook", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
     args = ap.parse_args()
 
     import torch
@@ -123,17 +246,24 @@ def main():
         K.build_library()
         lib = None
     from kanzi_go_amd import dist as kd
-    transform, entropy, bs, cfg_idx = CONFIGS[args.config]
+    transform, entropy, bs, cfg_idx, corpus = CONFIGS[args.config]
     transform, entropy = args.transform or transform, args.entropy or entropy
     bs = args.block_size or bs
 
-    base_size = args.size or bench_corpus.SILESIA_SIZE
-    base = bench_corpus.s_silesia(base_size)
-    size = base_size * world                                 # weak scaling: one copy of the corpus per GPU, ONE stream
+    if corpus == "enwik":
+        base_size = args.size or 200_000_000
+        base = bench_corpus.s_enwik(base_size)
+        corpus_name = "S-enwik"
+    else:
+        base_size = args.size or bench_corpus.SILESIA_SIZE
+        base = bench_corpus.s_silesia(base_size)
+        corpus_name = "S-silesia"
+    strong = args.scaling == "strong" or world == 1
+    size = base_size if strong else base_size * world       # strong: ONE job whatever N; weak: one corpus copy per GPU, one stream
     nblocks = (size + bs - 1) // bs
     lo_b, hi_b = kd.block_range(nblocks, rank, world)
-    per = (nblocks + world - 1) // world
-    lo, hi = lo_b * bs, min(hi_b * bs, size)
+    per = kd.max_blocks_per_rank(nblocks, world)
+    lo, hi = min(lo_b * bs, size), min(hi_b * bs, size)
 
     def tiled(a, b):                                         # bytes [a, b) of the corpus repeated back to back
         parts = []
@@ -155,15 +285,22 @@ def main():
     d_src = dev_zeros(max(n_my, 16))
     if n_my:
         d_src[:n_my] = torch.from_numpy(np.ascontiguousarray(my)).to(dev)
-    cap = (per * bs + (per * bs) // 2 + (1 << 20) + 15) & ~15   # same on every rank (gather uses equal-sized buffers)
+    cap = (per * bs + (per * bs) // 2 + (1 << 20) + 15) & ~15
     d_seg = dev_zeros(cap)
     d_back = dev_zeros(n_my + 4096)
     d_stream = dev_zeros(size + size // 2 + (1 << 20)) if rank == 0 and world > 1 else None
     stream = 0 if emu else torch.cuda.current_stream().cuda_stream
 
     stage = {"enc_transform": 0.0, "enc_entropy": 0.0, "enc_layout": 0.0, "enc_gather": 0.0, "dec_walk": 0.0, "dec_entropy": 0.0, "dec_transform": 0.0}
+    kern_ms, kern_launches = {}, {}
     t_enc = t_dec = 0.0
     result = {}
+
+    def add_kernels(codec_):
+        for name, ms in codec_.last_kernel_times():
+            k = kernel_key(name)
+            kern_ms[k] = kern_ms.get(k, 0.0) + ms
+            kern_launches[k] = kern_launches.get(k, 0) + 1
 
     def one_step(timed):
         nonlocal t_enc, t_dec
@@ -177,6 +314,8 @@ def main():
             pending, nbits = kd.sharded_compress_begin(codec, d_src, n_my, d_seg, size, d_stream if rank == 0 else d_seg, stream=stream)
             result["seg_bits"] = nbits
         tm = codec.last_timing()
+        if timed:
+            add_kernels(codec)
         if world == 1:
             sync()
         t1 = time.perf_counter()
@@ -184,7 +323,9 @@ def main():
             nd = codec.dev_decompress(d_seg.data_ptr(), result["stream_bytes"], d_back.data_ptr(), d_back.numel(), stream=stream)
         else:
             nd = codec.dev_decompress_blocks(d_seg.data_ptr(), result["seg_bits"], d_back.data_ptr(), d_back.numel(), stream=stream) if n_my else 0
-        td = codec.last_timing()
+        td = codec.last_timing() if (world == 1 or n_my) else [0.0] * 4
+        if timed and (world == 1 or n_my):
+            add_kernels(codec)
         sync()
         t2 = time.perf_counter()
         if world > 1:
@@ -228,48 +369,67 @@ def main():
         K_ = max(args.steps, 1)
         ms = elapsed / K_ * 1e3
         C_bytes = result["stream_bytes"]
+        counts = kd.blocks_per_rank(nblocks, world)
         out = {
             "metric": "encode+decode MB/s (round trip of the whole stream, uncompressed 10^6 B per second)",
             "value": round(size / 1e6 / (elapsed / K_), 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic" if not emu else "synthetic (EMULATOR TEST HARNESS on CPU: not a measurement)",
-            "config": {"workload": f"BASELINE.json configs[{cfg_idx}]: -t {transform} -e {entropy} -b {bs >> 20}m on "
-                                   + (f"{world} x " if world > 1 else "") + f"S-silesia ({base_size} B per GPU, one stream of {size} B, bench_corpus.py)",
+            "config": {"workload": f"BASELINE.json configs[{cfg_idx}]: -t {transform} -e {entropy} -b {bs >> 20}m on {corpus_name} "
+                                   f"(one .knz stream of {size} B" + ("" if strong else f" = {world} copies of {base_size} B") + ", bench_corpus.py)",
                        "blocks": nblocks, "block_size": bs,
-                       "parallelism": f"contiguous block ranges over {world} GPU(s), segments gathered to rank 0"},
+                       "parallelism": f"contiguous block ranges over {world} GPU(s) ({','.join(str(x) for x in counts)} blocks), segments gathered to rank 0"},
             "encode_MBps": round(size / 1e6 / (t_enc / K_), 2), "decode_MBps": round(size / 1e6 / (t_dec / K_), 2),
             "compressed_bytes": int(C_bytes), "roundtrip_ok": ok_roundtrip,
         }
-        # roofline of the dominant kernel, timed with HIP events on the launch stream inside the library
+        if args.config in PUBLISHED and not (args.transform or args.entropy):
+            out["reference_published"] = PUBLISHED[args.config]
+        # roofline of the dominant KERNEL: HIP events around its launches on the launch stream (knz_last_kernel_times)
+        n_local = n_my
+        c_local = (result.get("seg_bits", C_bytes * 8) + 7) // 8 if world > 1 else C_bytes
+        try:
+            m_local = codec.last_counter(1) or n_local            # bytes behind the transforms (entropy coder input) of the last encode batch
+        except Exception:   # noqa: BLE001
+            m_local = n_local
         per_launch = {k: v / K_ for k, v in stage.items()}
-        n_local, c_local = n_my, (result.get("seg_bits", C_bytes * 8) + 7) // 8 if world > 1 else C_bytes
-        kern = {
-            {"HUFFMAN": "knz_huf_hist+lengths+encode_kernels", "ANS0": "knz_ans0_stats+encode_kernels", "ANS1": "knz_ans1_hist+stats+merge+encode_kernels", "FPAQ": "knz_fpaq_encode_kernel", "NONE": "knz_raw_units_kernel"}[entropy]: (per_launch["enc_entropy"], n_local + c_local),
-            {"HUFFMAN": "knz_huf_walk_decode_kernel", "ANS0": "knz_ans0_walk_decode_kernel", "ANS1": "knz_ans1_dec_tables+decode_kernels", "FPAQ": "knz_fpaq_decode_kernel", "NONE": "knz_huf_decode_kernel (raw copy)"}[entropy]: (per_launch["dec_entropy"], n_local + c_local),
-            ("knz_dec_block_headers_kernel" if entropy in ("HUFFMAN", "ANS0") else "knz_dec_walk_blocks_kernel"): (per_launch["dec_walk"], c_local),
-            "forward transform stage kernels (" + transform + ")": (per_launch["enc_transform"], 2 * n_local),
-            "inverse transform stage kernels (" + transform + ")": (per_launch["dec_transform"], 2 * n_local),
-        }
-        dom = max(kern, key=lambda k: kern[k][0])
-        dur_ms, alg = kern[dom]
-        ach = alg / 1e9 / (dur_ms / 1e3) if dur_ms > 0 else 0.0
-        traffic = None
-        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/, see its _how)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_config2_v4.json")))
-            if args.config == "huffman" and world == 1 and not args.size and dom in pm["kernels"]:
-                traffic = pm["kernels"][dom]["hbm_bytes_corrected"]
-        except Exception:
-            traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                           "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(dur_ms, 4),
-                           "all_stage_ms": {k: round(v, 4) for k, v in per_launch.items()}}
+        roof = {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None,
+                "all_stage_ms": {k: round(v, 4) for k, v in per_launch.items()}}
+        if kern_ms:
+            dom = max(kern_ms, key=lambda k: kern_ms[k])
+            avg_ms = kern_ms[dom] / max(kern_launches[dom], 1)
+            launches_per_step = kern_launches[dom] / K_
+            alg = KERNEL_BYTES.get(dom, lambda n, m, c: n + c)(n_local, m_local, c_local) / max(launches_per_step, 1)
+            ach = alg / 1e9 / (avg_ms / 1e3) if avg_ms > 0 else 0.0
+            roof.update({"kernel": dom, "achieved": round(ach, 3), "frac": round(ach / HBM_PEAK_GBS, 6),
+                         "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
+                         "timing": "HIP events around the kernel's launches on the launch stream (knz_last_kernel_times)",
+                         "kernel_ms_per_step": {k: round(v / K_, 3) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])[:12]}})
+            if not args.no_pmc and world == 1 and not emu:
+                child = ["--config", args.config, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-verify", "--no-pmc", "--no-host-hook"]
+                for flag, val in (("--size", args.size), ("--block-size", args.block_size)):
+                    if val:
+                        child += [flag, str(val)]
+                for flag, val in (("--transform", args.transform), ("--entropy", args.entropy)):
+                    if val:
+                        child += [flag, val]
+                tr, how = pmc_traffic(child)
+                roof["traffic_source"] = how
+                if tr is not None and dom in tr:
+                    roof["traffic"] = int(tr[dom])
+                    roof["traffic_over_algorithmic"] = round(tr[dom] / max(alg, 1), 3)
+        out["roofline"] = roof
         if not args.no_verify:
             import oracle_lib as O
             exp = O.compress(tiled(0, size), transform, entropy, bs, 0, jobs=os.cpu_count() or 1)
             got = (d_seg if world == 1 else d_stream)[:C_bytes].cpu().numpy().tobytes()
             out["bit_exact_vs_oracle"] = bool(got == exp)
+            out["parity_note"] = "oracle = in-repo C++ restatement of kanzi-go; no Go toolchain in the image, so no reference-generated stream pins it (DESIGN.md section 2)"
+        if world == 1 and not emu and not args.no_host_hook:
+            try:
+                out["host_hook_MBps"] = host_hook_rate(K, (transform, entropy, bs, 0, local_rank), base[:size], bs)
+            except Exception as e:   # noqa: BLE001
+                out["host_hook_MBps"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(base, transform, entropy, bs)
         print(json.dumps(out), flush=True)

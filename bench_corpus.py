@@ -134,6 +134,55 @@ def s_silesia(size=SILESIA_SIZE):
     return np.ascontiguousarray(out[:size])
 
 
+def s_enwik(size=1_000_000_000, seed=20):
+    """S-enwik: XML-ish text, seed 20. Wiki-dump shaped: <page> records with a few tag lines (title, id, timestamp,
+    contributor) around a body of dictionary text with [[links]], ''markup'' and &quot; entities. Generated in 16 MB pieces
+    (PCG64 seeded per piece) so that any prefix is reproducible and 10^9 bytes never need more than one piece of scratch."""
+    piece = 16_000_000
+    parts, made, k = [], 0, 0
+    while made < size:
+        n = min(piece, size - made)
+        rng = np.random.Generator(np.random.PCG64(seed * 1000 + k))
+        body = _text(rng, n + 4096, dict_size=50000)
+        out = body[:n].copy()
+        # sprinkle markup: every ~2.5 KB a page header, every ~90 bytes a link / quote / entity
+        hdr = np.frombuffer(b"  </revision>\n  </page>\n  <page>\n    <title>", dtype=np.uint8)
+        mid = np.frombuffer(b"</title>\n    <id>", dtype=np.uint8)
+        tail = np.frombuffer(b"</id>\n    <revision>\n      <timestamp>2006-03-03T", dtype=np.uint8)
+        txt = np.frombuffer(b":00Z</timestamp>\n      <contributor>\n        <username>", dtype=np.uint8)
+        txt2 = np.frombuffer(b"</username>\n      </contributor>\n      <text xml:space=\"preserve\">", dtype=np.uint8)
+        pos = int(rng.integers(0, 1500))
+        pid = 1000 + 7919 * k
+        while pos + 400 < n:
+            cur = pos
+            for frag in (hdr, None, mid, str(pid).encode(), tail, f"{pid % 24:02d}:{pid % 60:02d}".encode(), txt, None, txt2):
+                if frag is None:
+                    ln = int(rng.integers(6, 24))
+                    cur += ln                                   # keep the body's words as title / user name
+                    continue
+                f = np.frombuffer(frag, dtype=np.uint8) if isinstance(frag, bytes) else frag
+                out[cur:cur + len(f)] = f
+                cur += len(f)
+            pid += int(rng.integers(1, 40))
+            pos = cur + int(rng.integers(800, 4200))
+        marks = rng.integers(40, 140, n // 90 + 1).cumsum()
+        marks = marks[marks < n - 16]
+        kinds = rng.integers(0, 4, len(marks))
+        for m, kd in zip(marks.tolist(), kinds.tolist()):
+            if kd == 0:
+                out[m:m + 2] = (91, 91); ln = 5 + (m % 13); out[m + ln:m + ln + 2] = (93, 93)
+            elif kd == 1:
+                out[m:m + 2] = (39, 39); ln = 4 + (m % 9); out[m + ln:m + ln + 2] = (39, 39)
+            elif kd == 2:
+                out[m:m + 6] = np.frombuffer(b"&quot;", dtype=np.uint8)
+            else:
+                out[m] = 10
+        parts.append(out)
+        made += n
+        k += 1
+    return np.ascontiguousarray(np.concatenate(parts)[:size])
+
+
 def s_rand(n, seed=101):
     return np.random.Generator(np.random.PCG64(seed)).integers(0, 256, n, dtype=np.uint8)
 

@@ -132,9 +132,15 @@ int knz_entropy_decode(void* handle, uint32_t type, const uint8_t* bits, uint64_
 enum { KNZ_STAGE_TRANSFORM = 0, KNZ_STAGE_ENTROPY = 1, KNZ_STAGE_LAYOUT = 2, KNZ_STAGE_GATHER = 3, KNZ_STAGE_COUNT = 4 };
 int knz_last_timing(void* handle, float* stage_ms, int cap);
 
+/* Per-kernel times of the last device batch: the launches that can dominate a batch (the per-block chains, the entropy
+ * kernels) are bracketed by a HIP event pair on the launch stream. names receives the kernel names separated by '\n'
+ * (launch order, a kernel launched several times appears several times), ms[i] the duration of launch i. Returns the
+ * number of launches reported. bench.py's roofline line is built from these. */
+int knz_last_kernel_times(void* handle, char* names, int names_cap, float* ms, int cap);
+
 /* Diagnostic counters of the last device batch. KNZ_COUNTER_HUF_SERIAL_CHUNKS: Huffman chunks the wave-parallel decoder
  * handed back to the serial (reference-order) decoder; 0 for any stream a kanzi encoder wrote. Returns 0 or an error code. */
-enum { KNZ_COUNTER_HUF_SERIAL_CHUNKS = 0 };
+enum { KNZ_COUNTER_HUF_SERIAL_CHUNKS = 0, KNZ_COUNTER_POST_TRANSFORM_BYTES = 1 /* entropy coder input of the last encode batch */ };
 int knz_last_counter(void* handle, int id, uint64_t* value);
 
 /* 1 when a transform/entropy id has a device implementation in this build */

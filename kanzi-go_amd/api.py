@@ -105,6 +105,7 @@ def load_library(path=None):
     L.knz_last_counter.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
     L.knz_last_counter.restype = C.c_int
     L.knz_supports.argtypes = [C.c_uint64, C.c_uint32]
+    L.knz_last_kernel_times.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.c_int]
     _LIB, _LIB_PATH = L, path
     return L
 
@@ -182,6 +183,14 @@ class Codec:
         t = (C.c_float * 4)()
         n = self.L.knz_last_timing(self.h, t, 4)
         return [t[i] for i in range(n)]
+
+    def last_kernel_times(self):
+        """[(kernel name, ms)] of the probed launches of the last device batch (HIP events on the launch stream)."""
+        names = C.create_string_buffer(8192)
+        ms = (C.c_float * 64)()
+        n = self.L.knz_last_kernel_times(self.h, names, 8192, ms, 64)
+        nm = names.value.decode().split("\n")
+        return [(nm[i], float(ms[i])) for i in range(n)]
 
 
 class BlockBatch:

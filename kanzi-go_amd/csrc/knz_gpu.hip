@@ -44,6 +44,19 @@ static void probe_end(Handle* h, hipStream_t st, int id) { if (id >= 0) hipEvent
         probe_end(h, st, pid__);                              \
     } while (0)
 
+// HIP's current device is a per-host-thread setting: every entry point binds the calling thread to the handle's device for the
+// duration of the call (a handle opened on device N may be used from any goroutine / OS thread) and restores what was there.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const Handle* h) {
+        if (h && hipGetDevice(&prev) == hipSuccess && prev != h->device) switched = hipSetDevice(h->device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 int knz_set_error(Handle* h, int code, const char* msg) {
     if (h) h->err = msg ? msg : "";
     return code;
@@ -162,6 +175,10 @@ extern "C" int knz_open(const knz_cfg* cfg, void** handle) {
     hipFree(probe);
     e = hipHostMalloc(&h->pinned, 4096);
     if (e != hipSuccess) { g_open_error = std::string("hipHostMalloc: ") + hipGetErrorString(e); delete h; return KNZ_ERR_CREATE_COMPRESSOR; }
+    // the handle's own stream: a blocking stream, i.e. ordered against the null stream (callers that prepare buffers on the
+    // default stream, PyTorch included, need no extra synchronisation) but not against the streams of other handles
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamDefault) == hipSuccess) h->own_stream = true;
+    else h->stream = nullptr;
     for (int i = 0; i <= KNZ_STAGE_COUNT; i++) hipEventCreate(&h->ev[i]);
     for (int i = 0; i < KNZ_STAGE_COUNT; i++) h->stage_ms[i] = 0.f;
     *handle = h;
@@ -171,6 +188,8 @@ extern "C" int knz_open(const knz_cfg* cfg, void** handle) {
 extern "C" int knz_close(void* handle) {
     Handle* h = (Handle*)handle;
     if (!h) return KNZ_OK;
+    DeviceGuard dg(h);                                  // (the workspace buffers are freed by ~Handle while the device is bound)
+    if (h->own_stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); h->stream = nullptr; h->own_stream = false; }
     if (h->pinned) hipHostFree(h->pinned);
     for (int i = 0; i <= KNZ_STAGE_COUNT; i++) hipEventDestroy(h->ev[i]);
     for (int i = 0; i < KNZ_MAX_PROBES; i++) if (h->probes[i].a) { hipEventDestroy(h->probes[i].a); hipEventDestroy(h->probes[i].b); }
@@ -195,6 +214,7 @@ extern "C" int knz_last_timing(void* handle, float* stage_ms, int cap) {
 extern "C" int knz_last_kernel_times(void* handle, char* names, int names_cap, float* ms, int cap) {
     Handle* h = (Handle*)handle;
     if (!h || !names || !ms || names_cap <= 0) return 0;
+    DeviceGuard dg(h);
     int n = 0, pos = 0;
     names[0] = 0;
     for (int i = 0; i < h->nprobes && n < cap; i++) {
@@ -210,8 +230,10 @@ extern "C" int knz_last_kernel_times(void* handle, char* names, int names_cap, f
 
 extern "C" int knz_last_counter(void* handle, int id, uint64_t* value) {
     Handle* h = (Handle*)handle;
-    if (!h || !value || id != KNZ_COUNTER_HUF_SERIAL_CHUNKS) return KNZ_ERR_INVALID_PARAM;
+    if (!h || !value || (id != KNZ_COUNTER_HUF_SERIAL_CHUNKS && id != KNZ_COUNTER_POST_TRANSFORM_BYTES)) return KNZ_ERR_INVALID_PARAM;
+    DeviceGuard dg(h);
     *value = 0;
+    if (id == KNZ_COUNTER_POST_TRANSFORM_BYTES) { *value = h->post_bytes; return KNZ_OK; }
     if (h->huf_fallback_n == 0) return KNZ_OK;
     std::vector<uint8_t> f(h->huf_fallback_n);
     if (hipMemcpy(f.data(), h->huf_fallback.p, f.size(), hipMemcpyDeviceToHost) != hipSuccess) return KNZ_ERR_UNKNOWN;
@@ -429,7 +451,9 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     int32_t* status = (int32_t*)((uint8_t*)h->pinned + 64);
     // block statuses: only the first 960 fit the pinned page; larger batches are checked in pieces
     std::vector<int32_t> stv(nblocks);
+    std::vector<uint32_t> lenv(nblocks);
     if (nblocks) HIP_OK(hipMemcpyAsync(stv.data(), h->blk_status.p, 4 * nblocks, hipMemcpyDeviceToHost, st));
+    if (nblocks) HIP_OK(hipMemcpyAsync(lenv.data(), h->blk_len.p, 4 * nblocks, hipMemcpyDeviceToHost, st));
     (void)status;
     HIP_OK(hipStreamSynchronize(st));
     HIP_OK(hipGetLastError());
@@ -437,6 +461,8 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     for (uint32_t b = 0; b < nblocks; b++)
         if (stv[b] != 0) return knz_set_error(h, stv[b], "block failed (the reference panics on this input: ERR_PROCESS_BLOCK)");
     eb.total_bits = res[0];
+    h->post_bytes = 0;
+    for (uint32_t b = 0; b < nblocks; b++) h->post_bytes += lenv[b];
     return KNZ_OK;
 }
 
@@ -444,6 +470,7 @@ extern "C" int knz_dev_compress(void* handle, const void* d_src, uint64_t n, int
                                 uint64_t dst_cap, uint64_t* out_bytes, void* hip_stream) {
     Handle* h = (Handle*)handle;
     if (!h || !d_dst || !out_bytes || (!d_src && n)) return KNZ_ERR_MISSING_PARAM;
+    DeviceGuard dg(h);
     if (((uintptr_t)d_dst & 3) || ((uintptr_t)d_src & 15)) return knz_set_error(h, KNZ_ERR_INVALID_PARAM, "d_src must be 16-byte and d_dst 4-byte aligned");
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
     EncodeBatch eb{(const uint8_t*)d_src, n, (uint8_t*)d_dst, dst_cap, 1, 1, 1, header_input_size, 0, 0, 0};
@@ -457,6 +484,7 @@ extern "C" int knz_dev_compress_blocks(void* handle, const void* d_src, uint64_t
                                        uint64_t* out_bits, void* hip_stream) {
     Handle* h = (Handle*)handle;
     if (!h || !d_dst || !out_bits || (!d_src && n)) return KNZ_ERR_MISSING_PARAM;
+    DeviceGuard dg(h);
     if (((uintptr_t)d_dst & 3) || ((uintptr_t)d_src & 15)) return knz_set_error(h, KNZ_ERR_INVALID_PARAM, "d_src must be 16-byte and d_dst 4-byte aligned");
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
     EncodeBatch eb{(const uint8_t*)d_src, n, (uint8_t*)d_dst, dst_cap, 1, 0, 0, 0, 0, 0, 0};

@@ -26,6 +26,7 @@ struct Handle {
     knz_cfg cfg;
     KernelProbe probes[KNZ_MAX_PROBES];
     int nprobes = 0;
+    uint64_t post_bytes = 0;          // bytes behind the transform sequence of the last encode batch (entropy coder input)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;

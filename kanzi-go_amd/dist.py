@@ -5,10 +5,21 @@ import torch
 import torch.distributed as dist
 
 
+def blocks_per_rank(nblocks, world):
+    """Static scatter: the first nblocks % world ranks own one block more (26 blocks over 8 GPUs: 4,4,3,3,3,3,3,3)."""
+    q, rem = divmod(nblocks, world)
+    return [q + (1 if r < rem else 0) for r in range(world)]
+
+
+def max_blocks_per_rank(nblocks, world):
+    return (nblocks + world - 1) // world
+
+
 def block_range(nblocks, rank, world):
     """Blocks [lo, hi) owned by `rank`: contiguous ranges so that the gather is one message per rank."""
-    per = (nblocks + world - 1) // world
-    return min(rank * per, nblocks), min((rank + 1) * per, nblocks)
+    q, rem = divmod(nblocks, world)
+    lo = rank * q + min(rank, rem)
+    return lo, lo + q + (1 if rank < rem else 0)
 
 
 class _PendingGather:
@@ -31,8 +42,20 @@ class _PendingGather:
         return nbytes, self.nbits
 
 
+class _Works:
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 def gather_segments(seg, seg_bits, group=None, async_op=False):
     """seg: uint8 tensor holding this rank's bit string (zero padded), seg_bits: its bit count.
+    Variable-size gather to rank 0: the bit counts are all-gathered (8 bytes per rank), then every rank sends
+    exactly its own bytes and rank 0 posts one receive per rank: one grouped send/recv (ncclGroupStart .. ncclSend/ncclRecv ..
+    ncclGroupEnd under backend "nccl" = RCCL), nothing is padded to the largest segment.
     Returns (work handle or None, list of per-rank tensors on rank 0 / None elsewhere, list of bit counts)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -40,11 +63,19 @@ def gather_segments(seg, seg_bits, group=None, async_op=False):
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([seg_bits], dtype=torch.int64, device=dev), group=group)
     bits = [int(s.item()) for s in sizes]
-    maxb = ((max(bits) + 7) // 8 + 8 + 15) & ~15
-    if maxb > seg.numel():
-        raise ValueError("segment buffers must be sized identically on every rank")
-    bufs = [torch.empty(maxb, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-    work = dist.gather(seg[:maxb], bufs, dst=0, group=group, async_op=async_op)
+    nbytes = [((b + 7) // 8 + 3) & ~3 for b in bits]                     # whole 32-bit words: the assembly reads words
+    if nbytes[rank] > seg.numel():
+        raise ValueError("segment buffer smaller than the segment")
+    ops, bufs = [], None
+    if rank == 0:
+        bufs = [seg[: nbytes[0]]] + [torch.empty(max(nbytes[r], 4), dtype=torch.uint8, device=dev) for r in range(1, world)]
+        ops = [dist.P2POp(dist.irecv, bufs[r][: nbytes[r]], r, group) for r in range(1, world) if nbytes[r]]
+    elif nbytes[rank]:
+        ops = [dist.P2POp(dist.isend, seg[: nbytes[rank]], 0, group)]
+    works = dist.batch_isend_irecv(ops) if ops else []
+    work = _Works(works)
+    if not async_op:
+        work.wait()
     return (work if async_op else None), bufs, bits
 
 

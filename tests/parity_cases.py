@@ -545,6 +545,20 @@ def check_utf_streams(be):
         assert be.to_host(ko, len(data)) == data
         c.close()
     assert len(O.compress(data, "UTF", "NONE", bs)) < len(data) - 30000       # the stage applied to the UTF-8 blocks
+    # more blocks than one workspace group holds (the UTF stage runs in groups of 64 blocks)
+    bs2 = 2048
+    many = utf_text(bs2 * 70 + 13, 31, (1, 1, 0))
+    for transform, entropy in (("UTF", "NONE"), ("UTF", "HUFFMAN")):
+        c = K.Codec(transform, entropy, bs2, lib=be.lib)
+        src, ks = be.to_dev(many)
+        cap = 2 * len(many) + (1 << 20)
+        dst, kd = be.empty(cap)
+        nb = c.dev_compress(src, len(many), dst, cap)
+        assert be.to_host(kd, nb) == O.compress(many, transform, entropy, bs2), (transform, entropy, "many blocks")
+        out, ko = be.empty(len(many) + 64)
+        assert c.dev_decompress(dst, nb, out, len(many) + 64) == len(many)
+        assert be.to_host(ko, len(many)) == many
+        c.close()
 
 
 def check_concurrent_handles(be, threads=8, rounds=3):

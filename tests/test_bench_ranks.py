@@ -31,7 +31,7 @@ def _run(nproc, extra):
 @pytest.mark.parametrize("nproc", [2, 3])
 def test_bench_ranks_weak_scaling(nproc):
     size, bs = 5 * 65536 + 4321, 65536
-    out = _run(nproc, ["--size", str(size), "--block-size", str(bs)])
+    out = _run(nproc, ["--config", "huffman", "--scaling", "weak", "--size", str(size), "--block-size", str(bs)])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline"):
         assert key in out, key
@@ -41,3 +41,18 @@ def test_bench_ranks_weak_scaling(nproc):
     assert out["roundtrip_ok"] is True
     assert out["bit_exact_vs_oracle"] is True
     assert "EMULATOR" in out["data"]
+
+
+@pytest.mark.timeout(1000)
+@pytest.mark.parametrize("nproc,nblk", [(2, 5), (3, 2)])
+def test_bench_ranks_strong_scaling_default_config(nproc, nblk):
+    """The default N>1 mode: ONE fixed job of BASELINE configs[3]'s pipeline (BWT+RANK+ZRLT / ANS1) split over the ranks by
+    contiguous block ranges; (3 ranks, 2 blocks) leaves a rank without any block."""
+    bs = 16384
+    size = (nblk - 1) * bs + 4321
+    out = _run(nproc, ["--size", str(size), "--block-size", str(bs)])
+    assert out["scaling"] == "strong" and out["n_gpus"] == nproc
+    assert "configs[3]" in out["config"]["workload"] and "BWT+RANK+ZRLT" in out["config"]["workload"]
+    assert out["config"]["blocks"] == nblk
+    assert out["roundtrip_ok"] is True and out["bit_exact_vs_oracle"] is True
+    assert out["roofline"]["kernel"] is not None and out["roofline"]["avg_launch_ms"] >= 0

@@ -19,13 +19,14 @@ from kanzi_go_amd import dist as kd
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=int(sys.argv[4]))
 rank, world = dist.get_rank(), dist.get_world_size()
 entropy, bs, n = sys.argv[5], int(sys.argv[6]), int(sys.argv[7])
+transform = sys.argv[8]
 data = P.corpus(n, 5)
 nblocks = (n + bs - 1) // bs
 lo_b, hi_b = kd.block_range(nblocks, rank, world)
 lo, hi = lo_b * bs, min(hi_b * bs, n)
 part = data[lo:hi]
-codec = K.Codec("NONE", entropy, bs, lib=knz.emu_library())
-per = (nblocks + world - 1) // world
+codec = K.Codec(transform, entropy, bs, lib=knz.emu_library())
+per = kd.max_blocks_per_rank(nblocks, world)
 cap = 2 * per * bs + (1 << 18)
 raw = torch.zeros(len(part) + 64, dtype=torch.uint8)
 off = (-raw.data_ptr()) % 16
@@ -39,7 +40,7 @@ out = out[(-out.data_ptr()) % 16:]
 nbytes, nbits = kd.sharded_compress(codec, src, len(part), seg, n, out)
 if rank == 0:
     got = out[:nbytes].numpy().tobytes()
-    assert got == O.compress(data, "NONE", entropy, bs), "assembled stream differs from the oracle"
+    assert got == O.compress(data, transform, entropy, bs), "assembled stream differs from the oracle"
 back = torch.zeros(len(part) + 64, dtype=torch.uint8)
 if part:
     assert codec.dev_decompress_blocks(seg.data_ptr(), nbits, back.data_ptr(), back.numel()) == len(part)
@@ -50,15 +51,18 @@ print("rank", rank, "ok")
 '''
 
 
-@pytest.mark.parametrize("cfg", [("HUFFMAN", 1 << 16, 5 * (1 << 16) + 777, 2), ("ANS0", 1 << 16, 2 * (1 << 16) + 5, 2), ("HUFFMAN", 1 << 16, 1000, 2)])
+@pytest.mark.parametrize("cfg", [("HUFFMAN", 1 << 16, 5 * (1 << 16) + 777, 2, "NONE"), ("ANS0", 1 << 16, 2 * (1 << 16) + 5, 2, "NONE"),
+                                 ("HUFFMAN", 1 << 16, 1000, 2, "NONE"),
+                                 ("ANS1", 1 << 14, 4 * (1 << 14) + 4321, 2, "BWT+RANK+ZRLT"),      # configs[3] pipeline, uneven last rank (3 + 2 blocks, ragged tail)
+                                 ("ANS1", 1 << 14, 2 * (1 << 14) + 99, 3, "BWT+RANK+ZRLT")])       # 3 blocks over 3 ranks, the last one 99 bytes
 def test_two_ranks_gloo(cfg, tmp_path):
-    entropy, bs, n, world = cfg
+    entropy, bs, n, world, transform = cfg
     import knz
     knz.emu_library()                                    # build once, before the ranks race for it
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = str(29500 + (os.getpid() % 2000))
-    procs = [subprocess.Popen([sys.executable, str(script), HERE, port, str(r), str(world), entropy, str(bs), str(n)],
+    procs = [subprocess.Popen([sys.executable, str(script), HERE, port, str(r), str(world), entropy, str(bs), str(n), transform],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
