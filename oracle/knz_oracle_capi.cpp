@@ -229,4 +229,16 @@ int knzo_suffix_array(const uint8_t* src, uint64_t n, int32_t* sa_out) {
     KNZO_CATCH
 }
 
+// DivSufSort.go restated (oracle/divsufsort.hpp): suffix array and the BWT algorithm switch (1 = DivSufSort, 0 = SA-IS)
+int knzo_suffix_array_divsufsort(const uint8_t* src, uint64_t n, int32_t* sa_out) {
+    KNZO_TRY
+    if (n < 2) { if (n) sa_out[0] = 0; return 0; }
+    DivSufSort d;
+    d.computeSuffixArray(src, sa_out, (int32_t)n);
+    return 0;
+    KNZO_CATCH
+}
+int knzo_set_bwt_algo(int algo) { bwtAlgo().store(algo ? 1 : 0); return 0; }
+int knzo_get_bwt_algo() { return bwtAlgo().load(); }
+
 } // extern "C"

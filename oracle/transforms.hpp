@@ -16,7 +16,9 @@
 //   v2/transform/SRT.go:49-132 Forward ; :134-167 preprocess ; :172-259 Inverse ; :261-275 encodeHeader ; :277-312 decodeHeader
 #pragma once
 #include "entropy_utils.hpp"
+#include "divsufsort.hpp"
 #include <algorithm>
+#include <atomic>
 
 namespace knzo {
 
@@ -101,6 +103,10 @@ static inline void suffixArray(const uint8_t* src, int32_t n, std::vector<int32_
 // BWT.go:631-637
 static inline int getBWTChunks(int size) { return size < 256 ? 1 : 8; }
 
+// which suffix sort BWT.forward uses: 1 = the restated DivSufSort (the reference's own algorithm, DivSufSort.go: what the CPU
+// baseline times), 0 = SA-IS (independent cross-check; tests compare the two)
+inline std::atomic<int>& bwtAlgo() { static std::atomic<int> a{1}; return a; }
+
 struct BWT {
     uint64_t primaryIndexes[8] = {0};
 
@@ -108,6 +114,14 @@ struct BWT {
     void forward(const uint8_t* src, uint8_t* dst, int count) {
         if (count == 0) return;
         if (count == 1) { dst[0] = src[0]; return; }
+        if (bwtAlgo().load() == 1) {                                  // BWT.go:170: this.saAlgo.ComputeBWT(src, dst, buffer, primaryIndexes, GetBWTChunks(count))
+            std::vector<int32_t> work((size_t)count + 1);
+            uint32_t idx[8] = {0};
+            DivSufSort d;
+            d.computeBWT(src, dst, work.data(), count, idx, getBWTChunks(count));
+            for (int i = 0; i < 8; i++) primaryIndexes[i] = idx[i];
+            return;
+        }
         std::vector<int32_t> sa;
         suffixArray(src, count, sa);
         int chunks = getBWTChunks(count);

@@ -87,6 +87,8 @@ def lib():
         L.knzo_bwt_forward.argtypes = [u8p, C.c_uint64, u8p, C.POINTER(C.c_uint64)]
         L.knzo_bwt_inverse.argtypes = [u8p, C.c_uint64, u8p, C.POINTER(C.c_uint64)]
         L.knzo_suffix_array.argtypes = [u8p, C.c_uint64, C.POINTER(C.c_int32)]
+        L.knzo_suffix_array_divsufsort.argtypes = [u8p, C.c_uint64, C.POINTER(C.c_int32)]
+        L.knzo_set_bwt_algo.argtypes = [C.c_int]
         _LIB = L
     return _LIB
 
@@ -229,6 +231,23 @@ def suffix_array(data):
     sa = np.zeros(max(len(a), 1), dtype=np.int32)
     _chk(lib().knzo_suffix_array(p, len(a), sa.ctypes.data_as(C.POINTER(C.c_int32))))
     return sa[: len(a)]
+
+
+def suffix_array_divsufsort(data):
+    """oracle/divsufsort.hpp (DivSufSort.go restated)"""
+    a, p = _u8(data)
+    sa = np.zeros(max(len(a), 1), dtype=np.int32)
+    _chk(lib().knzo_suffix_array_divsufsort(p, len(a), sa.ctypes.data_as(C.POINTER(C.c_int32))))
+    return sa[: len(a)]
+
+
+def set_bwt_algo(algo):
+    """1 = DivSufSort restatement (default: the reference's algorithm), 0 = SA-IS (independent cross-check)"""
+    lib().knzo_set_bwt_algo(int(algo))
+
+
+def bwt_kind():
+    return "DivSufSort.go restated (oracle/divsufsort.hpp)" if lib().knzo_get_bwt_algo() == 1 else "SA-IS (not the reference's divsufsort)"
 
 
 def huffman_codes(freqs):

@@ -406,6 +406,37 @@ def test_suffix_array_against_naive():
         assert sa == sorted(range(n), key=lambda i: c[i:])
 
 
+def test_divsufsort_restatement_against_sais_and_naive():
+    """oracle/divsufsort.hpp (DivSufSort.go restated: the oracle's default forward BWT and what the CPU baseline times) against the
+    independent SA-IS path and the naive definition: suffix arrays equal, BWT bytes and all 8 primary indexes equal; inputs that
+    drive sortTypeBstar / ssSort / trSort down their different paths (long repeats, periodic text, two symbols, Fibonacci word,
+    blocks larger than SS_BLOCKSIZE^2-ish merges, tiny inputs)."""
+    rng = np.random.default_rng(5)
+    fib = [b"a", b"ab"]
+    while len(fib[-1]) < 150000:
+        fib.append(fib[-1] + fib[-2])
+    cases = [b"mississippi", b"aa", b"ab", b"ba", bytes(1000), bytes(i & 255 for i in range(70000)), _corpus(300000),
+             rng.integers(0, 256, 200000, dtype=np.uint8).tobytes(), (rng.integers(0, 2, 100000) * 7).astype(np.uint8).tobytes(),
+             b"abcabcabd" * 20000, bytes(np.repeat(rng.integers(0, 4, 3000, dtype=np.uint8), rng.integers(1, 200, 3000))), fib[-1],
+             _corpus(1200000, 9)[::-1]]
+    cases += [rng.integers(0, 3, n, dtype=np.uint8).tobytes() for n in (2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 255, 256, 257, 1000)]
+    try:
+        for c in cases:
+            sa = O.suffix_array_divsufsort(c)
+            assert (sa == O.suffix_array(c)).all()
+            if len(c) <= 300:
+                assert sa.tolist() == sorted(range(len(c)), key=lambda i: c[i:])
+            O.set_bwt_algo(0)
+            b0 = O.bwt_forward(c)
+            O.set_bwt_algo(1)
+            b1 = O.bwt_forward(c)
+            assert b0 == b1
+            assert O.bwt_inverse(b1[0], b1[1]) == c
+    finally:
+        O.set_bwt_algo(1)
+    assert "DivSufSort" in O.bwt_kind()
+
+
 def _corpus(n, seed=3):
     rng = np.random.default_rng(seed)
     words = [bytes(rng.integers(97, 123, int(rng.integers(2, 9)), dtype=np.uint8)) for _ in range(500)]

@@ -77,6 +77,51 @@ def test_full_size_config2_properties(be):
     c.close()
 
 
+def _full_size_stream(be, transform, entropy, bs, data):
+    """device stream == oracle stream (sha256 of both + length) and device round trip, at a BASELINE configuration's full size"""
+    import hashlib
+    import oracle_lib as O
+    import torch
+    n = len(data)
+    c = P.K.Codec(transform, entropy, bs, lib=be.lib)
+    d_src = torch.from_numpy(np.ascontiguousarray(data)).to(be.dev)
+    cap = n + n // 2 + (1 << 20)
+    d_dst = torch.zeros(cap, dtype=torch.uint8, device=be.dev)
+    nb = c.dev_compress(d_src.data_ptr(), n, d_dst.data_ptr(), cap)
+    d_back = torch.zeros(n + 4096, dtype=torch.uint8, device=be.dev)
+    assert c.dev_decompress(d_dst.data_ptr(), nb, d_back.data_ptr(), n + 4096) == n
+    assert torch.equal(d_back[:n], d_src)
+    got = d_dst[:nb].cpu().numpy().tobytes()
+    exp = O.compress(data, transform, entropy, bs, 0, jobs=os.cpu_count() or 1)
+    assert len(got) == len(exp)
+    assert hashlib.sha256(got).digest() == hashlib.sha256(exp).digest()
+    c.close()
+
+
+@pytest.mark.timeout(900)
+def test_full_size_config3_lz_ans0(be):
+    """BASELINE.json configs[2] at full size: -t LZ -e ANS0 -b 4m on S-silesia (51 blocks of 4 MiB, 24-bit LZ window)."""
+    import bench_corpus
+    _full_size_stream(be, "LZ", "ANS0", 4 << 20, bench_corpus.s_silesia())
+
+
+@pytest.mark.timeout(900)
+def test_full_size_config4_bwt_ans1(be):
+    """BASELINE.json configs[3] at full size (the configuration the north-star target is quoted on): -t BWT+RANK+ZRLT -e ANS1 -b 8m
+    on S-silesia, 26 blocks, two 4 MiB rANS order-1 chunks per block."""
+    import bench_corpus
+    _full_size_stream(be, "BWT+RANK+ZRLT", "ANS1", 8 << 20, bench_corpus.s_silesia())
+
+
+@pytest.mark.timeout(1500)
+def test_config5_block_size_32m_fpaq(be):
+    """BASELINE.json configs[4]'s block size: one 32 MiB block and a ragged second one of S-enwik through BWT+RANK+ZRLT / FPAQ
+    (32 MiB suffix sort and the reference inverse's biPSIv2-sized block, BWT.go:31; 8 FPAQ sub-chunks per block with the
+    coder state carried across them, FPAQCodec.go:162-168; inverse RANK in its three-register form: times need 25 bits)."""
+    import bench_corpus
+    _full_size_stream(be, "BWT+RANK+ZRLT", "FPAQ", 32 << 20, bench_corpus.s_enwik((32 << 20) + 3333333))
+
+
 def test_stress_inputs(be):
     import bench_corpus
     for gen in (bench_corpus.s_rand, bench_corpus.s_ramp):
