@@ -332,6 +332,71 @@ def check_rank_chain_variants(be, monkeypatch, max_len=1 << 30, bwt_len=150000):
     c.close()
 
 
+def reference_test_inputs():
+    """tests/golden/reference_inputs.json: the deterministic input literals of the reference's own tests, extracted from the
+    reference source by tests/golden/make_reference_inputs.py (not re-typed)."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_inputs.json")))
+    return ([(e["name"], bytes.fromhex(e["hex"])) for e in g["entropy"]], [(e["name"], bytes.fromhex(e["hex"])) for e in g["transform"]])
+
+
+def check_reference_inputs(be):
+    """Every input literal of the reference's own tests (Entropy_test.go:617-693, Transforms_test.go:165-258,534-601,
+    BWT_test.go:60-84) through both directions of the boundary, crossed with the oracle: device-encode -> oracle-decode and
+    oracle-encode -> device-decode, as codec objects and as whole streams. (The reference's tests hold no output bytes: this pins
+    the inputs it exercises, not the bytes a Go build would write.)"""
+    ent, trf = reference_test_inputs()
+    c = K.Codec("NONE", "NONE", 1 << 16, lib=be.lib)
+    for ename in ("HUFFMAN", "ANS0", "ANS1", "FPAQ", "NONE"):
+        et = O.entropy_type(ename)
+        enc, dec = K.EntropyEncoder(c, ename), K.EntropyDecoder(c, ename)
+        for name, data in ent + trf:
+            if len(data) == 0 or len(data) > 5000:
+                continue
+            if ename == "ANS1" and len(data) in (2, 3):
+                continue                                   # the reference panics on an order-1 chunk of 2-3 bytes (ANSRangeCodec.go:353-362): mirrored, tested elsewhere
+            gb, gbits = enc.write(data)
+            ob, obits = O.entropy_encode(et, data)
+            assert (gb, gbits) == (ob, obits), (ename, name)
+            assert O.entropy_decode(et, gb, len(data))[0] == data, (ename, name, "device-encode -> oracle-decode")
+            assert dec.read(ob, len(data))[0] == data, (ename, name, "oracle-encode -> device-decode")
+    for tname in ("BWT", "RANK", "MTFT", "ZRLT", "LZ", "LZX", "LZP", "SRT"):
+        t = K.ByteTransform(c, tname)
+        tid = _TID[tname]
+        for name, data in trf + ent:
+            if len(data) == 0 or len(data) > (1 << 16):
+                continue
+            g = t.forward(data)
+            o = O.transform_forward(tid, data)
+            assert (g is None) == (o is None), (tname, name)
+            if o is None:
+                continue
+            assert g == o, (tname, name)
+            assert O.transform_inverse(tid, g, len(data) + 1024) == data, (tname, name, "device-forward -> oracle-inverse")
+            assert t.inverse(o, len(data) + max(512, len(data) >> 4)) == data, (tname, name, "oracle-forward -> device-inverse")
+    c.close()
+    # whole streams, both ways (block size 64 KiB: the 80 000-byte input spans two blocks)
+    for transform, entropy in (("NONE", "HUFFMAN"), ("BWT+RANK+ZRLT", "ANS1"), ("LZ", "ANS0"), ("BWT+RANK+ZRLT", "FPAQ")):
+        cs = K.Codec(transform, entropy, 1 << 16, lib=be.lib)
+        for name, data in trf + ent:
+            if len(data) == 0:
+                continue
+            src, ks = be.to_dev(data)
+            cap = 2 * len(data) + (1 << 18)
+            dst, kd = be.empty(cap)
+            nb = cs.dev_compress(src, len(data), dst, cap)
+            got = be.to_host(kd, nb)
+            exp = O.compress(data, transform, entropy, 1 << 16)
+            assert got == exp, (transform, entropy, name)
+            assert O.decompress(got, len(data) + 64) == data, (transform, entropy, name, "device stream -> oracle reader")
+            s2, k2 = be.to_dev(exp)
+            out, ko = be.empty(len(data) + 64)
+            assert cs.dev_decompress(s2, len(exp), out, len(data) + 64) == len(data)
+            assert be.to_host(ko, len(data)) == data, (transform, entropy, name, "oracle stream -> device reader")
+        cs.close()
+
+
 def _huffman_header_with_wrapped_delta(payload, nbits):
     """Re-encodes one negative code-length delta (-2..-11) of a Huffman chunk header with the 16-bit Exp-Golomb form whose
     magnitude wraps as int8 (ExpGolombCodec.go:159-190, readLengths casts to int8): a stream no kanzi encoder writes but

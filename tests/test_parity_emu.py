@@ -89,6 +89,10 @@ def test_mtft_segments(be):
     P.check_mtft_segments(be)
 
 
+def test_reference_test_inputs_both_directions(be):
+    P.check_reference_inputs(be)
+
+
 def test_rank_chain_variants(be, monkeypatch):
     P.check_rank_chain_variants(be, monkeypatch, max_len=4100, bwt_len=12000)
 

@@ -222,6 +222,24 @@ def test_mtft_segments(be):
     P.check_mtft_segments(be)
 
 
+def test_c_smoke_program(be, tmp_path):
+    """tests/csmoke/smoke.c: a plain C99 program compiled with gcc against include/knz_gpu.h and linked with the in-tree
+    libknz_gpu.so: what the cgo shim (go/gpu_batch.go) does, without Go: encode 3 host blocks, decode, flipped-bit error."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "kanzi-go_amd")
+    exe = str(tmp_path / "smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "csmoke", "smoke.c"),
+                           "-L", libdir, "-lknz_gpu", "-Wl,-rpath," + libdir, "-o", exe])
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "c smoke ok" in p.stdout
+
+
+def test_reference_test_inputs_both_directions(be):
+    P.check_reference_inputs(be)
+
+
 def test_rank_chain_variants(be, monkeypatch):
     P.check_rank_chain_variants(be, monkeypatch)
 
