@@ -214,6 +214,8 @@ __global__ __launch_bounds__(256) void knz_bwt_inv_keys_kernel(BwtInvArgs a, uin
     vals[i] = i;
 }
 
+#define KNZ_BWT_SPLIT 128u
+
 // LF links (BWT.go:228-247): slot p of the stably sorted order holds symbol v from payload index i; the link is
 // i-1 for 1 <= i < pIdx, i for i >= pIdx (the entry of i = 0 ends the text and is never followed).
 __global__ __launch_bounds__(256) void knz_bwt_inv_links_kernel(BwtInvArgs a, uint32_t total, const uint32_t* skeys, const uint32_t* svals, uint2* links) {
@@ -226,6 +228,14 @@ __global__ __launch_bounds__(256) void knz_bwt_inv_links_kernel(BwtInvArgs a, ui
     uint2 e;
     e.x = i == 0 ? 0xFFFFFFFFu : (i < pIdx ? i - 1 : i);
     e.y = skeys[p] & 0xFF;
+    // bit 31: the slot this link leads to is a splitter of the list ranking below (a multiple of KNZ_BWT_SPLIT or the start of
+    // one of the block's chunk chains): a walker learns it has arrived without another memory access
+    if (e.x != 0xFFFFFFFFu) {
+        bool sp = (e.x % KNZ_BWT_SPLIT) == 0;
+        const uint32_t* h = a.hdr + (size_t)b * 12;
+        for (uint32_t c = 0; c < h[1]; c++) sp = sp || (h[2 + c] - 1 == e.x);
+        if (sp) e.y |= 0x80000000u;
+    }
     links[p] = e;
 }
 
@@ -241,22 +251,24 @@ __global__ __launch_bounds__(256) void knz_bwt_inv_double_kernel(BwtInvArgs a, u
     const uint32_t cnt = a.in_len[b] - a.hdr[(size_t)b * 12];
     const uint2 e0 = in[p];
     uint2 o;
-    o.x = 0xFFFFFFFFu; o.y = e0.y;
+    const uint32_t ymask = symBits == 8 ? 0xFFu : 0xFFFFFFFFu;    // (the single links carry the splitter flag in bit 31)
+    o.x = 0xFFFFFFFFu; o.y = e0.y & ymask;
     if (e0.x < cnt) {
         const uint2 e1 = in[gs0 + e0.x];
         o.x = e1.x < cnt ? e1.x : 0xFFFFFFFFu;
-        o.y = e0.y | (e1.y << symBits);
+        o.y = (e0.y & ymask) | ((e1.y & ymask) << symBits);
     }
     out[p] = o;
 }
 
 // one wave per block, lanes 0..7 follow the 8 chunk chains (one lane when n < 256): 4 symbols per hop through links4,
 // the last < 4 symbols of a chain through the single links
-__global__ __launch_bounds__(64) void knz_bwt_inv_chains_kernel(BwtInvArgs a, const uint2* links, const uint2* links4) {
+__global__ __launch_bounds__(64) void knz_bwt_inv_chains_kernel(BwtInvArgs a, const uint2* links, const uint2* links4, const uint8_t* use_chain) {
     const uint32_t b = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t* h = a.hdr + (size_t)b * 12;
     if (!a.active[b] || h[10] == 0) return;
+    if (use_chain && !use_chain[b]) return;                          // the block went through the list ranking
     const uint32_t cnt = a.in_len[b] - h[0];
     uint8_t* dst = (uint8_t*)a.out_ptr[b];
     const uint8_t* src = (const uint8_t*)a.in_ptr[b] + h[0];
@@ -287,6 +299,150 @@ __global__ __launch_bounds__(64) void knz_bwt_inv_chains_kernel(BwtInvArgs a, co
         if (t >= cnt) { a.ok[b] = -KNZ_ERR_PROCESS_BLOCK; return; }
         const uint2 e = L[t];
         dst[i] = (uint8_t)e.y;
+        t = e.x;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Inverse BWT without the block-long pointer chase: LIST RANKING with splitters (Helman-JaJa). The LF links make one linked
+// list of n slots per block; the 8 chunk chains the format allows are still 1 M dependent HBM accesses each at 8 MiB (~430 ns per
+// hop, profiles/r02_lone_wave_latencies.md: 160 ms whatever the GPU does meanwhile). Instead:
+//   1. every KNZ_BWT_SPLIT-th slot (and every chunk start) is a splitter; one THREAD per splitter walks the list to the next
+//      splitter and records (successor, length): ~128 hops each, n / 128 independent walks per block: throughput, not latency;
+//   2. one workgroup per block ranks its splitter list by pointer jumping (Wyllie, log2(n/128) rounds over 64 K entries in L2):
+//      distance of every splitter to the end of the text, hence its text position;
+//   3. one thread per splitter walks its sub-list again, four symbols per hop through the doubled links, and stores the symbols
+//      at the text positions now known.
+// A block whose list is not one path from the first primary index to the terminator through all n slots with the chunk starts
+// at their positions (damaged stream), or with a sub-list longer than the cap, is handed to the chains kernel, which keeps the
+// reference's behaviour on such input. Blocks below KNZ_BWT_RANK_MIN go there directly.
+#define KNZ_BWT_SP_END 0xFFFFFFFFu
+#define KNZ_BWT_SP_UNUSED 0xFFFFFFFEu
+#define KNZ_BWT_WALK_CAP (1u << 22)
+
+struct BwtRankArgs {
+    BwtInvArgs a;
+    const uint2* links; const uint2* links4;
+    const uint32_t* sp_base;       // [nblocks + 1] first splitter id of each block (0 splitters: block takes the chains kernel)
+    uint32_t* sp_succ; uint32_t* sp_len;      // [total splitters]
+    uint32_t* sp_succ2; uint32_t* sp_dist; uint32_t* sp_dist2;
+    uint32_t* sp_pos;              // text position of the splitter's first symbol
+    uint8_t* use_chain;            // [nblocks] 1 = the chains kernel decodes this block
+};
+
+__device__ __forceinline__ uint32_t knz_bwt_sp_id(const uint32_t* h, uint32_t nreg, uint32_t slot) {
+    if (slot % KNZ_BWT_SPLIT == 0) return slot / KNZ_BWT_SPLIT;
+    for (uint32_t c = 0; c < h[1]; c++) if (h[2 + c] - 1 == slot) return nreg + c;
+    return KNZ_BWT_SP_UNUSED;
+}
+
+__global__ __launch_bounds__(256) void knz_bwt_inv_walk_kernel(BwtRankArgs r, uint32_t total_sp) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= total_sp) return;
+    const uint32_t b = knz_bwt_block_of(r.sp_base, r.a.nblocks, k);
+    const uint32_t j = k - r.sp_base[b];
+    const uint32_t* h = r.a.hdr + (size_t)b * 12;
+    const uint32_t cnt = r.a.in_len[b] - h[0];
+    const uint32_t nreg = (cnt + KNZ_BWT_SPLIT - 1) / KNZ_BWT_SPLIT;
+    uint32_t slot;
+    if (j < nreg) slot = j * KNZ_BWT_SPLIT;
+    else {
+        const uint32_t c = j - nreg;
+        slot = c < h[1] ? h[2 + c] - 1 : 0xFFFFFFFFu;
+        if (slot >= cnt || slot % KNZ_BWT_SPLIT == 0) { r.sp_succ[k] = KNZ_BWT_SP_UNUSED; r.sp_len[k] = 0; return; }   // (a chunk start that is a regular splitter already)
+    }
+    const uint2* L = r.links + r.a.gstart[b];
+    uint32_t t = slot, len = 0, succ = KNZ_BWT_SP_END;
+    for (;;) {
+        const uint2 e = L[t];
+        len++;
+        if (e.x >= cnt) break;                                       // the terminator's link (or a damaged one): end of this sub-list
+        if (e.y & 0x80000000u) { succ = knz_bwt_sp_id(h, nreg, e.x); break; }
+        t = e.x;
+        if (len >= KNZ_BWT_WALK_CAP) { succ = KNZ_BWT_SP_UNUSED; break; }   // no splitter in reach: the rank kernel rejects the block
+    }
+    r.sp_succ[k] = succ;
+    r.sp_len[k] = len;
+}
+
+__global__ __launch_bounds__(1024) void knz_bwt_inv_rank_kernel(BwtRankArgs r) {
+    __shared__ int s_bad;
+    const uint32_t b = blockIdx.x;
+    const uint32_t base = r.sp_base[b], n = r.sp_base[b + 1] - base;
+    if (n == 0) return;
+    const uint32_t* h = r.a.hdr + (size_t)b * 12;
+    if (!r.a.active[b] || h[10] == 0) return;
+    const uint32_t cnt = r.a.in_len[b] - h[0];
+    const uint32_t nreg = (cnt + KNZ_BWT_SPLIT - 1) / KNZ_BWT_SPLIT;
+    const uint32_t tid = threadIdx.x;
+    uint32_t* sa = r.sp_succ + base; uint32_t* sb = r.sp_succ2 + base;
+    uint32_t* da = r.sp_dist + base; uint32_t* db = r.sp_dist2 + base;
+    if (tid == 0) s_bad = 0;
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const uint32_t s = sa[i];
+        da[i] = r.sp_len[base + i];
+        if (s == KNZ_BWT_SP_UNUSED && r.sp_len[base + i] != 0) s_bad = 1;        // a walk that found no splitter / an unknown successor
+    }
+    __syncthreads();
+    uint32_t rounds = 1;
+    while ((1u << rounds) < n) rounds++;
+    for (uint32_t it = 0; it <= rounds; it++) {
+        for (uint32_t i = tid; i < n; i += 1024) {
+            const uint32_t s = sa[i];
+            if (s < n) { sb[i] = sa[s]; db[i] = da[i] + da[s]; }
+            else { sb[i] = s; db[i] = da[i]; }
+        }
+        __syncthreads();
+        uint32_t* t0 = sa; sa = sb; sb = t0;
+        uint32_t* t1 = da; da = db; db = t1;
+    }
+    // every used splitter must have reached the end of the text (cycles never do), the list must hold all cnt slots and every
+    // chunk must start where the format says
+    for (uint32_t i = tid; i < n; i += 1024)
+        if (r.sp_len[base + i] != 0 && sa[i] != KNZ_BWT_SP_END) s_bad = 1;
+    __syncthreads();
+    const uint32_t start = knz_bwt_sp_id(h, nreg, h[2] - 1);
+    if (start >= n) { if (tid == 0) r.use_chain[b] = 1; return; }
+    const uint32_t total = da[start];
+    if (tid == 0) {
+        if (total != cnt) s_bad = 1;
+        uint32_t ck = h[1] == 8 ? (cnt >> 3) : cnt;
+        if (h[1] == 8 && ck * 8 != cnt) ck++;
+        for (uint32_t c = 0; c < h[1]; c++) {
+            const uint32_t id = knz_bwt_sp_id(h, nreg, h[2 + c] - 1);
+            if (id >= n || total - da[id] != c * ck) s_bad = 1;
+        }
+    }
+    __syncthreads();
+    if (s_bad) { if (tid == 0) r.use_chain[b] = 1; return; }
+    for (uint32_t i = tid; i < n; i += 1024) r.sp_pos[base + i] = total - da[i];
+}
+
+__global__ __launch_bounds__(256) void knz_bwt_inv_emit_kernel(BwtRankArgs r, uint32_t total_sp) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= total_sp) return;
+    const uint32_t b = knz_bwt_block_of(r.sp_base, r.a.nblocks, k);
+    if (r.use_chain[b]) return;
+    const uint32_t j = k - r.sp_base[b];
+    uint32_t len = r.sp_len[k];
+    if (len == 0) return;
+    const uint32_t* h = r.a.hdr + (size_t)b * 12;
+    if (!r.a.active[b] || h[10] == 0) return;
+    const uint32_t cnt = r.a.in_len[b] - h[0];
+    const uint32_t nreg = (cnt + KNZ_BWT_SPLIT - 1) / KNZ_BWT_SPLIT;
+    uint32_t t = j < nreg ? j * KNZ_BWT_SPLIT : h[2 + (j - nreg)] - 1;
+    const uint2* L = r.links + r.a.gstart[b];
+    const uint2* L4 = r.links4 + r.a.gstart[b];
+    uint8_t* dst = (uint8_t*)r.a.out_ptr[b] + r.sp_pos[k];
+    for (; len >= 4; len -= 4, dst += 4) {                            // (validated: all len slots of the sub-list are inside the block)
+        const uint2 e = L4[t];
+        dst[0] = (uint8_t)e.y; dst[1] = (uint8_t)(e.y >> 8); dst[2] = (uint8_t)(e.y >> 16); dst[3] = (uint8_t)(e.y >> 24);
+        t = e.x;
+    }
+    for (; len > 0; len--, dst++) {
+        const uint2 e = L[t];
+        dst[0] = (uint8_t)e.y;
         t = e.x;
     }
 }

@@ -46,7 +46,7 @@ struct Handle {
     DevBuf xf_r1, xf_r2, xf_outptr, xf_outlen, xf_ok, xf_side, xf_active, xf_take, xf_sega, xf_segb, xf_gstart, xf_misc;
     DevBuf lz_hash, lz_tk, lz_mb, lz_ml;
     DevBuf a1_freqs, a1_tab, a1_ctxhdr, a1_ctxbits, a1_dtab, a1_info, a1_paybit, a1_f16, a1_ent, a1_cum;
-    DevBuf sa_keys0, sa_keys1, sa_vals0, sa_vals1, sa_rank, sa_gs, sa_head, sa_unres, sa_pos, sa_tmp, sa_links;
+    DevBuf sa_keys0, sa_keys1, sa_vals0, sa_vals1, sa_rank, sa_gs, sa_head, sa_unres, sa_pos, sa_tmp, sa_links, sa_sp;
     void* pinned = nullptr;           // small pinned host area for results
     hipEvent_t ev[KNZ_STAGE_COUNT + 1];
     bool ev_valid = false;

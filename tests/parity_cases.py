@@ -332,6 +332,25 @@ def check_rank_chain_variants(be, monkeypatch, max_len=1 << 30, bwt_len=150000):
     c.close()
 
 
+def check_bwt_list_ranking(be, monkeypatch, max_len=70000):
+    """Inverse BWT by list ranking (bwt.hip: splitter walks, Wyllie ranking, emit) forced onto small blocks (by default blocks
+    below 64 KiB take the 8-chain kernel): streams with ragged last blocks, the BWT_test.go inputs, and damaged streams, which the
+    ranking must hand back to the chains kernel (error-or-bytes agreement with the oracle is checked by check_corrupt_streams)."""
+    monkeypatch.setenv("KNZ_BWT_RANK_MIN", "256")
+    for cfg in (("BWT", "NONE", 1 << 14, 5 * (1 << 14) + 777), ("BWT+RANK+ZRLT", "ANS1", 1 << 15, 100003), ("BWT", "HUFFMAN", 1024, 5000),
+                ("BWT+MTFT+ZRLT", "ANS0", 4096, 4096 * 3 + 257)):
+        check_stream(be, *cfg)
+    c = K.Codec("NONE", "NONE", 1 << 20, lib=be.lib)
+    t = K.ByteTransform(c, "BWT")
+    for name, data in transform_inputs(max_len=max_len):
+        if len(data) < 2:
+            continue
+        f = O.transform_forward(_TID["BWT"], data)
+        assert t.inverse(f, len(data) + 512) == data, name
+    c.close()
+    monkeypatch.delenv("KNZ_BWT_RANK_MIN", raising=False)
+
+
 def reference_test_inputs():
     """tests/golden/reference_inputs.json: the deterministic input literals of the reference's own tests, extracted from the
     reference source by tests/golden/make_reference_inputs.py (not re-typed)."""

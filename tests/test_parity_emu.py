@@ -93,6 +93,12 @@ def test_reference_test_inputs_both_directions(be):
     P.check_reference_inputs(be)
 
 
+def test_bwt_inverse_list_ranking(be, monkeypatch):
+    P.check_bwt_list_ranking(be, monkeypatch, max_len=2100)
+    monkeypatch.setenv("KNZ_BWT_RANK_MIN", "256")
+    P.check_corrupt_streams(be, trials=2)
+
+
 def test_rank_chain_variants(be, monkeypatch):
     P.check_rank_chain_variants(be, monkeypatch, max_len=4100, bwt_len=12000)
 

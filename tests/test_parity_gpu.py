@@ -240,6 +240,12 @@ def test_reference_test_inputs_both_directions(be):
     P.check_reference_inputs(be)
 
 
+def test_bwt_inverse_list_ranking(be, monkeypatch):
+    P.check_bwt_list_ranking(be, monkeypatch)
+    monkeypatch.setenv("KNZ_BWT_RANK_MIN", "256")
+    P.check_corrupt_streams(be)
+
+
 def test_rank_chain_variants(be, monkeypatch):
     P.check_rank_chain_variants(be, monkeypatch)
 
