@@ -2,14 +2,25 @@
 // Replaces LZXCodec.Forward / findMatchLZX / emitLengthLZ / hash and LZXCodec.inverseV6
 // (v2/transform/LZCodec.go:249-591, 593-607, 193-214, 238-246, 621-778).
 //
-// The output of the forward transform is defined by the reference's SEQUENTIAL greedy parse (one-entry hash table that
-// every visited position overwrites, two repeat distances, +1 (+2) lazy probe, backward extension, skip acceleration),
-// so a block is one dependent chain: the kernel runs one wave per block, every lane executes the same (wave-uniform)
-// parse so that the wave can help where the work is wide: literal copies, hashing of the positions inside a match
-// (positions only grow, so "last writer wins" is an atomicMax) and, in the inverse, every match/literal copy
-// (overlapping matches are periodic: byte i comes from ref + i % dist). Parallelism across blocks only; the hash table
-// (256 KiB / 2 MiB per block) lives in HBM/L2. This is the slowest stage of the path on a GPU by construction and is
-// measured as such.
+// The bytes the forward transform writes are defined by a greedy parse whose every decision feeds the next one (a one-entry hash
+// table that every visited position overwrites, two repeat distances, a +1 (+2) lazy probe, backward extension, skip
+// acceleration): one chain of ~230 K visited positions per MiB, one wave per block. What a lone wave pays for on this part is
+// measured (profiles/r02_lone_wave_latencies.md): ~2.5 ns per instruction and 100-400 ns per DEPENDENT memory access; the
+// kernel is built around the second number:
+//   * the source is read-only for the kernel, so everything the chain reads of it (the 8 bytes at the position, the 4 bytes
+//     at the two repeat candidates and at the hash candidate) comes through the scalar cache as wave-uniform s_load's: no
+//     vector loads, no v_readfirstlane, several of them in flight at once;
+//   * the hash table entry of the NEXT position (the one visited if this position finds nothing) is fetched while this
+//     position is being decided, so a run of literals pays one dependent access per position (the candidate's bytes)
+//     instead of three (position bytes -> table entry -> candidate bytes); an entry fetched ahead is corrected when the
+//     current position hashes to the same slot;
+//   * match lengths are measured by the whole wave, 512 bytes per round (8 bytes per lane, one ballot), and so are the
+//     backward extension (64 bytes per round), the literal copies and the hashing of the positions inside a match
+//     (positions only grow, so the sequential "last writer wins" is an atomicMax);
+//   * every position the parse inserts is larger than all earlier ones, so a table write is an atomicMax (order-free, no fence on
+//     the chain) and a table read a relaxed load, both at workgroup scope (the XCD's own L2: agent scope costs ~1 us per access); only the burst of inserts behind a match is
+//     drained before the chain goes on.
+// Parallelism across blocks only (the format gives no other); the table (256 KiB / 2 MiB per block) lives in HBM/L2.
 #include "bits.h"
 
 #define KNZ_LZ_MAX_DIST1 ((1 << 16) - 2)
@@ -34,14 +45,40 @@ __device__ __forceinline__ uint32_t knz_le32(const uint8_t* p) {
 }
 __device__ __forceinline__ uint64_t knz_le64(const uint8_t* p) { return (uint64_t)knz_le32(p) | ((uint64_t)knz_le32(p + 4) << 32); }
 
-__device__ __forceinline__ int knz_lz_find_match(const uint8_t* src, int srcIdx, int ref, int maxMatch) {   // :593-607
-    int bestLen = 0;
-    while (bestLen + 8 <= maxMatch) {
-        const uint64_t diff = knz_le64(src + srcIdx + bestLen) ^ knz_le64(src + ref + bestLen);
-        if (diff != 0) { bestLen += (int)(__ffsll((unsigned long long)diff) - 1) >> 3; break; }
-        bestLen += 8;
+// per-lane unaligned 8-byte load (one global_load_dwordx2: gfx950 runs with unaligned access enabled)
+struct __attribute__((packed)) KnzPacked64 { uint64_t v; };
+__device__ __forceinline__ uint64_t knz_vle64(const uint8_t* p) { return ((const KnzPacked64*)p)->v; }
+
+// wave-uniform little-endian reads of the (read-only) source through the scalar cache: the aligned dwords around p, shifted
+__device__ __forceinline__ uint64_t knz_sle64(const uint8_t* p) {
+    const uintptr_t a = (uintptr_t)p & ~(uintptr_t)3;
+    const uint32_t sh = ((uint32_t)(uintptr_t)p & 3u) * 8u;
+    const uint32_t w0 = wave_sload_u32((const uint8_t*)a), w1 = wave_sload_u32((const uint8_t*)a + 4), w2 = wave_sload_u32((const uint8_t*)a + 8);
+    const uint64_t lo = ((uint64_t)w1 << 32) | w0;
+    return sh ? ((lo >> sh) | ((uint64_t)w2 << (64 - sh))) : lo;
+}
+__device__ __forceinline__ uint32_t knz_sle32(const uint8_t* p) {
+    const uintptr_t a = (uintptr_t)p & ~(uintptr_t)3;
+    const uint32_t sh = ((uint32_t)(uintptr_t)p & 3u) * 8u;
+    const uint32_t w0 = wave_sload_u32((const uint8_t*)a), w1 = wave_sload_u32((const uint8_t*)a + 4);
+    return (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh);
+}
+
+// findMatchLZX (:593-607) by the whole wave: lane l compares the 8 bytes at offset base + 8 l, the first lane that differs (or
+// whose 8 bytes no longer fit under maxMatch) ends the match; 512 bytes per round
+__device__ __forceinline__ int knz_lz_match_wave(const uint8_t* src, int a, int b, int maxMatch, int lane) {
+    for (int base = 0;; base += 512) {
+        const int off = base + 8 * lane;
+        const bool valid = off + 8 <= maxMatch;
+        const uint64_t diff = valid ? (knz_vle64(src + a + off) ^ knz_vle64(src + b + off)) : 0;
+        const uint64_t stop = wave_ballot(!valid || diff != 0);
+        if (stop) {
+            const uint32_t l = (uint32_t)(__ffsll((unsigned long long)stop) - 1);
+            const uint32_t dlo = wave_readlane((uint32_t)diff, l), dhi = wave_readlane((uint32_t)(diff >> 32), l);
+            const uint64_t d = ((uint64_t)dhi << 32) | dlo;
+            return base + 8 * (int)l + (d ? (int)((__ffsll((unsigned long long)d) - 1) >> 3) : 0);   // (d == 0: the lane ran out of room)
+        }
     }
-    return bestLen;
 }
 
 __device__ __forceinline__ int knz_lz_emit_length(uint8_t* block, int length, bool writer) {   // :193-214
@@ -55,6 +92,10 @@ __device__ __forceinline__ int knz_lz_emit_length(uint8_t* block, int length, bo
     if (writer) { block[0] = 255; block[1] = (uint8_t)(length >> 16); block[2] = (uint8_t)(length >> 8); block[3] = (uint8_t)length; }
     return 4;
 }
+
+// hash table entries: the table belongs to this workgroup alone, so workgroup-scope relaxed atomics (served by the XCD's L2: a load
+// issued after a write of the same wave sees it, no fence)
+__device__ __forceinline__ int knz_lz_tab_load(const int32_t* p) { return (int)wave_bcast((uint32_t)knz_wg_load_i32(p), 0); }   // (lane 0 is the lane that writes the table)
 
 __global__ __launch_bounds__(64) void knz_lz_forward_kernel(LzArgs a) {
     const int lane = threadIdx.x;
@@ -83,78 +124,102 @@ __global__ __launch_bounds__(64) void knz_lz_forward_kernel(LzArgs a) {
     int srcIdx = 0, dstIdx = 13, anchor = 0, mLenIdx = 0, mIdx = 0, tkIdx = 0;
     int repd0 = count, repd1 = count, repdIdx = 0, srcInc = 0;
     int status = 1;                                                 // 1 ok, 0 skip, <0 error
-#define KNZ_LZ_HASH(P) ((uint32_t)(((knz_le64(P) << 24) * (uint64_t)0x1E35A7BD) >> rshift))
+    // fetched ahead for position pfPos: its 8 bytes, its hash, and its table entry, which stays a pending per-lane load (pfLoad)
+    // until the position is visited, unless the entry is known without asking memory (pfKnown >= 0: the slot was just written)
+    int pfPos = -1, pfKnown = -1;
+    uint32_t pfHash = 0, pfLoad = 0;
+    uint64_t pfBytes = 0;
+#define KNZ_LZ_HASHV(V) ((uint32_t)((((V) << 24) * (uint64_t)0x1E35A7BD) >> rshift))
 
     while (srcIdx < srcEnd) {
         int bestLen = 0;
-        const uint32_t h0 = KNZ_LZ_HASH(src + srcIdx);
-        const int ref0 = hashes[h0];
-        wave_sync();                                                // every lane has read the entry before lane 0 overwrites it
-        if (writer) hashes[h0] = srcIdx;
-        wave_sync();                                                // and sees the new value from here on
-        const uint64_t p = knz_le64(src + srcIdx);
+        const bool ahead = pfPos == srcIdx;
+        const uint64_t p = ahead ? pfBytes : knz_sle64(src + srcIdx);
+        const uint32_t h0 = ahead ? pfHash : KNZ_LZ_HASHV(p);
+        const int ref0 = ahead ? (pfKnown >= 0 ? pfKnown : (int)wave_bcast(pfLoad, 0)) : knz_lz_tab_load(hashes + h0);
+        if (writer) knz_wg_max_i32(&hashes[h0], srcIdx);
         const int srcIdx1 = srcIdx + 1;
+        // fetch ahead for the position this one leads to when it finds no match (:356-358): its bytes, its hash, and a request for
+        // its table entry that is left in flight (issued before the candidate reads below, so that it overlaps them)
+        const int nextPos = srcIdx1 + (srcInc >> 6);
+        pfPos = -1;
+        if (nextPos < srcEnd) {
+            pfBytes = knz_sle64(src + nextPos);
+            pfHash = KNZ_LZ_HASHV(pfBytes);
+            pfKnown = pfHash == h0 ? srcIdx : -1;
+            pfLoad = (uint32_t)knz_wg_load_i32(hashes + pfHash);
+            pfPos = nextPos;
+        }
         const int maxMatch = min(srcEnd - srcIdx1, KNZ_LZ_MAX_MATCH);
-        int ref = srcIdx1 - (repdIdx ? repd1 : repd0);
         const int minRef = max(srcIdx - maxDist, 0);
-        if (ref > minRef && (uint32_t)(p >> 8) == knz_le32(src + ref)) {
-            bestLen = knz_lz_find_match(src, srcIdx1, ref, maxMatch);
+        // the 4 bytes at the two repeat candidates and at the hash candidate: three scalar loads in flight together (one wait)
+        const int refA = srcIdx1 - (repdIdx ? repd1 : repd0), refB = srcIdx1 - (repdIdx ? repd0 : repd1);
+        const uint32_t vA = refA > minRef ? knz_sle32(src + refA) : 0, vB = refB > minRef ? knz_sle32(src + refB) : 0;
+        const uint32_t vC = ref0 > minRef ? knz_sle32(src + ref0) : 0;
+        int ref = refA;
+        if (ref > minRef && (uint32_t)(p >> 8) == vA) {
+            bestLen = knz_lz_match_wave(src, srcIdx1, ref, maxMatch, lane);
         } else {
-            ref = srcIdx1 - (repdIdx ? repd0 : repd1);
-            if (ref > minRef && (uint32_t)(p >> 8) == knz_le32(src + ref)) bestLen = knz_lz_find_match(src, srcIdx1, ref, maxMatch);
+            ref = refB;
+            if (ref > minRef && (uint32_t)(p >> 8) == vB) bestLen = knz_lz_match_wave(src, srcIdx1, ref, maxMatch, lane);
         }
         if (bestLen < minMatch) {
             ref = ref0;
             bool found = false;
-            if (ref > minRef && (uint32_t)p == knz_le32(src + ref)) {
-                bestLen = knz_lz_find_match(src, srcIdx, ref, min(srcEnd - srcIdx, KNZ_LZ_MAX_MATCH));
+            if (ref > minRef && (uint32_t)p == vC) {
+                bestLen = knz_lz_match_wave(src, srcIdx, ref, min(srcEnd - srcIdx, KNZ_LZ_MAX_MATCH), lane);
                 found = bestLen >= minMatch;
             }
             if (!found) {
-                srcIdx = srcIdx1 + (srcInc >> 6);
+                srcIdx = nextPos;
                 srcInc++;
                 repdIdx = 0;
                 continue;
             }
             if (ref != srcIdx - repd0 && ref != srcIdx - repd1) {      // checkNext (:362-398)
-                const uint32_t h1 = KNZ_LZ_HASH(src + srcIdx1);
-                const int ref1 = hashes[h1];
-                wave_sync();
-                if (writer) hashes[h1] = srcIdx1;
-                wave_sync();
-                if (ref1 > minRef + 1 && knz_le32(src + srcIdx1 + bestLen - 3) == knz_le32(src + ref1 + bestLen - 3)) {
-                    const int bestLen1 = knz_lz_find_match(src, srcIdx1, ref1, maxMatch);
+                uint32_t h1;
+                int ref1;
+                if (pfPos == srcIdx1) { h1 = pfHash; ref1 = pfKnown >= 0 ? pfKnown : (int)wave_bcast(pfLoad, 0); }
+                else { h1 = KNZ_LZ_HASHV(knz_sle64(src + srcIdx1)); ref1 = h1 == h0 ? srcIdx : knz_lz_tab_load(hashes + h1); }
+                if (writer) knz_wg_max_i32(&hashes[h1], srcIdx1);
+                if (ref1 > minRef + 1 && knz_sle32(src + srcIdx1 + bestLen - 3) == knz_sle32(src + ref1 + bestLen - 3)) {
+                    const int bestLen1 = knz_lz_match_wave(src, srcIdx1, ref1, maxMatch, lane);
                     if (bestLen1 >= bestLen) { ref = ref1; bestLen = bestLen1; srcIdx = srcIdx1; }
                 }
                 if (a.extra) {
                     const int srcIdx2 = srcIdx1 + 1;
-                    const uint32_t h2 = KNZ_LZ_HASH(src + srcIdx2);
-                    const int ref2 = hashes[h2];
-                    wave_sync();
-                    if (writer) hashes[h2] = srcIdx2;
-                    wave_sync();
-                    if (ref2 > minRef + 2 && knz_le32(src + srcIdx2 + bestLen - 3) == knz_le32(src + ref2 + bestLen - 3)) {
-                        const int bestLen2 = knz_lz_find_match(src, srcIdx2, ref2, min(srcEnd - srcIdx2, KNZ_LZ_MAX_MATCH));
+                    const uint32_t h2 = KNZ_LZ_HASHV(knz_sle64(src + srcIdx2));
+                    const int ref2 = h2 == h1 ? srcIdx1 : (h2 == h0 ? srcIdx1 - 1 : knz_lz_tab_load(hashes + h2));
+                    if (writer) knz_wg_max_i32(&hashes[h2], srcIdx2);
+                    if (ref2 > minRef + 2 && knz_sle32(src + srcIdx2 + bestLen - 3) == knz_sle32(src + ref2 + bestLen - 3)) {
+                        const int bestLen2 = knz_lz_match_wave(src, srcIdx2, ref2, min(srcEnd - srcIdx2, KNZ_LZ_MAX_MATCH), lane);
                         if (bestLen2 >= bestLen) { ref = ref2; bestLen = bestLen2; srcIdx = srcIdx2; }
                     }
                 }
             }
-            while (srcIdx > anchor && ref > minRef && src[srcIdx - 1] == src[ref - 1]) { bestLen++; ref--; srcIdx--; }
+            // extend backwards (:400-405): 64 bytes per round
+            for (;;) {
+                const int room = min(srcIdx - anchor, ref - minRef);
+                const bool same = lane < room && src[srcIdx - 1 - lane] == src[ref - 1 - lane];
+                const uint64_t stop = wave_ballot(!same);
+                const int k = stop ? (int)(__ffsll((unsigned long long)stop) - 1) : 64;
+                bestLen += k; ref -= k; srcIdx -= k;
+                if (k < 64) break;
+            }
             if (bestLen > KNZ_LZ_MAX_MATCH) {
                 srcIdx += bestLen - KNZ_LZ_MAX_MATCH;
                 ref += bestLen - KNZ_LZ_MAX_MATCH;
                 bestLen = KNZ_LZ_MAX_MATCH;
             }
         } else {
-            if (src[srcIdx] == src[ref - 1] && bestLen < KNZ_LZ_MAX_MATCH) { bestLen++; ref--; }
+            if ((uint8_t)p == (uint8_t)knz_sle32(src + ref - 1) && bestLen < KNZ_LZ_MAX_MATCH) { bestLen++; ref--; }
             else {
                 srcIdx++;
-                const uint32_t h1 = KNZ_LZ_HASH(src + srcIdx);
-                wave_sync();
-                if (writer) hashes[h1] = srcIdx;
-                wave_sync();
+                const uint32_t h1 = pfPos == srcIdx ? pfHash : KNZ_LZ_HASHV(knz_sle64(src + srcIdx));
+                if (writer) knz_wg_max_i32(&hashes[h1], srcIdx);
             }
         }
+        pfPos = -1;                                                  // a match: the chain restarts behind it
         srcInc = 0;
         const int dist = srcIdx - ref;
         const int mLen = bestLen - minMatch;
@@ -189,10 +254,10 @@ __global__ __launch_bounds__(64) void knz_lz_forward_kernel(LzArgs a) {
             dstIdx += litLen;
         }
         anchor = srcIdx + bestLen;
-        // every position inside the match is hashed (:517-553); positions grow, so the sequential "last writer wins" is a max
-        wave_sync();
-        for (int pos = srcIdx + 1 + lane; pos < anchor; pos += 64) atomicMax(&hashes[KNZ_LZ_HASH(src + pos)], pos);
-        wave_sync();
+        // every position inside the match is hashed (:517-553); positions grow, so the sequential "last writer wins" is a max. Nothing
+        // waits for them: the table loads that follow are issued behind them by the same wave and reach the same L2 channel in order.
+        for (int pos = srcIdx + 1 + lane; pos < anchor; pos += 64) knz_wg_max_i32(&hashes[KNZ_LZ_HASHV(knz_vle64(src + pos))], pos);
+        wave_order_lanes();
         srcIdx = anchor;
     }
     if (status == 1) {
