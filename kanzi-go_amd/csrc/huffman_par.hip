@@ -598,6 +598,7 @@ __device__ __forceinline__ void knz_walk_block_body(const WalkBlocksArgs& a, con
     volatile uint32_t* vsync = s_sync;
     const uint64_t ringOrigin = (a.blk_bit[b] >> 5) & ~(uint64_t)255;  // ring word r holds stream word ringOrigin + r (mod ring size)
     const bool ringOk = (((uintptr_t)a.stream) & 15) == 0;             // 16-byte loads; otherwise the serial parser runs
+    bool ringLive = ringOk;                                            // cleared when the feeder does not answer in time: serial parser from there on
     if (FUSED) wave_raise_priority();                 // the decoders of the same launch share the CU with this chain
     if (threadIdx.x >= 64) {
         // ---- feeder ---------------------------------------------------------------------------------------------------------
@@ -675,7 +676,7 @@ __device__ __forceinline__ void knz_walk_block_body(const WalkBlocksArgs& a, con
             const uint32_t sz = min(chunkSize, preLen - k * chunkSize);
             if (writer) knz_publish64(&a.chunk_bit[(size_t)b * cpb + k], pos);
             published = k + 1;
-            if (entropy == KNZ_E_HUFFMAN && sz >= 32 && ringOk) {
+            if (entropy == KNZ_E_HUFFMAN && sz >= 32 && ringLive) {
                 KNZ_PROF_T(w0);
                 const uint64_t w0i = pos >> 5;
                 const uint32_t rel = (uint32_t)(w0i - ringOrigin);
@@ -686,9 +687,12 @@ __device__ __forceinline__ void knz_walk_block_body(const WalkBlocksArgs& a, con
                 if (filled < need) {
                     uint32_t spins = 0;
                     while ((filled = vsync[0]) < need) { wave_spin_pause(); if (++spins > (1u << 24)) break; }
-                    if (filled < need) { status = KNZ_ERR_PROCESS_BLOCK; break; }
-                    wg_fence_acquire();
+                    // a feeder that does not answer (emulator, debugger, oversubscribed CU) is a timing event, not a damaged stream:
+                    // the walk goes on with the serial parser, which reads the stream directly
+                    if (filled < need) ringLive = false;
+                    else wg_fence_acquire();
                 }
+              if (ringLive) {
                 KNZ_PROF_T(w1);
                 KNZ_PROF_T(w2);
                 // the ring holds byte-swapped words (the feeder swaps): the header is parsed in place
@@ -709,6 +713,7 @@ __device__ __forceinline__ void knz_walk_block_body(const WalkBlocksArgs& a, con
                     continue;
                 }
                 // unusual header: serial parser below
+              }
             }
             if (stale) { r.seek(pos); stale = false; }
             if (entropy == KNZ_E_NONE || (entropy == KNZ_E_HUFFMAN && sz < 32) || ((entropy == KNZ_E_ANS0 || entropy == KNZ_E_ANS1) && preLen <= 32)) {

@@ -198,6 +198,36 @@ def check_assemble(be, entropy, block_size, n, ranks):
     c.close()
 
 
+def check_short_inner_block(be):
+    """A stream whose NON-final blocks are short (concatenated segments, other writers): io.Reader accepts it
+    (CompressedStream.go:1707-1710 only bounds a block by the stream's block size), so must knz_dev_decompress. Built by
+    assembling two independently encoded segments, the first of which ends in a short block."""
+    bs = 1 << 14
+    for transform, entropy in (("NONE", "HUFFMAN"), ("BWT+RANK+ZRLT", "ANS0")):
+        a, b = corpus(bs + 4321, 7), corpus(2 * bs + 99, 8)
+        c = K.Codec(transform, entropy, bs, lib=be.lib)
+        segs, bits, keep = [], [], []
+        for part in (a, b):
+            src, ks = be.to_dev(part)
+            cap = 2 * len(part) + 65536
+            dst, kd = be.empty(cap)
+            bits.append(c.dev_compress_blocks(src, len(part), dst, cap))
+            segs.append(dst)
+            keep += [ks, kd]
+        n = len(a) + len(b)
+        cap = 2 * n + 65536
+        out, kout = be.empty(cap)
+        total = c.dev_assemble(n, segs, bits, out, cap)
+        stream = be.to_host(kout, total)
+        assert O.decompress(stream, n + 64) == a + b                         # the oracle's Reader takes the short block in the middle
+        sp, ksp = be.to_dev(stream, 4)
+        # blocks are placed at multiples of the block size first, so the destination holds nblocks * block_size
+        back, kb = be.empty(5 * bs + 64)
+        assert c.dev_decompress(sp, len(stream), back, 5 * bs + 64) == n
+        assert be.to_host(kb, n) == a + b
+        c.close()
+
+
 def transform_inputs(zrlt=False, max_len=1 << 30):
     for name, data in _transform_inputs(zrlt):
         if len(data) <= max_len:

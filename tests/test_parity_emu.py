@@ -93,6 +93,10 @@ def test_reference_test_inputs_both_directions(be):
     P.check_reference_inputs(be)
 
 
+def test_short_block_inside_stream(be):
+    P.check_short_inner_block(be)
+
+
 def test_bwt_inverse_list_ranking(be, monkeypatch):
     P.check_bwt_list_ranking(be, monkeypatch, max_len=2100)
     monkeypatch.setenv("KNZ_BWT_RANK_MIN", "256")
