@@ -289,7 +289,10 @@ def main():
     d_seg = dev_zeros(cap)
     d_back = dev_zeros(n_my + 4096)
     d_stream = dev_zeros(size + size // 2 + (1 << 20)) if rank == 0 and world > 1 else None
-    stream = 0 if emu else torch.cuda.current_stream().cuda_stream
+    # the steps run on a stream of their own (non-blocking): a NULL stream would mean the handle's own stream, which is ordered against
+    # the legacy default stream and pays that ordering on every launch (visible on the microsecond-scale configs)
+    bench_stream = None if emu else torch.cuda.Stream(device=dev)
+    stream = 0 if emu else bench_stream.cuda_stream
 
     stage = {"enc_transform": 0.0, "enc_entropy": 0.0, "enc_layout": 0.0, "enc_gather": 0.0, "dec_walk": 0.0, "dec_entropy": 0.0, "dec_transform": 0.0}
     kern_ms, kern_launches = {}, {}
@@ -342,6 +345,9 @@ def main():
             stage["enc_transform"] += tm[0]; stage["enc_entropy"] += tm[1]; stage["enc_layout"] += tm[2]; stage["enc_gather"] += tm[3]
             stage["dec_walk"] += td[0]; stage["dec_entropy"] += td[1]; stage["dec_transform"] += td[2]
 
+    sync()
+    if bench_stream is not None:
+        torch.cuda.set_stream(bench_stream)                   # torch.distributed orders its collectives against the current stream
     for _ in range(args.warmup):
         one_step(False)
     if world > 1:
