@@ -250,39 +250,47 @@ struct RankChainV {
         if (!PACKED) p[K] = keep ? p[K] : (ins ? vi : ps);
         q[K] = keep ? q[K] : min(vqc, qs);
     }
-    __device__ __forceinline__ uint32_t step_high(uint32_t r, uint32_t vi8, uint32_t vi) {
-        const uint32_t kr = r >> 6, l = r & 63;
-        uint32_t se, sp = 0;
-        if (kr == 1) { se = wave_readlane(e[1], l); if (!PACKED) sp = wave_readlane(p[1], l); }
-        else if (kr == 2) { se = wave_readlane(e[2], l); if (!PACKED) sp = wave_readlane(p[2], l); }
-        else { se = wave_readlane(e[3], l); if (!PACKED) sp = wave_readlane(p[3], l); }
+    template <int KR>
+    __device__ __forceinline__ uint32_t step_high_in(uint32_t r, uint32_t vi8, uint32_t vi) {        // r lives in register KR
+        const uint32_t l = r & 63;
+        const uint32_t se = wave_readlane(e[KR], l);
         int vqc;
         uint32_t vnew;
         if (PACKED) { vqc = MODE == 1 ? (int)(vi8 >> 8) : (int)((se + vi8) >> 9); vnew = (se & vff) | vi8; }
-        else { vqc = MODE == 1 ? (int)vi : (int)((sp + vi) >> 1); vnew = se; }
-        if (kr == 3) high_reg<3>(r, vqc, vnew, vi);
-        if (kr >= 2) high_reg<2>(r, vqc, vnew, vi);
+        else { vqc = MODE == 1 ? (int)vi : (int)((wave_readlane(p[KR], l) + vi) >> 1); vnew = se; }
+        if (KR >= 3) high_reg<3>(r, vqc, vnew, vi);
+        if (KR >= 2) high_reg<2>(r, vqc, vnew, vi);
         high_reg<1>(r, vqc, vnew, vi);
         high_reg<0>(r, vqc, vnew, vi);
         refresh();
         return se;
+    }
+    __device__ __forceinline__ uint32_t step_high(uint32_t r, uint32_t vi8, uint32_t vi) {           // one straight-line body per register of r
+        const uint32_t kr = r >> 6;
+        if (kr == 1) return step_high_in<1>(r, vi8, vi);
+        if (kr == 2) return step_high_in<2>(r, vi8, vi);
+        return step_high_in<3>(r, vi8, vi);
     }
     // any rank, scalar time (tails, unaligned sources)
     __device__ __forceinline__ uint32_t step_any(uint32_t r, uint32_t i) {
         const uint32_t vi8 = wave_in_vgpr(i << 8), vi = wave_in_vgpr(i);
         return (r < 64 ? step_low(r, vi8, vi) : step_high(r, vi8, vi)) & (PACKED ? 0xFFu : 0xFFFFFFFFu);
     }
-    // four ranks of one word of a group that holds ranks >= 64, first symbol at time i; returns the symbols in lanes 0..3
-    __device__ __forceinline__ uint32_t word_any(uint32_t w, uint32_t i) {
-        if (w == 0) return run_top(i + 3, 4);
+    // word W (0..3) of a group that holds ranks >= 64, first symbol at time i: one dispatch per symbol; symbols go to lanes 4W .. 4W+3 of ob
+    template <int W>
+    __device__ __forceinline__ void word_any(uint32_t w, uint32_t i, uint32_t& ob) {
+        if (w == 0) {
+            const uint32_t s = run_top(i + 3, 4);
+            ob = wave_writelane_c<4 * W>(ob, s); ob = wave_writelane_c<4 * W + 1>(ob, s);
+            ob = wave_writelane_c<4 * W + 2>(ob, s); ob = wave_writelane_c<4 * W + 3>(ob, s);
+            return;
+        }
         const uint32_t vi8 = wave_in_vgpr(i << 8), vi = wave_in_vgpr(i);
-        uint32_t ow = 0;
         const uint32_t r0 = w & 0xFFu, r1 = (w >> 8) & 0xFFu, r2 = (w >> 16) & 0xFFu, r3 = w >> 24;
-        ow = wave_writelane_c<0>(ow, r0 < 64 ? step_low(r0, vi8, vi) : step_high(r0, vi8, vi));
-        ow = wave_writelane_c<1>(ow, r1 < 64 ? step_low(r1, vi8 + 0x100u, vi + 1u) : step_high(r1, vi8 + 0x100u, vi + 1u));
-        ow = wave_writelane_c<2>(ow, r2 < 64 ? step_low(r2, vi8 + 0x200u, vi + 2u) : step_high(r2, vi8 + 0x200u, vi + 2u));
-        ow = wave_writelane_c<3>(ow, r3 < 64 ? step_low(r3, vi8 + 0x300u, vi + 3u) : step_high(r3, vi8 + 0x300u, vi + 3u));
-        return ow;
+        ob = wave_writelane_c<4 * W>(ob, r0 < 64 ? step_low(r0, vi8, vi) : step_high(r0, vi8, vi));
+        ob = wave_writelane_c<4 * W + 1>(ob, r1 < 64 ? step_low(r1, vi8 + 0x100u, vi + 1u) : step_high(r1, vi8 + 0x100u, vi + 1u));
+        ob = wave_writelane_c<4 * W + 2>(ob, r2 < 64 ? step_low(r2, vi8 + 0x200u, vi + 2u) : step_high(r2, vi8 + 0x200u, vi + 2u));
+        ob = wave_writelane_c<4 * W + 3>(ob, r3 < 64 ? step_low(r3, vi8 + 0x300u, vi + 3u) : step_high(r3, vi8 + 0x300u, vi + 3u));
     }
     // word W (0..3) of a 16-symbol group whose ranks are all < 64, first symbol at time i; symbols go to lanes 4W .. 4W+3 of
     // ob (low byte): no branch and no register traffic between the steps
@@ -318,15 +326,9 @@ __device__ __forceinline__ void knz_rank_chain_block_v(const uint8_t* src, uint8
             uint32_t ob = 0;
             const uint32_t any = cur.x | cur.y | cur.z | cur.w;
             if (any == 0) ob = c.run_top(i + 15, 16);
-            else if (any & 0xC0C0C0C0u) {                                        // ranks >= 64 in the group: one dispatch per symbol, word by word
-                knz_u32x4 t = cur;
-#pragma nounroll
-                for (uint32_t wi = 0; wi < 4; wi++) {
-                    const uint32_t ow = c.word_any(t.x, i + 4 * wi);
-                    if (lane < 4) dst[i + 4 * wi + lane] = (uint8_t)ow;           // (a zero word's symbol is wave-uniform: every lane has it)
-                    t.x = t.y; t.y = t.z; t.z = t.w;
-                }
-                continue;
+            else if (any & 0xC0C0C0C0u) {                                        // ranks >= 64 in the group: one dispatch per symbol
+                c.template word_any<0>(cur.x, i, ob); c.template word_any<1>(cur.y, i + 4, ob);
+                c.template word_any<2>(cur.z, i + 8, ob); c.template word_any<3>(cur.w, i + 12, ob);
             } else {
                 c.template word<0>(cur.x, i, ob); c.template word<1>(cur.y, i + 4, ob);
                 c.template word<2>(cur.z, i + 8, ob); c.template word<3>(cur.w, i + 12, ob);
