@@ -425,6 +425,10 @@ def main():
                     roof["traffic"] = int(tr[dom])
                     roof["traffic_over_algorithmic"] = round(tr[dom] / max(alg, 1), 3)
         out["roofline"] = roof
+        if entropy == "HUFFMAN" and not emu:
+            # the single-launch walk + decode hands a chunk to the serial kernel when a decoder gives up waiting for its walker:
+            # 0 for every stream a kanzi encoder wrote unless the dispatch order went against the kernel
+            out["huffman_serial_chunks_last_decode"] = int(codec.last_counter(0))
         if not args.no_verify:
             import oracle_lib as O
             exp = O.compress(tiled(0, size), transform, entropy, bs, 0, jobs=os.cpu_count() or 1)

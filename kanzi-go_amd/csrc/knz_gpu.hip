@@ -191,6 +191,8 @@ extern "C" int knz_close(void* handle) {
     DeviceGuard dg(h);                                  // (the workspace buffers are freed by ~Handle while the device is bound)
     if (h->own_stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); h->stream = nullptr; h->own_stream = false; }
     if (h->pinned) hipHostFree(h->pinned);
+    if (h->pinned_status) hipHostFree(h->pinned_status);
+    if (h->pinned_len) hipHostFree(h->pinned_len);
     for (int i = 0; i <= KNZ_STAGE_COUNT; i++) hipEventDestroy(h->ev[i]);
     for (int i = 0; i < KNZ_MAX_PROBES; i++) if (h->probes[i].a) { hipEventDestroy(h->probes[i].a); hipEventDestroy(h->probes[i].b); }
     delete h;
@@ -446,15 +448,15 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     hipEventRecord(h->ev[4], st);
     h->ev_valid = true;
 
+    // results come back through the handle's pinned page (truly asynchronous copies, one synchronisation): total bits, overflow flag,
+    // and the per-block status / post-transform length tables (batches beyond the page's capacity go through a pinned side buffer)
     uint64_t* res = (uint64_t*)h->pinned;
     HIP_OK(hipMemcpyAsync(res, h->total_bits.p, 16, hipMemcpyDeviceToHost, st));
-    int32_t* status = (int32_t*)((uint8_t*)h->pinned + 64);
-    // block statuses: only the first 960 fit the pinned page; larger batches are checked in pieces
-    std::vector<int32_t> stv(nblocks);
-    std::vector<uint32_t> lenv(nblocks);
-    if (nblocks) HIP_OK(hipMemcpyAsync(stv.data(), h->blk_status.p, 4 * nblocks, hipMemcpyDeviceToHost, st));
-    if (nblocks) HIP_OK(hipMemcpyAsync(lenv.data(), h->blk_len.p, 4 * nblocks, hipMemcpyDeviceToHost, st));
-    (void)status;
+    if (h->reserve_pinned_tables((size_t)nblocks)) return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "pinned host allocation failed");
+    int32_t* stv = h->pinned_status;
+    uint32_t* lenv = h->pinned_len;
+    if (nblocks) HIP_OK(hipMemcpyAsync(stv, h->blk_status.p, 4 * (size_t)nblocks, hipMemcpyDeviceToHost, st));
+    if (nblocks) HIP_OK(hipMemcpyAsync(lenv, h->blk_len.p, 4 * (size_t)nblocks, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     HIP_OK(hipGetLastError());
     if (res[1] != 0) return knz_set_error(h, KNZ_ERR_WRITE_FILE, "destination buffer too small");

@@ -48,6 +48,19 @@ struct Handle {
     DevBuf a1_freqs, a1_tab, a1_ctxhdr, a1_ctxbits, a1_dtab, a1_info, a1_paybit, a1_f16, a1_ent, a1_cum;
     DevBuf sa_keys0, sa_keys1, sa_vals0, sa_vals1, sa_rank, sa_gs, sa_head, sa_unres, sa_pos, sa_tmp, sa_links, sa_sp;
     void* pinned = nullptr;           // small pinned host area for results
+    int32_t* pinned_status = nullptr; // pinned per-block tables of the last encode batch (grow-only)
+    uint32_t* pinned_len = nullptr;
+    size_t pinned_tables_cap = 0;
+    int reserve_pinned_tables(size_t n) {
+        if (n <= pinned_tables_cap) return 0;
+        if (pinned_status) hipHostFree(pinned_status);
+        if (pinned_len) hipHostFree(pinned_len);
+        pinned_status = nullptr; pinned_len = nullptr; pinned_tables_cap = 0;
+        const size_t want = n + n / 4 + 64;
+        if (hipHostMalloc((void**)&pinned_status, 4 * want) != hipSuccess || hipHostMalloc((void**)&pinned_len, 4 * want) != hipSuccess) return -1;
+        pinned_tables_cap = want;
+        return 0;
+    }
     hipEvent_t ev[KNZ_STAGE_COUNT + 1];
     bool ev_valid = false;
     float stage_ms[KNZ_STAGE_COUNT];
