@@ -46,6 +46,12 @@ int knzo_entropy_decode(uint32_t type, const uint8_t* bits, uint64_t nbytes, uin
     KNZO_CATCH
 }
 
+// ctx["blockSize"] / ctx["entropy"] of the calling thread for the single-object and single-block entry points below (the stream entry points
+// set them from their own arguments); block_size 0 / entropy 0xFFFFFFFF = key absent. Read by the TEXT transform only.
+int knzo_set_ctx(uint32_t block_size, uint32_t entropy_type) { tlsBlockSize = block_size; tlsEntropyType = entropy_type; return 0; }
+int knzo_get_data_type() { return tlsDataType; }
+int knzo_set_data_type(int dt) { tlsDataType = dt; return 0; }
+
 // rc -1 = transform declined (Forward error => skipped by the sequence)
 int knzo_transform_forward(uint64_t t, const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap, uint64_t* out_n) {
     KNZO_TRY

@@ -12,7 +12,7 @@ using namespace knzo;
 static uint64_t transformId(const std::string& tok) {
     if (tok == "NONE") return T_NONE; if (tok == "BWT") return T_BWT; if (tok == "LZ") return T_LZ;
     if (tok == "LZX") return T_LZX; if (tok == "ZRLT") return T_ZRLT; if (tok == "MTFT") return T_MTFT;
-    if (tok == "RANK") return T_RANK; if (tok == "SRT") return T_SRT; if (tok == "LZP") return T_LZP; if (tok == "UTF") return T_UTF;
+    if (tok == "RANK") return T_RANK; if (tok == "SRT") return T_SRT; if (tok == "LZP") return T_LZP; if (tok == "UTF") return T_UTF; if (tok == "TEXT") return T_TEXT;
     fprintf(stderr, "unknown transform %s\n", tok.c_str()); exit(2);
 }
 // Factory.go:289-328 GetType

@@ -18,7 +18,7 @@
 namespace knzo {
 
 // transform ids (Factory.go:31-53)
-enum : uint64_t { T_NONE = 0, T_BWT = 1, T_LZ = 3, T_ZRLT = 6, T_MTFT = 7, T_RANK = 8, T_SRT = 13, T_LZP = 14, T_LZX = 16, T_UTF = 17 };
+enum : uint64_t { T_NONE = 0, T_BWT = 1, T_LZ = 3, T_ZRLT = 6, T_MTFT = 7, T_RANK = 8, T_TEXT = 10, T_SRT = 13, T_LZP = 14, T_LZX = 16, T_UTF = 17 };
 // entropy ids (EntropyCodecFactory.go:26-42)
 enum : uint32_t { E_NONE = 0, E_HUFFMAN = 1, E_FPAQ = 2, E_ANS0 = 5, E_ANS1 = 8 };
 
@@ -75,7 +75,7 @@ static inline uint64_t xxhash64(const uint8_t* data, size_t len, uint64_t seed) 
 
 // ---- single transform dispatch (Factory.go:97-185 newToken) ---------------------------------
 static inline bool transformSupported(uint64_t t) {
-    return t == T_NONE || t == T_BWT || t == T_LZ || t == T_LZX || t == T_ZRLT || t == T_MTFT || t == T_RANK || t == T_SRT || t == T_LZP || t == T_UTF;
+    return t == T_NONE || t == T_BWT || t == T_LZ || t == T_LZX || t == T_ZRLT || t == T_MTFT || t == T_RANK || t == T_SRT || t == T_LZP || t == T_UTF || t == T_TEXT;
 }
 static inline size_t transformMaxEncodedLen(uint64_t t, size_t n) {
     switch (t) {
@@ -102,6 +102,7 @@ static inline size_t transformForward1(uint64_t t, const uint8_t* src, size_t n,
         case T_SRT: return srtForward(src, n, dst, cap);
         case T_LZP: return lzpForward(src, n, dst, cap);
         case T_UTF: return utfForward(src, n, dst, cap);
+        case T_TEXT: return textForward(src, n, dst, cap);
         default: throw KnzError(ERR_CREATE_CODEC, "Unknown transform type");
     }
 }
@@ -119,6 +120,7 @@ static inline size_t transformInverse1(uint64_t t, const uint8_t* src, size_t n,
         case T_SRT: return srtInverse(src, n, dst, cap);
         case T_LZP: return lzpInverse(src, n, dst, cap);
         case T_UTF: return utfInverse(src, n, dst, cap);
+        case T_TEXT: return textInverse(src, n, dst, cap);
         default: throw KnzError(ERR_INVALID_CODEC, "Unknown transform type");
     }
 }
@@ -492,6 +494,7 @@ static inline void compressStream(const uint8_t* src, size_t n, uint64_t transfo
     std::atomic<int> errCode(0);
     std::string errMsg;
     auto worker = [&]() {
+        tlsBlockSize = (uint32_t)blockSize; tlsEntropyType = entropyType;       // ctx["blockSize"], ctx["entropy"] (:218-220)
         for (;;) {
             size_t b = next.fetch_add(1);
             if (b >= nblocks || errCode.load()) return;
@@ -535,6 +538,7 @@ static inline void decompressStream(const uint8_t* src, size_t n, int jobs, std:
     std::atomic<int> errCode(0);
     std::string errMsg;
     auto worker = [&]() {
+        tlsBlockSize = (uint32_t)h.blockSize; tlsEntropyType = h.entropyType;   // ctx["blockSize"], ctx["entropy"] (:1385,:1406)
         for (;;) {
             size_t b = next.fetch_add(1);
             if (b >= nblocks || errCode.load()) return;

@@ -26,6 +26,10 @@ struct SkipTransform : std::runtime_error { // a Forward "error" = transform not
     explicit SkipTransform(const std::string& m) : std::runtime_error(m) {}
 };
 
+} // namespace knzo
+#include "text.hpp"      // the TEXT transform, the data types and the ctx thread-locals
+namespace knzo {
+
 // ---------------------------------------------------------------------------------------------
 // Suffix array by induced sorting (SA-IS). Standard published algorithm (Nong, Zhang, Chan 2009).
 // Order: plain lexicographic with "shorter is smaller" (as if a unique smallest sentinel followed).
@@ -880,8 +884,6 @@ static inline size_t srtInverse(const uint8_t* src, size_t n, uint8_t* dst, size
 // UTF codec (UTFCodec.go): UTF-8 code points -> 1- or 2-byte ranks by decreasing frequency, behind a map of the code points.
 // ctx["dataType"] (internal/Global.go:26-40) travels in a thread-local here: encodeBlock sets it from the block's magic number
 // (io/CompressedStream.go:811-819), a transform object used on its own sees DT_UNDEFINED.
-enum : int { DT_UNDEFINED = 0, DT_BIN = 6, DT_EXE = 5, DT_MULTIMEDIA = 4, DT_UTF8 = 8 };   // (distinct values; only equality matters)
-static thread_local int tlsDataType = DT_UNDEFINED;
 static const int UTF_MIN_BLOCKSIZE = 1024;
 
 static inline int utfSize(uint8_t b) {                       // _UTF_SIZES :31-48

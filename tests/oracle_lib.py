@@ -16,9 +16,9 @@ _LIB = None
 
 # transform / entropy ids (v2/transform/Factory.go:31-53, v2/entropy/EntropyCodecFactory.go:26-42)
 T_NONE, T_BWT, T_LZ, T_ZRLT, T_MTFT, T_RANK, T_LZX = 0, 1, 3, 6, 7, 8, 16
-T_SRT, T_LZP, T_UTF = 13, 14, 17
+T_SRT, T_LZP, T_UTF, T_TEXT = 13, 14, 17, 10
 E_NONE, E_HUFFMAN, E_FPAQ, E_ANS0, E_ANS1 = 0, 1, 2, 5, 8
-_TNAMES = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "LZP": 14, "LZX": 16, "UTF": 17}
+_TNAMES = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "LZP": 14, "LZX": 16, "UTF": 17, "TEXT": 10}
 _ENAMES = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5, "ANS1": 8}
 
 
@@ -54,6 +54,7 @@ def lib():
         L.knzo_entropy_decode.argtypes = [C.c_uint32, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.knzo_transform_forward.argtypes = [C.c_uint64, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.knzo_transform_inverse.argtypes = [C.c_uint64, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.knzo_set_ctx.argtypes = [C.c_uint32, C.c_uint32]
         L.knzo_max_encoded_len.argtypes = [C.c_uint64, C.c_uint64]
         L.knzo_max_encoded_len.restype = C.c_uint64
         L.knzo_sequence_forward.argtypes = [C.c_uint64, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64), u8p]
@@ -125,6 +126,16 @@ def entropy_decode(etype, payload, n):
     used = C.c_uint64()
     _chk(lib().knzo_entropy_decode(etype, p, len(a), out.ctypes.data_as(C.POINTER(C.c_uint8)), n, C.byref(used)))
     return out[:n].tobytes(), used.value
+
+
+def set_ctx(block_size=0, entropy=None):
+    """ctx["blockSize"] / ctx["entropy"] (type id) seen by single transform / block calls on this thread (TEXT reads them)."""
+    lib().knzo_set_ctx(int(block_size), 0xFFFFFFFF if entropy is None else int(entropy))
+
+
+def data_type():
+    """ctx["dataType"] as the last transform call on this thread left it (internal/Global.go:26-40 numbering)."""
+    return int(lib().knzo_get_data_type())
 
 
 def transform_forward(t, data):
