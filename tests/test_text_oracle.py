@@ -81,7 +81,7 @@ def test_not_text_sets_the_data_type():
         5: rng.choice(np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/", dtype=np.uint8), 5000).tobytes(),  # DT_BASE64
         7: rng.integers(0, 256, 100000).astype(np.uint8).tobytes(),                          # DT_BIN: all 256 values present
         9: rng.choice(np.frombuffer(b"\x01\x02\x03", dtype=np.uint8), 5000).tobytes(),       # DT_SMALL_ALPHABET
-        8: ("д" * 3000).encode("utf-8"),                                                     # DT_UTF8 (half the bytes are continuation bytes)
+        8: "".join(chr(0x410 + int(k)) for k in rng.integers(0, 60, 3000)).encode("utf-8"),         # DT_UTF8 (half the bytes are continuation bytes)
         0: bytes(range(1, 200)) * 30,                                                        # nothing recognisable
     }
     for dt, block in cases.items():
