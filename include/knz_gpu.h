@@ -35,7 +35,7 @@ enum {
 enum { KNZ_FLAG_SKIP_BLOCKS = 1 };
 
 /* transform ids, v2/transform/Factory.go:31-53 (6 bits each, first transform in bits 47..42) */
-enum { KNZ_T_NONE = 0, KNZ_T_BWT = 1, KNZ_T_LZ = 3, KNZ_T_ZRLT = 6, KNZ_T_MTFT = 7, KNZ_T_RANK = 8, KNZ_T_SRT = 13, KNZ_T_LZP = 14, KNZ_T_LZX = 16, KNZ_T_UTF = 17 };
+enum { KNZ_T_NONE = 0, KNZ_T_BWT = 1, KNZ_T_LZ = 3, KNZ_T_ZRLT = 6, KNZ_T_MTFT = 7, KNZ_T_RANK = 8, KNZ_T_TEXT = 10, KNZ_T_SRT = 13, KNZ_T_LZP = 14, KNZ_T_LZX = 16, KNZ_T_UTF = 17 };
 /* entropy ids, v2/entropy/EntropyCodecFactory.go:26-42 */
 enum { KNZ_E_NONE = 0, KNZ_E_HUFFMAN = 1, KNZ_E_FPAQ = 2, KNZ_E_ANS0 = 5, KNZ_E_ANS1 = 8 };
 

@@ -11,7 +11,7 @@ _LIB = None
 _LIB_PATH = None
 
 # v2/transform/Factory.go:31-53 ; v2/entropy/EntropyCodecFactory.go:26-42
-_TNAMES = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "LZP": 14, "LZX": 16, "UTF": 17}
+_TNAMES = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "LZP": 14, "LZX": 16, "UTF": 17, "TEXT": 10}
 _ENAMES = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5, "ANS1": 8}
 
 

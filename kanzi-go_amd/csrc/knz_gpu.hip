@@ -12,6 +12,7 @@
 #include "bwt.hip"
 #include "lz.hip"
 #include "srt_lzp.hip"
+#include "text.hip"
 #include "utf.hip"
 #include "xxhash.hip"
 #include "skip.hip"
@@ -119,7 +120,7 @@ uint32_t knz_build_stream_header(const knz_cfg& cfg, int64_t inputSize, uint32_t
 static bool transform_on_device(uint64_t t) {                    // packed sequence
     for (int s = 42; s >= 0; s -= 6) {
         const uint32_t id = (uint32_t)((t >> s) & 63);
-        if (!(id == KNZ_T_NONE || id == KNZ_T_BWT || id == KNZ_T_RANK || id == KNZ_T_MTFT || id == KNZ_T_ZRLT || id == KNZ_T_LZ || id == KNZ_T_LZX || id == KNZ_T_SRT || id == KNZ_T_LZP || id == KNZ_T_UTF)) return false;
+        if (!(id == KNZ_T_NONE || id == KNZ_T_BWT || id == KNZ_T_RANK || id == KNZ_T_MTFT || id == KNZ_T_ZRLT || id == KNZ_T_LZ || id == KNZ_T_LZX || id == KNZ_T_SRT || id == KNZ_T_LZP || id == KNZ_T_UTF || id == KNZ_T_TEXT)) return false;
     }
     return true;
 }
@@ -343,8 +344,8 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     if (nblocks && cfg.transform != 0) {
         xb.cur_ptr = h->blk_off.as<uint64_t>(); xb.cur_len = h->blk_len.as<uint32_t>(); xb.skip = h->blk_skip.as<uint8_t>();
         xb.blk_status = h->blk_status.as<int32_t>();
-        bool hasUtf = false;
-        for (int sft = 42; sft >= 0; sft -= 6) hasUtf = hasUtf || ((cfg.transform >> sft) & 63) == KNZ_T_UTF;
+        bool hasUtf = false;                                             // (or TEXT: the two stages that read and write ctx["dataType"])
+        for (int sft = 42; sft >= 0; sft -= 6) hasUtf = hasUtf || ((cfg.transform >> sft) & 63) == KNZ_T_UTF || ((cfg.transform >> sft) & 63) == KNZ_T_TEXT;
         if (hasUtf) {                                                    // ctx["dataType"] from the magic number of the untransformed block (:811-819)
             if (h->blk_dt.reserve(nblocks + 16)) return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
             hipLaunchKernelGGL(knz_block_datatype_kernel, dim3((nblocks + 63) / 64), dim3(64), 0, st, nblocks, (const uint64_t*)h->blk_off.as<uint64_t>(),

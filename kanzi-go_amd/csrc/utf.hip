@@ -32,7 +32,7 @@ struct UtfArgs {
     uint64_t* inv_map;           // [nblocks * 32768] bytes of the code point | length << 32 (inverse)
     uint8_t* chain_bits;         // [nblocks * bits_stride] code point starts of the sequential walk (forward, dataType == UTF8 only)
     uint64_t bits_stride;
-    uint8_t* blk_dt;             // [nblocks] ctx["dataType"]: 0 undefined, 1 set by the magic number (not UTF), 2 UTF8; may be null
+    uint8_t* blk_dt;             // [nblocks] ctx["dataType"] (internal/Global.go:26-40 numbering, text.hip): 0 undefined, 8 UTF8, ...; may be null
 };
 
 __device__ __forceinline__ uint32_t knz_utf_size(uint32_t b) {          // _UTF_SIZES :31-48
@@ -65,12 +65,12 @@ __global__ __launch_bounds__(64) void knz_utf_forward_kernel(UtfArgs a) {
     const uint32_t dt = a.blk_dt ? a.blk_dt[b] : 0u;
     if (count == 0) { if (lane == 0) { a.ok[b] = 1; a.out_len[b] = 0; } return; }
     // :93-114: block size, output size, ctx["dataType"]
-    if (count < KNZ_UTF_MIN_BLOCK || (uint64_t)a.out_cap < (uint64_t)count + 8192 || dt == 1) { if (lane == 0) { a.ok[b] = 0; a.out_len[b] = 0; } return; }
+    if (count < KNZ_UTF_MIN_BLOCK || (uint64_t)a.out_cap < (uint64_t)count + 8192 || (dt != KNZ_DT_UNDEFINED && dt != KNZ_DT_UTF8)) { if (lane == 0) { a.ok[b] = 0; a.out_len[b] = 0; } return; }
     int32_t* map = a.alias_map + ((size_t)b << KNZ_UTF_MAP_LOG);
     uint32_t* syms = a.symlist + (size_t)b * KNZ_UTF_MAX_SYMS;
     uint32_t* ranks = a.ranks + (size_t)b * KNZ_UTF_MAX_SYMS;
     uint8_t* cbits = a.chain_bits + (size_t)b * a.bits_stride;
-    const bool chainMode = dt == 2;                                      // mustValidate == false
+    const bool chainMode = dt == KNZ_DT_UTF8;                                      // mustValidate == false
     int start = 0;
     if (src[1] == 0xEF && src[2] == 0xBB && src[3] == 0xBF) start = 3;   // BigEndian.Uint32(src) & 0x00FFFFFF == 0xEFBBBF (:118)
     else while (start < 4 && knz_utf_size(src[start]) == 0) start++;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void knz_utf_forward_kernel(UtfArgs a) {
     const bool skip = dstIdx >= maxTarget;
     if (lane == 0) {
         a.ok[b] = skip ? 0 : 1; a.out_len[b] = skip ? 0 : (uint32_t)dstIdx;
-        if (!skip && a.blk_dt) a.blk_dt[b] = 2;                          // ctx["dataType"] = DT_UTF8 (:131-133: set once the block validated)
+        if (!skip && a.blk_dt) a.blk_dt[b] = KNZ_DT_UTF8;                          // ctx["dataType"] = DT_UTF8 (:131-133: set once the block validated)
     }
 }
 
@@ -302,30 +302,3 @@ __global__ __launch_bounds__(64) void knz_utf_inverse_kernel(UtfArgs a) {
     if (lane == 0) { a.ok[b] = 1; a.out_len[b] = (uint32_t)dstIdx; }
 }
 
-// ctx["dataType"] of every block from its magic number (v2/io/CompressedStream.go:811-819, internal/Magic.go:83-222):
-// 1 = BIN / MULTIMEDIA / EXE (a UTF stage declines), 0 = undefined
-__global__ void knz_block_datatype_kernel(uint32_t nblocks, const uint64_t* blk_off, const uint32_t* blk_len, uint8_t* blk_dt) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblocks) return;
-    uint32_t dt = 0;
-    if (blk_len[b] >= 4) {
-        const uint8_t* s = (const uint8_t*)blk_off[b];
-        const uint32_t key = ((uint32_t)s[0] << 24) | ((uint32_t)s[1] << 16) | ((uint32_t)s[2] << 8) | s[3];
-        const uint32_t k24 = key >> 8, k16 = key >> 16, sub = (key >> 8) & 0xFF;
-        bool known32 = false;
-        switch (key) {                                                   // the 32-bit magics GetMagicType knows; PDF / KNZ-like ones that set no type included
-            case 0x47494638u: case 0x504B0304u: case 0x377ABCAFu: case 0x89504E47u: case 0x7F454C46u: case 0xFEEDFACEu: case 0xCEFAEDFEu:
-            case 0xFEEDFACFu: case 0xCFFAEDFEu: case 0x28B52FFDu: case 0x81CFB2CEu: case 0x4D534346u: case 0x52494646u: case 0x664C6143u:
-            case 0xFD377A58u: case 0x4B414E5Au: case 0x52617221u: dt = 1; known32 = true; break;
-            case 0x25504446u: known32 = true; break;                     // PDF: recognised, none of the three classes
-            default: break;
-        }
-        if ((key & ~0x0Fu) == 0xFFD8FFE0u) dt = key == 0xFFD8FFE0u ? 1u : 0u;        // JPG: the class tests compare with the E0 form only
-        else if (k24 == 0x425A68u || k24 == 0x494433u) dt = 1;                       // BZIP2, MP3
-        else if (!known32) {
-            if (k16 == 0x1F8Bu || k16 == 0x424Du || k16 == 0x4D5Au) dt = 1;          // GZIP, BMP, WIN
-            else if ((k16 == 0x5034u || k16 == 0x5035u || k16 == 0x5036u) && (sub == 0x07 || sub == 0x0A || sub == 0x0D || sub == 0x20)) dt = 1;
-        }
-    }
-    blk_dt[b] = (uint8_t)dt;
-}

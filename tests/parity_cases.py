@@ -272,7 +272,7 @@ def _transform_inputs(zrlt=False):
     yield "binary", (rng.integers(0, 256, 50000, dtype=np.uint8) & rng.integers(0, 256, 50000, dtype=np.uint8) & rng.integers(0, 256, 50000, dtype=np.uint8)).tobytes()
 
 
-_TID = {"BWT": 1, "ZRLT": 6, "MTFT": 7, "RANK": 8, "LZ": 3, "LZX": 16, "SRT": 13, "LZP": 14, "UTF": 17}
+_TID = {"BWT": 1, "ZRLT": 6, "MTFT": 7, "RANK": 8, "LZ": 3, "LZX": 16, "SRT": 13, "LZP": 14, "UTF": 17, "TEXT": 10}
 
 
 def utf_text(n, seed, kinds=(0, 1, 2, 3)):
@@ -673,6 +673,75 @@ def check_utf_streams(be):
         assert c.dev_decompress(dst, nb, out, len(many) + 64) == len(many)
         assert be.to_host(ko, len(many)) == many
         c.close()
+
+
+def text_inputs(n=200_000):
+    import text_corpus as T
+    rng = np.random.default_rng(5)
+    yield "plain", T.make_text(n, seed=1)
+    yield "crlf", T.make_text(n, seed=2, crlf=True)
+    yield "utf8", T.make_text(n, seed=3, utf8=0.05)
+    yield "markup", T.make_text(n, seed=4, markup=True)
+    yield "escapes", T.make_text(n, seed=5, escapes=0.02)
+    yield "big-vocabulary", T.make_text(n, seed=6, vocab=40000, static_share=0.05)
+    yield "capitals", T.make_text(n, seed=7, upper=0.6)
+    yield "long-words", T.make_text(n, seed=8, max_word=40)
+    yield "leading-spaces", b"   " + T.make_text(n // 4, seed=9)
+    yield "static-words", b"the be and of in to with " * 200
+    yield "just-1024", T.make_text(1024, seed=10)
+    yield "below-1024", T.make_text(1023, seed=11)
+    yield "zip-magic", b"PK\x03\x04" + T.make_text(5000, seed=12)
+    yield "dna", rng.choice(np.frombuffer(b"acgt", dtype=np.uint8), 5000).tobytes()
+    yield "numeric", rng.choice(np.frombuffer(b"0123456789,. ", dtype=np.uint8), 5000).tobytes()
+    yield "base64", rng.choice(np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/", dtype=np.uint8), 5000).tobytes()
+    yield "binary", rng.integers(0, 256, 60000).astype(np.uint8).tobytes()
+    yield "small-alphabet", rng.choice(np.frombuffer(b"\x01\x02\x03", dtype=np.uint8), 5000).tobytes()
+    yield "cyrillic", "".join(chr(0x410 + int(k)) for k in rng.integers(0, 60, 3000)).encode("utf-8")
+    yield "bytes-1-199", bytes(range(1, 200)) * 30
+    yield "no-gain", (b"qzj xvk wpf " * 100)[:1100]                        # text by the statistics, nothing to replace: the output does not fit
+    yield "many-high-bytes", T.make_text(n // 4, seed=13, utf8=0.5)
+
+
+def check_text(be, n=200_000):
+    """TEXT transform objects (both stream formats: the entropy stage of the handle picks one, Factory.go:100-120) vs the oracle,
+    then TEXT inside streams: text, UTF-8, binary and magic-number blocks side by side, ctx["dataType"] handed to the UTF stage."""
+    import text_corpus as T
+    for entropy in ("ANS0", "ANS1"):
+        for bs in (4 << 20, 1 << 16):
+            c = K.Codec("NONE", entropy, bs, lib=be.lib)
+            t = K.ByteTransform(c, "TEXT")
+            applied = 0
+            for name, data in text_inputs(n):
+                O.set_ctx(bs, O.entropy_type(entropy))
+                o = O.transform_forward(O.T_TEXT, data)
+                g = t.forward(data)
+                assert (g is None) == (o is None), (entropy, bs, name)
+                if o is None:
+                    continue
+                assert g == o, (entropy, bs, name, len(g), len(o))
+                applied += 1
+                assert t.inverse(o, len(data) + 64) == data, (entropy, bs, name)
+            assert applied >= 11, applied
+            c.close()
+    bs = 1 << 16
+    rng = np.random.default_rng(9)
+    data = (T.make_text(bs, seed=21) + T.make_text(bs, seed=22, crlf=True) + rng.integers(0, 256, bs).astype(np.uint8).tobytes() +
+            T.make_text(bs, seed=23, utf8=0.3) + "".join(chr(0x410 + int(k)) for k in rng.integers(0, 60, bs // 2)).encode("utf-8") +
+            bytes([0x1F, 0x8B]) + T.make_text(bs - 2, seed=24) + b"MZ" + T.make_text(bs - 2, seed=25) + T.make_text(bs // 3 + 5, seed=26, markup=True))
+    for transform, entropy in (("TEXT", "NONE"), ("TEXT", "ANS1"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT+BWT+RANK+ZRLT", "ANS1"),
+                               ("TEXT+UTF", "HUFFMAN"), ("UTF+TEXT", "ANS0"), ("TEXT+TEXT", "FPAQ")):
+        exp = O.compress(data, transform, entropy, bs)
+        c = K.Codec(transform, entropy, bs, lib=be.lib)
+        src, ks = be.to_dev(data)
+        cap = 2 * len(data) + (1 << 20)
+        dst, kd = be.empty(cap)
+        nb = c.dev_compress(src, len(data), dst, cap)
+        assert be.to_host(kd, nb) == exp, (transform, entropy)
+        out, ko = be.empty(len(data) + 64)
+        assert c.dev_decompress(dst, nb, out, len(data) + 64) == len(data)
+        assert be.to_host(ko, len(data)) == data
+        c.close()
+    assert len(O.compress(data, "TEXT", "NONE", bs)) < len(data) - 50000
 
 
 def check_concurrent_handles(be, threads=8, rounds=3):

@@ -115,6 +115,10 @@ def test_utf_streams(be):
     P.check_utf_streams(be)
 
 
+def test_text_transform_and_streams(be):
+    P.check_text(be, n=60_000)
+
+
 def test_skip_blocks_option(be):
     P.check_skip_blocks(be, light=True)
 

@@ -262,6 +262,10 @@ def test_utf_streams(be):
     P.check_utf_streams(be)
 
 
+def test_text_transform_and_streams(be):
+    P.check_text(be)
+
+
 def test_skip_blocks_option(be):
     P.check_skip_blocks(be)
 
