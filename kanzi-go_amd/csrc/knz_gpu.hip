@@ -13,6 +13,7 @@
 #include "lz.hip"
 #include "srt_lzp.hip"
 #include "text.hip"
+#include "text_par.hip"
 #include "utf.hip"
 #include "xxhash.hip"
 #include "skip.hip"
@@ -233,10 +234,16 @@ extern "C" int knz_last_kernel_times(void* handle, char* names, int names_cap, f
 
 extern "C" int knz_last_counter(void* handle, int id, uint64_t* value) {
     Handle* h = (Handle*)handle;
-    if (!h || !value || (id != KNZ_COUNTER_HUF_SERIAL_CHUNKS && id != KNZ_COUNTER_POST_TRANSFORM_BYTES)) return KNZ_ERR_INVALID_PARAM;
+    if (!h || !value || (id != KNZ_COUNTER_HUF_SERIAL_CHUNKS && id != KNZ_COUNTER_POST_TRANSFORM_BYTES && id != KNZ_COUNTER_TEXT_CHAIN_BLOCKS)) return KNZ_ERR_INVALID_PARAM;
     DeviceGuard dg(h);
     *value = 0;
     if (id == KNZ_COUNTER_POST_TRANSFORM_BYTES) { *value = h->post_bytes; return KNZ_OK; }
+    if (id == KNZ_COUNTER_TEXT_CHAIN_BLOCKS) {
+        uint32_t v = 0;
+        if (h->text_cnt.p && hipMemcpy(&v, h->text_cnt.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return KNZ_ERR_UNKNOWN;
+        *value = v;
+        return KNZ_OK;
+    }
     if (h->huf_fallback_n == 0) return KNZ_OK;
     std::vector<uint8_t> f(h->huf_fallback_n);
     if (hipMemcpy(f.data(), h->huf_fallback.p, f.size(), hipMemcpyDeviceToHost) != hipSuccess) return KNZ_ERR_UNKNOWN;

@@ -32,6 +32,7 @@ struct TextArgs {
     uint32_t* ent;                 // [nblocks][3][2^19]: hash | length << 24 + index | text pointer
     const uint32_t* stat;          // static dictionary: hash[1024] | data[1024] | offset[1024] | letters (lower case)
     uint32_t log_hash, kind;       // kind 1 / 2 = the stream format
+    uint32_t* chain_count;         // blocks scanned by the one-lane kernels (diagnostic counter)
 };
 
 __device__ __forceinline__ bool knz_tc_is_text(uint32_t v) { v |= 0x20; return v >= 'a' && v <= 'z'; }     // :492-494
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(64) void knz_text_forward_chain_kernel(TextArgs a) 
     const int lane = threadIdx.x;
     if (!a.active[b]) return;
     const int mode = a.tmode[b];
+    if (mode == -3) return;                                              // done by the parallel kernel (text_par.hip)
     if (mode < 0) { if (lane == 0) { a.ok[b] = mode == -2 ? 1 : 0; a.out_len[b] = 0; } return; }
     const int count = (int)a.in_len[b];
     const uint8_t* src = (const uint8_t*)a.in_ptr[b];
@@ -329,6 +331,7 @@ __global__ __launch_bounds__(64) void knz_text_forward_chain_kernel(TextArgs a) 
     TextDict d;
     knz_tc_dict_reset(d, a, b, count, src, lane);
     if (lane != 0) return;
+    atomicAdd(a.chain_count, 1u);
     const uint32_t kind = a.kind;
     const bool crlf = (mode & 0x40) != 0;
     const int srcEnd = count, dstEnd = count, dstEndRef = kind == 1 ? dstEnd - 4 : dstEnd - 3;
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(64) void knz_text_forward_chain_kernel(TextArgs a) 
 __global__ __launch_bounds__(64) void knz_text_inverse_chain_kernel(TextArgs a) {
     const uint32_t b = blockIdx.x;
     const int lane = threadIdx.x;
-    if (!a.active[b]) return;
+    if (!a.active[b] || a.tmode[b] == -3) return;                        // (-3: done by the parallel kernel, text_par.hip)
     const int64_t srcEnd = (int64_t)a.in_len[b], dstEnd = (int64_t)a.out_cap;
     const uint8_t* src = (const uint8_t*)a.in_ptr[b];
     uint8_t* dst = (uint8_t*)a.out_ptr[b];
@@ -393,6 +396,7 @@ __global__ __launch_bounds__(64) void knz_text_inverse_chain_kernel(TextArgs a) 
     TextDict d;
     knz_tc_dict_reset(d, a, b, (int)(dstEnd > (1 << 30) ? (1 << 30) : dstEnd), src, lane);
     if (lane != 0) return;
+    atomicAdd(a.chain_count, 1u);
     const uint32_t kind = a.kind;
     const bool crlf = (src[0] & 0x40) != 0;
     bool wordRun = false, bad = false;

@@ -700,10 +700,13 @@ def text_inputs(n=200_000):
     yield "bytes-1-199", bytes(range(1, 200)) * 30
     yield "no-gain", (b"qzj xvk wpf " * 100)[:1100]                        # text by the statistics, nothing to replace: the output does not fit
     yield "many-high-bytes", T.make_text(n // 4, seed=13, utf8=0.5)
+    if n >= 200_000:                                                       # (GPU runs) more than 16384 words enter the dictionary: 3-letter words stop entering (:801)
+        import bench_corpus
+        yield "length-3-cut-off", bench_corpus._text(np.random.default_rng(1), 10 * n, dict_size=60000).tobytes()
 
 
-def check_text(be, n=200_000):
-    """TEXT transform objects (both stream formats: the entropy stage of the handle picks one, Factory.go:100-120) vs the oracle,
+def check_text(be, n=200_000, chain=False):
+    """(chain: the caller set KNZ_TEXT_CHAIN, the one-lane scan does the forward direction too.) TEXT transform objects (both stream formats: the entropy stage of the handle picks one, Factory.go:100-120) vs the oracle,
     then TEXT inside streams: text, UTF-8, binary and magic-number blocks side by side, ctx["dataType"] handed to the UTF stage."""
     import text_corpus as T
     for entropy in ("ANS0", "ANS1"):
@@ -719,8 +722,10 @@ def check_text(be, n=200_000):
                 if o is None:
                     continue
                 assert g == o, (entropy, bs, name, len(g), len(o))
+                assert c.last_counter(2) == (1 if chain else 0), (entropy, bs, name)       # the parallel kernel settled (or was not asked)
                 applied += 1
                 assert t.inverse(o, len(data) + 64) == data, (entropy, bs, name)
+                assert c.last_counter(2) == (1 if chain else 0), (entropy, bs, name, "inverse")
             assert applied >= 11, applied
             c.close()
     bs = 1 << 16
@@ -742,6 +747,51 @@ def check_text(be, n=200_000):
         assert be.to_host(ko, len(data)) == data
         c.close()
     assert len(O.compress(data, "TEXT", "NONE", bs)) < len(data) - 50000
+
+
+def check_text_damaged(be, trials=60, n=20_000, seed=1):
+    """TEXT inverse on damaged input: byte flips, truncations and spliced index bytes in valid encodings. Whatever the reference's scan does
+    with them (fail, or decode to something else) both device paths must do as well: same bytes or an error where the oracle fails."""
+    import text_corpus as T
+    rng = np.random.default_rng(seed)
+    for entropy in ("ANS0", "ANS1"):
+        bs = 1 << 16
+        c = K.Codec("NONE", entropy, bs, lib=be.lib)
+        t = K.ByteTransform(c, "TEXT")
+        base = T.make_text(n, seed=seed + 40, escapes=0.01, utf8=0.02, crlf=True)
+        O.set_ctx(bs, O.entropy_type(entropy))
+        good = O.transform_forward(O.T_TEXT, base)
+        assert good is not None
+        for k in range(trials):
+            d = bytearray(good)
+            kind = k % 5
+            if kind == 0:
+                for _ in range(int(rng.integers(1, 4))):
+                    d[int(rng.integers(0, len(d)))] = int(rng.integers(0, 256))
+            elif kind == 1:
+                d = d[: int(rng.integers(2, len(d)))]
+            elif kind == 2:                                                # a run of index-like bytes dropped in
+                p = int(rng.integers(1, len(d)))
+                d[p:p] = bytes(int(v) for v in rng.choice([0x0F, 0x0E, 0x80, 0xC1, 0xF3, 0x41, 0x20, 0x7F, 0xFF], int(rng.integers(1, 6))))
+            elif kind == 3:                                                # a reference to an entry far ahead of the dictionary
+                p = int(rng.integers(1, len(d) - 4))
+                d[p:p + 3] = bytes([0x0F, 0xE1, 0x85]) if entropy == "ANS1" else bytes([0xF1, 0x20, 0x33])
+            else:
+                p, q = sorted(int(v) for v in rng.integers(1, len(d), 2))
+                d = d[:p] + d[q:]
+            d = bytes(d)
+            cap = len(base) + 4096
+            O.set_ctx(bs, O.entropy_type(entropy))
+            try:
+                exp = O.transform_inverse(O.T_TEXT, d, cap)
+            except O.OracleError:
+                exp = None
+            try:
+                got = t.inverse(d, cap)
+            except K.KnzError:
+                got = None
+            assert got == exp, (entropy, k, kind, None if exp is None else len(exp), None if got is None else len(got))
+        c.close()
 
 
 def check_concurrent_handles(be, threads=8, rounds=3):

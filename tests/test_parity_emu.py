@@ -119,6 +119,17 @@ def test_text_transform_and_streams(be):
     P.check_text(be, n=60_000)
 
 
+def test_text_damaged_input(be, monkeypatch):
+    P.check_text_damaged(be, trials=40, n=8000)
+    monkeypatch.setenv("KNZ_TEXT_CHAIN", "1")
+    P.check_text_damaged(be, trials=40, n=8000, seed=2)
+
+
+def test_text_one_lane_scan(be, monkeypatch):
+    monkeypatch.setenv("KNZ_TEXT_CHAIN", "1")
+    P.check_text(be, n=30_000, chain=True)
+
+
 def test_skip_blocks_option(be):
     P.check_skip_blocks(be, light=True)
 

@@ -266,6 +266,44 @@ def test_text_transform_and_streams(be):
     P.check_text(be)
 
 
+def test_text_dictionary_wrap(be):
+    K, O = P.K, P.O
+    """More than 2^19 distinct words in one block: the dictionary wraps and recycles its oldest entries (TextCodec.go:816-821). The parallel
+    kernel hands such a block to the one-lane scan (counter == 1); both directions against the oracle."""
+    rng = np.random.default_rng(3)
+    nwords = 700_000
+    lens = rng.integers(4, 9, nwords)
+    letters = rng.integers(0, 26, int(lens.sum())).astype(np.uint8) + ord("a")
+    out = np.full(int(lens.sum()) + nwords, ord(" "), dtype=np.uint8)
+    starts = np.concatenate(([0], np.cumsum(lens + 1)[:-1]))
+    idx = np.repeat(starts, lens) + (np.arange(int(lens.sum())) - np.repeat(np.concatenate(([0], np.cumsum(lens)[:-1])), lens))
+    out[idx] = letters
+    data = out.tobytes() + (out[: 1 << 20].tobytes())                     # then a stretch of repeats: references into the wrapped dictionary
+    bs = 8 << 20
+    assert len(data) <= bs
+    for entropy in ("ANS0", "ANS1"):
+        c = K.Codec("NONE", entropy, bs, lib=be.lib)
+        t = K.ByteTransform(c, "TEXT")
+        O.set_ctx(bs, O.entropy_type(entropy))
+        o = O.transform_forward(O.T_TEXT, data)
+        g = t.forward(data)
+        assert o is not None and g == o
+        assert c.last_counter(2) == 1
+        assert t.inverse(o, len(data) + 64) == data
+        c.close()
+
+
+def test_text_damaged_input(be, monkeypatch):
+    P.check_text_damaged(be, trials=150)
+    monkeypatch.setenv("KNZ_TEXT_CHAIN", "1")
+    P.check_text_damaged(be, trials=150, seed=2)
+
+
+def test_text_one_lane_scan(be, monkeypatch):
+    monkeypatch.setenv("KNZ_TEXT_CHAIN", "1")
+    P.check_text(be, n=100_000, chain=True)
+
+
 def test_skip_blocks_option(be):
     P.check_skip_blocks(be)
 
