@@ -37,6 +37,7 @@ struct LzArgs {
     uint8_t* tk; uint8_t* mb; uint8_t* ml;     // [nblocks * buf_stride] each
     uint64_t buf_stride;
     uint32_t extra;             // 1 = LZX
+    const uint8_t* blk_dt;      // [nblocks] ctx["dataType"] (text.hip numbering) or null: DNA = min match 6, small alphabet = skip (:298-311)
 };
 
 // unaligned little-endian loads composed of byte loads (wave-uniform addresses: one transaction each)
@@ -118,7 +119,9 @@ __global__ __launch_bounds__(64) void knz_lz_forward_kernel(LzArgs a) {
     int maxDist = KNZ_LZ_MAX_DIST2;
     uint32_t flag = 1;
     if (srcEnd < 4 * KNZ_LZ_MAX_DIST1) { maxDist = KNZ_LZ_MAX_DIST1; flag = 0; }
-    const int minMatch = 4;
+    const uint32_t dt = a.blk_dt ? a.blk_dt[b] : 0u;
+    if (dt == 9u /* DT_SMALL_ALPHABET */) { if (writer) { a.ok[b] = 0; a.out_len[b] = 0; } return; }
+    const int minMatch = dt == 6u /* DT_DNA */ ? 6 : 4;
     flag |= ((minMatch - 2) & 7) << 1;
     if (writer) dst[12] = (uint8_t)flag;
     int srcIdx = 0, dstIdx = 13, anchor = 0, mLenIdx = 0, mIdx = 0, tkIdx = 0;

@@ -415,7 +415,7 @@ static inline int lzFindMatch(const uint8_t* src, int srcIdx, int ref, int maxMa
     return bestLen;
 }
 
-// :249-591. dataType: 0 = none ; (DT_DNA / DT_SMALL_ALPHABET are never set on the hot path)
+// :249-591. ctx["dataType"]: DT_DNA (min match 6) and DT_SMALL_ALPHABET (skip) are only ever set by a TEXT stage in front
 static inline size_t lzForward(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap, bool extra) {
     if (n == 0 || dstCap == 0) return 0;
     int count = (int)n;
@@ -434,6 +434,8 @@ static inline size_t lzForward(const uint8_t* src, size_t n, uint8_t* dst, size_
     dst[12] = 1;
     if (srcEnd < 4 * LZX_MAX_DISTANCE1) { maxDist = LZX_MAX_DISTANCE1; dst[12] = 0; }
     int minMatch = 4;
+    if (tlsDataType == DT_DNA) minMatch = 6;                                // :298-311: ctx["dataType"] as a TEXT stage in front left it
+    else if (tlsDataType == DT_SMALL_ALPHABET) throw SkipTransform("LZCodec forward transform skip: Small alphabet");
     dst[12] |= (uint8_t)(((minMatch - 2) & 0x07) << 1);
     int srcIdx = 0, dstIdx = 13, anchor = 0, mLenIdx = 0, mIdx = 0, tkIdx = 0;
     int repd[2] = {count, count};

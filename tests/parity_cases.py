@@ -705,12 +705,16 @@ def text_inputs(n=200_000):
         yield "length-3-cut-off", bench_corpus._text(np.random.default_rng(1), 10 * n, dict_size=60000).tobytes()
 
 
-def check_text(be, n=200_000, chain=False):
+TEXT_STREAMS = (("TEXT", "NONE"), ("TEXT", "ANS1"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT+BWT+RANK+ZRLT", "ANS1"), ("TEXT+UTF", "HUFFMAN"),
+                ("UTF+TEXT", "ANS0"), ("TEXT+TEXT", "FPAQ"))
+
+
+def check_text(be, n=200_000, chain=False, streams=TEXT_STREAMS, bs_stream=1 << 16):
     """(chain: the caller set KNZ_TEXT_CHAIN, the one-lane scan does the forward direction too.) TEXT transform objects (both stream formats: the entropy stage of the handle picks one, Factory.go:100-120) vs the oracle,
     then TEXT inside streams: text, UTF-8, binary and magic-number blocks side by side, ctx["dataType"] handed to the UTF stage."""
     import text_corpus as T
-    for entropy in ("ANS0", "ANS1"):
-        for bs in (4 << 20, 1 << 16):
+    for entropy, bs in (("ANS0", 4 << 20), ("ANS1", 4 << 20), ("ANS0", 1 << 16), ("ANS1", 1 << 16))[: 4 if n >= 200_000 else 3]:
+        if True:
             c = K.Codec("NONE", entropy, bs, lib=be.lib)
             t = K.ByteTransform(c, "TEXT")
             applied = 0
@@ -728,13 +732,14 @@ def check_text(be, n=200_000, chain=False):
                 assert c.last_counter(2) == (1 if chain else 0), (entropy, bs, name, "inverse")
             assert applied >= 11, applied
             c.close()
-    bs = 1 << 16
+    if not streams:
+        return
+    bs = bs_stream
     rng = np.random.default_rng(9)
     data = (T.make_text(bs, seed=21) + T.make_text(bs, seed=22, crlf=True) + rng.integers(0, 256, bs).astype(np.uint8).tobytes() +
             T.make_text(bs, seed=23, utf8=0.3) + "".join(chr(0x410 + int(k)) for k in rng.integers(0, 60, bs // 2)).encode("utf-8") +
             bytes([0x1F, 0x8B]) + T.make_text(bs - 2, seed=24) + b"MZ" + T.make_text(bs - 2, seed=25) + T.make_text(bs // 3 + 5, seed=26, markup=True))
-    for transform, entropy in (("TEXT", "NONE"), ("TEXT", "ANS1"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT+BWT+RANK+ZRLT", "ANS1"),
-                               ("TEXT+UTF", "HUFFMAN"), ("UTF+TEXT", "ANS0"), ("TEXT+TEXT", "FPAQ")):
+    for transform, entropy in streams:
         exp = O.compress(data, transform, entropy, bs)
         c = K.Codec(transform, entropy, bs, lib=be.lib)
         src, ks = be.to_dev(data)
@@ -746,7 +751,24 @@ def check_text(be, n=200_000, chain=False):
         assert c.dev_decompress(dst, nb, out, len(data) + 64) == len(data)
         assert be.to_host(ko, len(data)) == data
         c.close()
-    assert len(O.compress(data, "TEXT", "NONE", bs)) < len(data) - 50000
+    assert len(O.compress(data, "TEXT", "NONE", bs)) < len(data) - 3 * bs // 4
+    # the data type a TEXT stage detects reaches an LZ stage behind it (LZCodec.go:298-311): DNA = minimum match 6, small alphabet = LZ declines
+    dna = rng.choice(np.frombuffer(b"acgt", dtype=np.uint8), bs).tobytes()
+    dna = dna[: bs // 2] + dna[: bs // 2]
+    small = rng.choice(np.frombuffer(b"\x01\x02\x03", dtype=np.uint8), bs).tobytes()
+    data2 = dna + small + T.make_text(bs // 2, seed=27)
+    for transform, entropy in (("TEXT+LZ", "HUFFMAN"), ("TEXT+LZX", "ANS0")):
+        exp = O.compress(data2, transform, entropy, bs)
+        c = K.Codec(transform, entropy, bs, lib=be.lib)
+        src, ks = be.to_dev(data2)
+        cap = 2 * len(data2) + (1 << 20)
+        dst, kd = be.empty(cap)
+        nb = c.dev_compress(src, len(data2), dst, cap)
+        assert be.to_host(kd, nb) == exp, (transform, entropy)
+        out, ko = be.empty(len(data2) + 64)
+        assert c.dev_decompress(dst, nb, out, len(data2) + 64) == len(data2)
+        assert be.to_host(ko, len(data2)) == data2
+        c.close()
 
 
 def check_text_damaged(be, trials=60, n=20_000, seed=1):

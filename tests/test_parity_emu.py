@@ -116,7 +116,8 @@ def test_utf_streams(be):
 
 
 def test_text_transform_and_streams(be):
-    P.check_text(be, n=60_000)
+    P.check_text(be, n=40_000, bs_stream=1 << 14,
+                 streams=(("TEXT", "NONE"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT+UTF", "HUFFMAN"), ("UTF+TEXT", "ANS1"), ("TEXT+TEXT", "FPAQ")))
 
 
 def test_text_damaged_input(be, monkeypatch):
@@ -127,7 +128,7 @@ def test_text_damaged_input(be, monkeypatch):
 
 def test_text_one_lane_scan(be, monkeypatch):
     monkeypatch.setenv("KNZ_TEXT_CHAIN", "1")
-    P.check_text(be, n=30_000, chain=True)
+    P.check_text(be, n=12_000, chain=True, streams=())
 
 
 def test_skip_blocks_option(be):

@@ -271,7 +271,7 @@ def test_text_dictionary_wrap(be):
     """More than 2^19 distinct words in one block: the dictionary wraps and recycles its oldest entries (TextCodec.go:816-821). The parallel
     kernel hands such a block to the one-lane scan (counter == 1); both directions against the oracle."""
     rng = np.random.default_rng(3)
-    nwords = 700_000
+    nwords = 1_500_000
     lens = rng.integers(4, 9, nwords)
     letters = rng.integers(0, 26, int(lens.sum())).astype(np.uint8) + ord("a")
     out = np.full(int(lens.sum()) + nwords, ord(" "), dtype=np.uint8)
@@ -279,7 +279,7 @@ def test_text_dictionary_wrap(be):
     idx = np.repeat(starts, lens) + (np.arange(int(lens.sum())) - np.repeat(np.concatenate(([0], np.cumsum(lens)[:-1])), lens))
     out[idx] = letters
     data = out.tobytes() + (out[: 1 << 20].tobytes())                     # then a stretch of repeats: references into the wrapped dictionary
-    bs = 8 << 20
+    bs = 32 << 20                                                           # (2^20 / 2^22 hash slots: room for more than 2^19 entries)
     assert len(data) <= bs
     for entropy in ("ANS0", "ANS1"):
         c = K.Codec("NONE", entropy, bs, lib=be.lib)

@@ -1,5 +1,6 @@
 """Synthetic text for the TEXT transform's parity cases: sentences over the static dictionary's words plus a Zipf vocabulary of made-up words,
 capitalised sentence starts, punctuation, numbers, LF or CR+LF line ends, optional UTF-8 letters, markup and the codec's own escape bytes."""
+import functools
 import json
 import os
 import re
@@ -9,11 +10,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+@functools.lru_cache(maxsize=None)
 def static_words():
     letters = json.load(open(os.path.join(_HERE, "golden", "reference_constants.json")))["text_codec"]["static_dictionary_letters"]
     return [w.lower() for w in re.findall(r"[A-Z][a-z]*", letters)]
 
 
+@functools.lru_cache(maxsize=256)
 def make_text(n, seed=0, vocab=4000, crlf=False, utf8=0.0, markup=False, escapes=0.0, upper=0.08, max_word=14, static_share=0.5):
     rng = np.random.default_rng(seed)
     sw = static_words()
