@@ -301,7 +301,7 @@ __device__ __forceinline__ uint32_t knz_ts_next(uint32_t kind, uint32_t s, uint3
 // the byte at q (state st in front of it) is the last byte of a reference to a WORD (an entry longer than one letter)
 __device__ __forceinline__ bool knz_ts_word_ref_end(uint32_t kind, const uint8_t* src, const uint8_t* st, int q) {
     if (q < 1) return false;
-    const uint32_t s = st[q], c = src[q];
+    const uint32_t s = st[q] & 7u, c = src[q];
     if (kind == 1) {
         if (s == 1) return c < 128;                                         // one index byte: a static word
         uint32_t idx;
@@ -314,12 +314,34 @@ __device__ __forceinline__ bool knz_ts_word_ref_end(uint32_t kind, const uint8_t
     if (s == KNZ_TS_F) return (c & 0x7F) < 64;
     return s == KNZ_TS_N && c > 0x80 && (c & 0x7F) < 64;
 }
+// what the byte at p (state s in front of it) does to the decoder's wordRun flag (:1062-1075, :1093): 1 = it ends a reference to a word
+// (the flag is set), 2 = it is or ends an item that clears the flag (a literal that is not a letter, an escaped literal, a reference to a
+// one-letter escape entry), 0 = nothing (letters leave the flag alone; so do bytes inside an item)
+__device__ __forceinline__ uint32_t knz_ts_event(uint32_t kind, const uint8_t* src, uint32_t s, uint32_t c, int p) {
+    if (kind == 1) {
+        if (s == 0) return (c == 0x0F || c == 0x0E || knz_tc_is_text(c)) ? 0u : 2u;
+        if (s == 1) return c < 128 ? 1u : 0u;
+        uint32_t idx;
+        if (s == 2) { if (c >= 128) return 0u; idx = (((uint32_t)src[p - 1] & 0x7F) << 7) | c; }
+        else idx = (((((uint32_t)src[p - 2] & 0x1F) << 7) | ((uint32_t)src[p - 1] & 0x7F)) << 7) | c;
+        return (idx == KNZ_TC_STATIC || idx == KNZ_TC_STATIC + 1) ? 2u : 1u;
+    }
+    if (s == KNZ_TS_N) {
+        if (c == 0x80 || c == 0x0F) return 0u;
+        if (c > 0x80) return (c & 0x7F) < 64 ? 1u : 0u;
+        return knz_tc_is_text(c) ? 0u : 2u;
+    }
+    if (s == KNZ_TS_F) return (c & 0x7F) < 64 ? 1u : 0u;
+    if (s == KNZ_TS_I1) return 1u;
+    if (s == KNZ_TS_E) return 2u;
+    return 0u;
+}
 // literal word in front of the literal delimiter at e (:983-986): its length (0 = none) and where its letters start
 __device__ __forceinline__ int knz_tsp_word_len(uint32_t kind, const uint8_t* src, const uint8_t* st, int e, int& start) {
     const uint32_t c = src[e];
-    if (st[e] != KNZ_TS_N || knz_tc_is_text(c) || !knz_tc_is_delim(c)) return 0;
+    if ((st[e] & 7u) != KNZ_TS_N || knz_tc_is_text(c) || !knz_tc_is_delim(c)) return 0;
     int a = e;
-    while (a > 1 && e - a <= 32 && st[a - 1] == KNZ_TS_N && knz_tc_is_text(src[a - 1])) a--;
+    while (a > 1 && e - a <= 32 && (st[a - 1] & 7u) == KNZ_TS_N && knz_tc_is_text(src[a - 1])) a--;
     if (knz_ts_word_ref_end(kind, src, st, a - 1)) a++;                     // delimAnchor sits one byte behind a word reference (:1070)
     const int len = e - a;
     start = a;
@@ -375,9 +397,26 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_inverse_par_kernel(T
         if (s != KNZ_TS_N) s_flag = 1;                                       // the block ends inside an item
     }
     __syncthreads();
+    {   // wordRun in front of every byte: the last setter / clearer wins, letters pass it on (so it can reach across any number of them)
+        uint32_t s = s_start[tid], ev = 0;
+        for (int p = lo; p < hi; p++) { const uint32_t c = src[p]; const uint32_t e = knz_ts_event(kind, src, s, c, p); ev = e ? e : ev; s = knz_ts_next(kind, s, c); }
+        s_map[tid] = (uint16_t)ev;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t wr = 0;
+        for (int i = 0; i < KNZ_TCP_THREADS; i++) { const uint32_t ev = s_map[i]; s_start[i] = (uint8_t)(s_start[i] | (wr << 3)); wr = ev ? (ev == 1 ? 1u : 0u) : wr; }
+    }
+    __syncthreads();
     {
-        uint32_t s = s_start[tid];
-        for (int p = lo; p < hi; p++) { st[p] = (uint8_t)s; s = knz_ts_next(kind, s, src[p]); }
+        uint32_t s = s_start[tid] & 7u, wr = s_start[tid] >> 3;
+        for (int p = lo; p < hi; p++) {
+            const uint32_t c = src[p];
+            st[p] = (uint8_t)(s | (wr << 3));
+            const uint32_t e = knz_ts_event(kind, src, s, c, p);
+            wr = e ? (e == 1 ? 1u : 0u) : wr;
+            s = knz_ts_next(kind, s, c);
+        }
         if (tid == 0) st[0] = 7;
     }
     __syncthreads();
@@ -464,7 +503,7 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_inverse_par_kernel(T
             const int p = p0 + j;
             il[j] = 0; iw[j] = 0;
             if (p < 1 || p >= m) continue;
-            const uint32_t s = st[p], c = src[p];
+            const uint32_t s = st[p] & 7u, c = src[p];
             int lead = -1;                                                     // position of the first index byte of a reference anchored here
             uint32_t flip = 0;
             int first = p;                                                     // first byte of the item
@@ -502,7 +541,7 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_inverse_par_kernel(T
                 if ((int)k.h2[tk] < first) { code = 0x100000u + tk; n = k.len[tk]; }
             }
             if (code == 0xFFFFFFFFu) { bad = true; continue; }
-            const uint32_t sp = (n > 1 && knz_ts_word_ref_end(kind, src, st, first - 1)) ? 1u : 0u;
+            const uint32_t sp = (n > 1 && (st[first] >> 3) != 0) ? 1u : 0u;    // wordRun when the item starts
             il[j] = (uint32_t)n + sp;
             iw[j] = 0x80000000u | (flip << 30) | (sp << 29) | code;
         }
@@ -512,7 +551,7 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_inverse_par_kernel(T
         for (int j = 0; j < 4; j++) {
             const int p = p0 + j;
             if (p < 1 || p >= m) continue;
-            const uint32_t s = st[p], c = src[p];
+            const uint32_t s = st[p] & 7u, c = src[p];
             if (s == KNZ_TS_N && (int64_t)o >= dstEnd) { bad = true; o += il[j]; continue; }   // a loop iteration starts here: the scan stops at a full buffer with input left
             if (il[j] == 0) continue;
             if (iw[j]) {

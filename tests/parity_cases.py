@@ -786,8 +786,12 @@ def check_text_damaged(be, trials=60, n=20_000, seed=1):
         assert good is not None
         for k in range(trials):
             d = bytearray(good)
-            kind = k % 5
-            if kind == 0:
+            kind = k % 6
+            if kind == 5:                                                  # letters where delimiters were: the implied-space flag runs across letters
+                for _ in range(int(rng.integers(1, 6))):
+                    cand = [i for i in range(1, len(d)) if d[i] in b" _,.;-"]
+                    d[cand[int(rng.integers(0, len(cand)))]] = ord("C")
+            elif kind == 0:
                 for _ in range(int(rng.integers(1, 4))):
                     d[int(rng.integers(0, len(d)))] = int(rng.integers(0, 256))
             elif kind == 1:
