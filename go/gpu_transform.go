@@ -1,7 +1,7 @@
 // gpu_transform.go — goes into github.com/flanglet/kanzi-go/v2/transform.
 //
 // A kanzi.ByteTransform (v2/Definitions.go:78-91) backed by knz_transform_forward / knz_transform_inverse of
-// libknz_gpu.so for the transforms of the hot path: BWT (block codec form), RANK, MTFT, ZRLT, LZ, LZX, LZP, SRT, UTF.
+// libknz_gpu.so for the transforms of the hot path: BWT (block codec form), RANK, MTFT, ZRLT, LZ, LZX, LZP, SRT, UTF, TEXT (DICT_TYPE).
 // transform.New (Factory.go:97-185) returns it for those ids when a GPU handle is present in the context.
 package transform
 
