@@ -885,7 +885,11 @@ def check_skip_blocks(be, light=False):
 
 
 def _fuzz_data(r, n):
-    kind = int(r.integers(0, 10))
+    kind = int(r.integers(0, 12))
+    if kind >= 10:                                   # English-like text (TEXT territory): capitals, CR+LF, markup, escapes, UTF-8 letters
+        import text_corpus as T
+        return T.make_text(n, seed=int(r.integers(0, 1 << 30)), crlf=bool(r.integers(0, 2)), utf8=[0.0, 0.03][int(r.integers(0, 2))],
+                           markup=bool(r.integers(0, 2)), escapes=[0.0, 0.01][int(r.integers(0, 2))], vocab=int(r.integers(50, 3000)))
     if kind >= 8:                                    # UTF-8 text (Cyrillic / CJK / emoji / ASCII words), sometimes cut inside a code point
         kinds = [(1,), (1, 1, 0), (2,), (3, 1), (0, 1, 2, 3)][int(r.integers(0, 5))]
         t = utf_text(n + 3, int(r.integers(0, 1 << 30)), kinds)
@@ -923,7 +927,7 @@ def check_fuzz(be, cases, seed, max_n, heavy_max_n=None):
     """Seeded differential test: random transform sequences x entropy codecs x block sizes x checksum sizes x data shapes,
     device stream == oracle stream, the device decodes the oracle's stream, the oracle decodes the device's."""
     r = np.random.default_rng(seed)
-    tnames = ["NONE", "BWT", "RANK", "MTFT", "ZRLT", "LZ", "LZX", "LZP", "SRT", "UTF"]
+    tnames = ["NONE", "BWT", "RANK", "MTFT", "ZRLT", "LZ", "LZX", "LZP", "SRT", "UTF", "TEXT"]
     enames = ["NONE", "HUFFMAN", "ANS0", "ANS1", "FPAQ"]
     heavy = {"BWT", "RANK", "MTFT", "SRT"}          # slow on the emulator (cross-lane heavy): smaller inputs there
     done = 0
