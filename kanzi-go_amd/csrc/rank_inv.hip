@@ -237,13 +237,15 @@ struct RankChainV {
     // lane 0 from lane 63 of the register below. Registers above r's are not touched.
     template <int K>
     __device__ __forceinline__ void high_reg(uint32_t r, int vqc, uint32_t vnew, uint32_t vi) {
-        uint32_t es = wave_shr1(e[K]), ps = PACKED ? 0u : wave_shr1(p[K]);
-        int qs = (int)wave_shr1((uint32_t)q[K]);
+        // the lane-1 copy of register K: lanes 1..63 from K itself, lane 0 from lane 63 of register K-1 (a rotate of K-1 puts it there:
+        // two DPP moves, no v_readlane / v_writelane pair with its SGPR in between)
+        uint32_t es, ps = 0u;
+        int qs;
         if (K > 0) {
-            es = wave_writelane0(es, wave_bcast(e[K > 0 ? K - 1 : 0], 63));
-            if (!PACKED) ps = wave_writelane0(ps, wave_bcast(p[K > 0 ? K - 1 : 0], 63));
-            qs = (int)wave_writelane0((uint32_t)qs, wave_bcast((uint32_t)q[K > 0 ? K - 1 : 0], 63));
-        } else qs = qp;                                                           // register 0: the maintained copy (lane 0 = +inf)
+            es = wave_shr1_keep0(wave_ror1(e[K > 0 ? K - 1 : 0]), e[K]);
+            if (!PACKED) ps = wave_shr1_keep0(wave_ror1(p[K > 0 ? K - 1 : 0]), p[K]);
+            qs = (int)wave_shr1_keep0(wave_ror1((uint32_t)q[K > 0 ? K - 1 : 0]), (uint32_t)q[K]);
+        } else { es = ep; ps = pp; qs = qp; }                                      // register 0: the maintained copies (q: lane 0 = +inf)
         const int qx = (int)wave_in_vgpr(64u * K + (uint32_t)lane > r ? 0x7FFFFFFFu : (uint32_t)q[K]);
         const bool keep = qx > vqc, ins = qs > vqc;
         e[K] = keep ? e[K] : (ins ? vnew : es);
@@ -279,6 +281,7 @@ struct RankChainV {
     // word W (0..3) of a group that holds ranks >= 64, first symbol at time i: one dispatch per symbol; symbols go to lanes 4W .. 4W+3 of ob
     template <int W>
     __device__ __forceinline__ void word_any(uint32_t w, uint32_t i, uint32_t& ob) {
+        if ((w & 0xC0C0C0C0u) == 0) { word<W>(w, i, ob); return; }               // a clean word inside the group: no per-symbol dispatch
         if (w == 0) {
             const uint32_t s = run_top(i + 3, 4);
             ob = wave_writelane_c<4 * W>(ob, s); ob = wave_writelane_c<4 * W + 1>(ob, s);
@@ -326,7 +329,7 @@ __device__ __forceinline__ void knz_rank_chain_block_v(const uint8_t* src, uint8
             uint32_t ob = 0;
             const uint32_t any = cur.x | cur.y | cur.z | cur.w;
             if (any == 0) ob = c.run_top(i + 15, 16);
-            else if (any & 0xC0C0C0C0u) {                                        // ranks >= 64 in the group: one dispatch per symbol
+            else if (any & 0xC0C0C0C0u) {                                        // ranks >= 64 in the group: words without one take the clean body
                 c.template word_any<0>(cur.x, i, ob); c.template word_any<1>(cur.y, i + 4, ob);
                 c.template word_any<2>(cur.z, i + 8, ob); c.template word_any<3>(cur.w, i + 12, ob);
             } else {

@@ -30,6 +30,8 @@ __device__ __forceinline__ void wave_sync() {
 }
 // value of lane-1 (lane 0 reads 0): one DPP move, no LDS crossbar
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xF, 0xF, true); }
+// value of lane-1, lane 0 reads lane 63 (DPP wave_ror:1)
+__device__ __forceinline__ uint32_t wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x13C, 0xF, 0xF, true); }
 // value of lane+1 (lane 63 reads 0)
 __device__ __forceinline__ uint32_t wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xF, 0xF, true); }
 // v with lane 0 replaced by the wave-uniform value `val`: v_writelane_b32 (one SGPR + an inline-constant lane select)
@@ -123,6 +125,7 @@ inline uint32_t wave_readlane(uint32_t v, uint32_t src) { return wave_shfl(v, (i
 inline void wave_sync() { hipemu::wave_barrier(); }
 inline void wave_sync_lds() { hipemu::wave_barrier(); }
 inline uint32_t wave_shr1(uint32_t v) { const uint32_t r = wave_shfl(v, hipemu::lane() - 1); return hipemu::lane() == 0 ? 0u : r; }
+inline uint32_t wave_ror1(uint32_t v) { return wave_shfl(v, (hipemu::lane() + 63) & 63); }
 inline uint32_t wave_writelane0(uint32_t v, uint32_t val) { return hipemu::lane() == 0 ? val : v; }
 inline uint32_t wave_shl1(uint32_t v) { const uint32_t r = wave_shfl(v, hipemu::lane() + 1); return hipemu::lane() == 63 ? 0u : r; }
 inline uint32_t wave_shr1_old(uint32_t v, uint32_t old) { const uint32_t r = wave_shfl(v, hipemu::lane() - 1); return hipemu::lane() == 0 ? old : r; }
