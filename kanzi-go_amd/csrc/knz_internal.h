@@ -37,7 +37,7 @@ struct Handle {
     DevBuf stage_in, stage_out;       // host-pointer entry points stage through these
     DevBuf dec_tables;                // decoder per-chunk positions
     DevBuf utf_map, utf_syms, utf_ranks, utf_inv, utf_bits, blk_dt;   // UTF codec: alias table / code points / ranks / inverse map / walk bitmap, ctx["dataType"] per block
-    DevBuf text_tok, text_pos, text_instok, text_cnt;                           // parallel TEXT: per-token arrays, per-position marks, entry -> token
+    DevBuf text_tok, text_pos, text_instok, text_cnt, text_prof;                           // parallel TEXT: per-token arrays, per-position marks, entry -> token
     DevBuf text_map, text_ent, text_stat, text_mode;                  // TEXT codec: hash tables, dictionary entries, static dictionary (uploaded once), mode bytes
     bool text_stat_ready = false;
     DevBuf srt_tab, srt_tmp, srt_ptrs;                               // parallel SRT forward: per-block tables, MTFT ranks, pointer / dummy arrays

@@ -1,17 +1,22 @@
-// Device-wide sort / scan / select primitives used by the suffix sort and the inverse BWT.
-// On the GPU these are rocPRIM's (ROCm's device-wide primitives library, header-only, compiled by hipcc for gfx950);
-// everything BWT-specific around them is hand-written in bwt.hip. Under the execution-model emulator (tests/emu,
-// CPU container, test infrastructure only) the same entry points are served by plain loops over host memory.
+// Device-wide sort / scan / select primitives used by the suffix sort and the inverse BWT: the hand-written kernels of prims.hip.
+// KNZ_PRIMS=rocprim routes the same entry points to rocPRIM's (ROCm's device primitives library) for A/B timing only. Under the
+// execution-model emulator (tests/emu, CPU container, test infrastructure only) the entry points are served by plain loops over host
+// memory unless KNZ_EMU_PRIMS=kernels asks for the real kernels (one dedicated test: the loops keep the BWT cases of the CPU suite fast).
 #pragma once
 #include "knz_internal.h"
+#include "prims.hip"
 
 #ifndef KNZ_HIP_EMU
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
+static inline bool knz_prims_rocprim() { static const bool v = getenv("KNZ_PRIMS") != nullptr && strcmp(getenv("KNZ_PRIMS"), "rocprim") == 0; return v; }
+
+// (kin, vin) are scratch: clobbered. The result is in (kout, vout).
 static inline int knz_sort_pairs_u64(DevBuf& tmp, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
                                      unsigned b0, unsigned b1, hipStream_t st) {
     if (n == 0) return 0;
+    if (!knz_prims_rocprim()) return knz_own_sort_pairs<uint64_t>(tmp, kin, kout, vin, vout, n, b0, b1, st);
     size_t bytes = 0;
     if (rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, b0, b1, st) != hipSuccess) return -1;
     if (tmp.reserve(bytes + 256)) return -1;
@@ -20,6 +25,7 @@ static inline int knz_sort_pairs_u64(DevBuf& tmp, uint64_t* kin, uint64_t* kout,
 static inline int knz_sort_pairs_u32(DevBuf& tmp, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
                                      unsigned b0, unsigned b1, hipStream_t st) {
     if (n == 0) return 0;
+    if (!knz_prims_rocprim()) return knz_own_sort_pairs<uint32_t>(tmp, kin, kout, vin, vout, n, b0, b1, st);
     size_t bytes = 0;
     if (rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, b0, b1, st) != hipSuccess) return -1;
     if (tmp.reserve(bytes + 256)) return -1;
@@ -27,6 +33,7 @@ static inline int knz_sort_pairs_u32(DevBuf& tmp, uint32_t* kin, uint32_t* kout,
 }
 static inline int knz_scan_max_u32(DevBuf& tmp, uint32_t* in, uint32_t* out, size_t n, hipStream_t st) {
     if (n == 0) return 0;
+    if (!knz_prims_rocprim()) return knz_own_scan_max_u32(tmp, in, out, n, st);
     size_t bytes = 0;
     if (rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::maximum<uint32_t>(), st) != hipSuccess) return -1;
     if (tmp.reserve(bytes + 256)) return -1;
@@ -35,6 +42,7 @@ static inline int knz_scan_max_u32(DevBuf& tmp, uint32_t* in, uint32_t* out, siz
 // out_idx[k] = k-th index i in [0,n) with flags[i] != 0 ; *d_count = number selected
 static inline int knz_select_flagged(DevBuf& tmp, const uint8_t* flags, uint32_t* out_idx, uint32_t* d_count, size_t n, hipStream_t st) {
     if (n == 0) return 0;
+    if (!knz_prims_rocprim()) return knz_own_select_flagged(tmp, flags, out_idx, d_count, n, st);
     size_t bytes = 0;
     rocprim::counting_iterator<uint32_t> it(0);
     if (rocprim::select(nullptr, bytes, it, flags, out_idx, d_count, n, st) != hipSuccess) return -1;
@@ -54,18 +62,23 @@ static inline int knz_sort_pairs_emu(K* kin, K* kout, uint32_t* vin, uint32_t* v
     for (size_t i = 0; i < n; i++) { kout[i] = kin[idx[i]]; vout[i] = vin[idx[i]]; }
     return 0;
 }
-static inline int knz_sort_pairs_u64(DevBuf&, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n, unsigned b0, unsigned b1, hipStream_t) {
+static inline bool knz_emu_kernels() { return getenv("KNZ_EMU_PRIMS") != nullptr; }
+static inline int knz_sort_pairs_u64(DevBuf& tmp, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n, unsigned b0, unsigned b1, hipStream_t st) {
+    if (knz_emu_kernels()) return knz_own_sort_pairs<uint64_t>(tmp, kin, kout, vin, vout, n, b0, b1, st);
     return knz_sort_pairs_emu(kin, kout, vin, vout, n, b0, b1);
 }
-static inline int knz_sort_pairs_u32(DevBuf&, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout, size_t n, unsigned b0, unsigned b1, hipStream_t) {
+static inline int knz_sort_pairs_u32(DevBuf& tmp, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout, size_t n, unsigned b0, unsigned b1, hipStream_t st) {
+    if (knz_emu_kernels()) return knz_own_sort_pairs<uint32_t>(tmp, kin, kout, vin, vout, n, b0, b1, st);
     return knz_sort_pairs_emu(kin, kout, vin, vout, n, b0, b1);
 }
-static inline int knz_scan_max_u32(DevBuf&, uint32_t* in, uint32_t* out, size_t n, hipStream_t) {
+static inline int knz_scan_max_u32(DevBuf& tmp, uint32_t* in, uint32_t* out, size_t n, hipStream_t st) {
+    if (knz_emu_kernels()) return knz_own_scan_max_u32(tmp, in, out, n, st);
     uint32_t m = 0;
     for (size_t i = 0; i < n; i++) { m = in[i] > m ? in[i] : m; out[i] = m; }
     return 0;
 }
-static inline int knz_select_flagged(DevBuf&, const uint8_t* flags, uint32_t* out_idx, uint32_t* d_count, size_t n, hipStream_t) {
+static inline int knz_select_flagged(DevBuf& tmp, const uint8_t* flags, uint32_t* out_idx, uint32_t* d_count, size_t n, hipStream_t st) {
+    if (knz_emu_kernels()) return knz_own_select_flagged(tmp, flags, out_idx, d_count, n, st);
     uint32_t c = 0;
     for (size_t i = 0; i < n; i++) if (flags[i]) out_idx[c++] = (uint32_t)i;
     *d_count = c;

@@ -26,7 +26,14 @@ struct TextParArgs {
     uint8_t* mark; uint8_t* refb;  // [nblocks * pos_stride]
     uint64_t pos_stride;
     uint32_t* ins_tok;             // [nblocks << 19] token of the r-th entry made
+    unsigned long long* prof;      // [nblocks * 8] phase time stamps (KNZ_TEXT_PROF diagnostics) or null
 };
+
+#ifndef KNZ_HIP_EMU
+#define KNZ_TCP_STAMP(k) do { if (pa.prof && tid == 0) pa.prof[(size_t)b * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define KNZ_TCP_STAMP(k) do { } while (0)
+#endif
 
 // exclusive prefix sum over the workgroup (16 waves); total = sum of all
 __device__ __forceinline__ uint32_t knz_wg_scan_excl(uint32_t v, uint32_t* s_w, uint32_t& total) {
@@ -110,6 +117,7 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_forward_par_kernel(T
     const uint32_t nslots = 1u << a.log_hash;
 
     // ---- phase A: tokens (words of 2..31 letters in front of a delimiter), in order, with both hashes ------------------------------
+    KNZ_TCP_STAMP(0);
     uint32_t nt = 0;
     for (int base = 0; base < count; base += 4 * KNZ_TCP_THREADS) {
         const int p0 = base + 4 * (int)tid;
@@ -140,9 +148,12 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_forward_par_kernel(T
     __syncthreads();
 
     // ---- phase B: which tokens enter the dictionary (fixed point, see the header) ---------------------------------------------------
+    KNZ_TCP_STAMP(1);
+    int rounds = 0;
     bool settled = false;
     uint32_t madeLast = 0;                                                   // entries made under the guess the last round started from
     for (int round = 0; round < KNZ_TCP_MAX_ROUNDS && !settled; round++) {
+        rounds = round + 1;
         if (round) for (uint32_t s = tid; s < nslots; s += KNZ_TCP_THREADS) if (k.owner[s] >= 0) k.owner[s] = KNZ_TCP_NIL;
         __syncthreads();
         uint32_t made = 0;
@@ -190,6 +201,8 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_forward_par_kernel(T
     if (!settled || (uint32_t)k.staticSize + madeLast >= KNZ_TC_MAX_DICT) return;
 
     // ---- phase C: mark replaced words, their index bytes, and the lone spaces between two of them ----------------------------------
+    KNZ_TCP_STAMP(2);
+    if (pa.prof && tid == 0) { pa.prof[(size_t)b * 8 + 6] = (unsigned long long)rounds; pa.prof[(size_t)b * 8 + 7] = nt; }
     for (uint32_t t = tid; t < nt; t += KNZ_TCP_THREADS) {
         const uint32_t r = k.ref[t];
         if (!(r & 0x80000000u)) continue;
@@ -206,6 +219,7 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_forward_par_kernel(T
     __syncthreads();
 
     // ---- phase D: emit (emitSymbols :884-934 / :1415-1487 + the index bytes), with the reference's room checks --------------------
+    KNZ_TCP_STAMP(3);
     const bool crlf = (mode & 0x40) != 0;
     const int dstEnd = count, dstEndRef = kind == 1 ? dstEnd - 4 : dstEnd - 3;
     uint32_t outPos = 1;
@@ -260,6 +274,7 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_forward_par_kernel(T
     __syncthreads();
     if (fail) s_flag = 1;
     __syncthreads();
+    KNZ_TCP_STAMP(4);
     if (tid == 0) {
         const bool bad = s_flag != 0 || (int)outPos > dstEnd;
         a.ok[b] = bad ? 0 : 1;

@@ -115,6 +115,15 @@ def test_utf_streams(be):
     P.check_utf_streams(be)
 
 
+def test_own_sort_scan_select_kernels(be, monkeypatch):
+    """The hand-written radix sort / max-scan / select of prims.hip under the emulator (the other BWT cases of this suite take the plain
+    loops of prims.h to stay fast): BWT objects of every input shape, a multi-block stream, the inverse BWT's u32 sort."""
+    monkeypatch.setenv("KNZ_EMU_PRIMS", "kernels")
+    P.check_transform(be, "BWT", max_len=70000)
+    P.check_stream(be, "BWT+RANK+ZRLT", "ANS0", 1 << 14, 100000)
+    P.check_stream(be, "BWT", "NONE", 4096, 4096 * 5 + 77)
+
+
 def test_text_transform_and_streams(be):
     P.check_text(be, n=40_000, bs_stream=1 << 14,
                  streams=(("TEXT", "NONE"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT+UTF", "HUFFMAN"), ("UTF+TEXT", "ANS1"), ("TEXT+TEXT", "FPAQ")))
