@@ -3,7 +3,7 @@
 // v2/transform/BWT.go:132-175, v2/transform/DivSufSort.go:179-311). The BWT is a function of the input alone (sorted
 // suffixes, a suffix that ends first is smaller), so DivSufSort's induced sorting is replaced by a GPU suffix sort:
 // prefix doubling over the concatenation of ALL blocks in HBM (block id in the top key bits keeps blocks apart):
-//   round 0: radix sort of (block id, first 6 symbols) keys            [rocPRIM device radix sort, prims.h]
+//   round 0: radix sort of (block id, first 6 symbols) keys            [radix sort of prims.hip]
 //   round k: only suffixes whose group is not yet a singleton are re-sorted by (group start, rank of suffix i+h);
 //            group starts double as ranks, h doubles every round (Manber-Myers / Larsson-Sadakane refinement).
 // Output rule (DivSufSort.go:187-197): dst[0] = src[n-1], then src[SA[r]-1] for every rank r except the rank of

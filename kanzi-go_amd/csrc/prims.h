@@ -1,5 +1,5 @@
-// Device-wide sort / scan / select primitives used by the suffix sort and the inverse BWT: the hand-written kernels of prims.hip.
-// KNZ_PRIMS=rocprim routes the same entry points to rocPRIM's (ROCm's device primitives library) for A/B timing only. Under the
+// Device-wide sort / scan / select primitives used by the suffix sort and the inverse BWT: the hand-written kernels of prims.hip
+// (round 1 used rocPRIM's; the last A/B is profiles/r02_config4_bench_{own,rocprim}_primitives.json: forward stage 88.0 vs 100.7 ms). Under the
 // execution-model emulator (tests/emu, CPU container, test infrastructure only) the entry points are served by plain loops over host
 // memory unless KNZ_EMU_PRIMS=kernels asks for the real kernels (one dedicated test: the loops keep the BWT cases of the CPU suite fast).
 #pragma once
@@ -7,47 +7,19 @@
 #include "prims.hip"
 
 #ifndef KNZ_HIP_EMU
-#include <cstring>
-#include <rocprim/rocprim.hpp>
-
-static inline bool knz_prims_rocprim() { static const bool v = getenv("KNZ_PRIMS") != nullptr && strcmp(getenv("KNZ_PRIMS"), "rocprim") == 0; return v; }
-
 // (kin, vin) are scratch: clobbered. The result is in (kout, vout).
 static inline int knz_sort_pairs_u64(DevBuf& tmp, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
                                      unsigned b0, unsigned b1, hipStream_t st) {
-    if (n == 0) return 0;
-    if (!knz_prims_rocprim()) return knz_own_sort_pairs<uint64_t>(tmp, kin, kout, vin, vout, n, b0, b1, st);
-    size_t bytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, b0, b1, st) != hipSuccess) return -1;
-    if (tmp.reserve(bytes + 256)) return -1;
-    return rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, b0, b1, st) == hipSuccess ? 0 : -1;
+    return knz_own_sort_pairs<uint64_t>(tmp, kin, kout, vin, vout, n, b0, b1, st);
 }
 static inline int knz_sort_pairs_u32(DevBuf& tmp, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
                                      unsigned b0, unsigned b1, hipStream_t st) {
-    if (n == 0) return 0;
-    if (!knz_prims_rocprim()) return knz_own_sort_pairs<uint32_t>(tmp, kin, kout, vin, vout, n, b0, b1, st);
-    size_t bytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, b0, b1, st) != hipSuccess) return -1;
-    if (tmp.reserve(bytes + 256)) return -1;
-    return rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, b0, b1, st) == hipSuccess ? 0 : -1;
+    return knz_own_sort_pairs<uint32_t>(tmp, kin, kout, vin, vout, n, b0, b1, st);
 }
-static inline int knz_scan_max_u32(DevBuf& tmp, uint32_t* in, uint32_t* out, size_t n, hipStream_t st) {
-    if (n == 0) return 0;
-    if (!knz_prims_rocprim()) return knz_own_scan_max_u32(tmp, in, out, n, st);
-    size_t bytes = 0;
-    if (rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::maximum<uint32_t>(), st) != hipSuccess) return -1;
-    if (tmp.reserve(bytes + 256)) return -1;
-    return rocprim::inclusive_scan(tmp.p, bytes, in, out, n, rocprim::maximum<uint32_t>(), st) == hipSuccess ? 0 : -1;
-}
+static inline int knz_scan_max_u32(DevBuf& tmp, uint32_t* in, uint32_t* out, size_t n, hipStream_t st) { return knz_own_scan_max_u32(tmp, in, out, n, st); }
 // out_idx[k] = k-th index i in [0,n) with flags[i] != 0 ; *d_count = number selected
 static inline int knz_select_flagged(DevBuf& tmp, const uint8_t* flags, uint32_t* out_idx, uint32_t* d_count, size_t n, hipStream_t st) {
-    if (n == 0) return 0;
-    if (!knz_prims_rocprim()) return knz_own_select_flagged(tmp, flags, out_idx, d_count, n, st);
-    size_t bytes = 0;
-    rocprim::counting_iterator<uint32_t> it(0);
-    if (rocprim::select(nullptr, bytes, it, flags, out_idx, d_count, n, st) != hipSuccess) return -1;
-    if (tmp.reserve(bytes + 256)) return -1;
-    return rocprim::select(tmp.p, bytes, it, flags, out_idx, d_count, n, st) == hipSuccess ? 0 : -1;
+    return knz_own_select_flagged(tmp, flags, out_idx, d_count, n, st);
 }
 #else
 #include <algorithm>

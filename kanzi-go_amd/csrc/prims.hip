@@ -1,5 +1,5 @@
 // Device-wide primitives of the suffix sort and the inverse BWT, hand-written for gfx950: LSD radix sort of (key, value) pairs, inclusive
-// max-scan, selection of flagged indexes. (Round 1 used rocPRIM's; prims.h keeps that path behind KNZ_PRIMS=rocprim for A/B timing.)
+// max-scan, selection of flagged indexes. (Round 1 used rocPRIM's.)
 //
 // Radix sort: 8-bit digits, least significant first, stable. One pass = three launches over tiles of 4096 pairs (256 threads x 16):
 //   hist     per-tile digit counts, stored digit-major (hist[digit * tiles + tile]) so that
@@ -198,21 +198,34 @@ __global__ __launch_bounds__(KNZ_RS_THREADS) void knz_scan_apply_kernel(const ui
 }
 
 // ---- select: out_idx[k] = k-th i with flags[i] != 0 (after the counts of the tiles went through the sum scan above) -------------------------
+// bit j = flags[p0 + j] != 0 for the 16 flags of a thread (one 16-byte load when they are all inside the array and aligned)
+__device__ __forceinline__ uint32_t knz_flags16(const uint8_t* flags, uint64_t p0, uint64_t n) {
+    uint32_t f = 0;
+    if (p0 + KNZ_RS_ITEMS <= n && (((uintptr_t)(flags + p0)) & 15) == 0) {
+        const uint4 v = *(const uint4*)(flags + p0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) f |= ((w[q] >> (8 * j)) & 0xFFu) ? 1u << (4 * q + j) : 0u;
+    } else {
+        for (int j = 0; j < KNZ_RS_ITEMS; j++) if (p0 + j < n && flags[p0 + j]) f |= 1u << j;
+    }
+    return f;
+}
 __global__ __launch_bounds__(KNZ_RS_THREADS) void knz_select_count_kernel(const uint8_t* flags, uint64_t n, uint32_t* sums) {
     __shared__ uint32_t s_w[KNZ_RS_THREADS / 64];
     const uint64_t p0 = (uint64_t)blockIdx.x * KNZ_RS_TILE + (uint64_t)threadIdx.x * KNZ_RS_ITEMS;
-    uint32_t acc = 0;
-    for (int j = 0; j < KNZ_RS_ITEMS; j++) if (p0 + j < n && flags[p0 + j]) acc++;
+    const uint32_t f = knz_flags16(flags, p0, n);
     uint32_t total;
-    knz_wg256_scan_incl<KnzOpSum>(acc, s_w, total);
+    knz_wg256_scan_incl<KnzOpSum>((uint32_t)__popc(f), s_w, total);
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 __global__ __launch_bounds__(KNZ_RS_THREADS) void knz_select_write_kernel(const uint8_t* flags, uint64_t n, const uint32_t* sums, uint32_t tilesN, uint32_t* out_idx, uint32_t* d_count) {
     __shared__ uint32_t s_w[KNZ_RS_THREADS / 64];
     __shared__ uint32_t s_prev[KNZ_RS_THREADS];
     const uint64_t p0 = (uint64_t)blockIdx.x * KNZ_RS_TILE + (uint64_t)threadIdx.x * KNZ_RS_ITEMS;
-    uint32_t f = 0, acc = 0;
-    for (int j = 0; j < KNZ_RS_ITEMS; j++) if (p0 + j < n && flags[p0 + j]) { f |= 1u << j; acc++; }
+    const uint32_t f = knz_flags16(flags, p0, n), acc = (uint32_t)__popc(f);
     uint32_t total;
     const uint32_t incl = knz_wg256_scan_incl<KnzOpSum>(acc, s_w, total);
     s_prev[threadIdx.x] = incl;
