@@ -410,13 +410,14 @@ def check_reference_inputs(be):
             assert (gb, gbits) == (ob, obits), (ename, name)
             assert O.entropy_decode(et, gb, len(data))[0] == data, (ename, name, "device-encode -> oracle-decode")
             assert dec.read(ob, len(data))[0] == data, (ename, name, "oracle-encode -> device-decode")
-    for tname in ("BWT", "RANK", "MTFT", "ZRLT", "LZ", "LZX", "LZP", "SRT"):
+    for tname in ("BWT", "RANK", "MTFT", "ZRLT", "LZ", "LZX", "LZP", "SRT", "TEXT", "UTF"):
         t = K.ByteTransform(c, tname)
         tid = _TID[tname]
         for name, data in trf + ent:
             if len(data) == 0 or len(data) > (1 << 16):
                 continue
             g = t.forward(data)
+            O.set_ctx(1 << 16, O.E_NONE)                                     # (TEXT reads ctx: the handle's block size and entropy stage)
             o = O.transform_forward(tid, data)
             assert (g is None) == (o is None), (tname, name)
             if o is None:
@@ -426,7 +427,7 @@ def check_reference_inputs(be):
             assert t.inverse(o, len(data) + max(512, len(data) >> 4)) == data, (tname, name, "oracle-forward -> device-inverse")
     c.close()
     # whole streams, both ways (block size 64 KiB: the 80 000-byte input spans two blocks)
-    for transform, entropy in (("NONE", "HUFFMAN"), ("BWT+RANK+ZRLT", "ANS1"), ("LZ", "ANS0"), ("BWT+RANK+ZRLT", "FPAQ")):
+    for transform, entropy in (("NONE", "HUFFMAN"), ("BWT+RANK+ZRLT", "ANS1"), ("LZ", "ANS0"), ("BWT+RANK+ZRLT", "FPAQ"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0")):
         cs = K.Codec(transform, entropy, 1 << 16, lib=be.lib)
         for name, data in trf + ent:
             if len(data) == 0:
