@@ -76,7 +76,7 @@ struct TcpBlock {
         return (v < 0 || (uint32_t)v < t) ? v : KNZ_TCP_NIL;
     }
     // entry `code` is the word (hash h, length n, letters at w): pe.hash == h && length equal && sameWords from the second letter on
-    __device__ __forceinline__ bool match(int code, uint32_t h, int n, const uint8_t* w) const {
+    __device__ __forceinline__ bool match(int code, uint32_t h, int n, const uint8_t* w, bool wsafe) const {
         if (code == KNZ_TCP_NIL) return false;
         const uint8_t* e;
         if (code < 0) {
@@ -86,16 +86,53 @@ struct TcpBlock {
             e = letters + stat[2 * KNZ_TC_STATIC + idx];
         } else {
             if (h1[code] != h || (int)len[code] != n) return false;
-            e = src + tok_end[code] - n;
+            e = src + tok_end[code] - n;                                   // (an earlier word of the block: readable wherever w is)
+        }
+        if (wsafe) {                                                         // 8 bytes at a time (both sides readable up to 7 bytes past the word)
+            for (int k = 0; k < n; k += 8) {
+                uint64_t x = knz_vle64(e + k) ^ knz_vle64(w + k);
+                if (k == 0) x &= ~(uint64_t)0xFF;                                // the first letter is not compared (:793)
+                if (n - k < 8) x &= ((uint64_t)1 << (8 * (n - k))) - 1;
+                if (x) return false;
+            }
+            return true;
         }
         for (int k = 1; k < n; k++) if (e[k] != w[k]) return false;
         return true;
+    }
+    // P[] of the current guess, the table of who made the r-th entry and the slot owners (atomicMin), 4 tokens per thread and step;
+    // returns the number of entries made
+    __device__ __forceinline__ uint32_t scan_round(uint32_t nt, uint32_t* s_w) {
+        uint32_t made = 0;
+        for (uint32_t base = 0; base < nt; base += 4 * KNZ_TCP_THREADS) {
+            const uint32_t t0 = base + 4 * threadIdx.x;
+            uint32_t v = 0;
+            if (t0 + 4 <= nt) v = *(const uint32_t*)(ins + t0);
+            else for (uint32_t j = 0; j < 4; j++) if (t0 + j < nt) v |= (uint32_t)ins[t0 + j] << (8 * j);
+            const uint32_t c = (v & 1u) + ((v >> 8) & 1u) + ((v >> 16) & 1u) + ((v >> 24) & 1u);
+            uint32_t tot;
+            uint32_t p = made + knz_wg_scan_excl(c, s_w, tot);
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t t = t0 + j;
+                if (t >= nt) break;
+                P[t] = p;
+                if ((v >> (8 * j)) & 1u) {
+                    if (p < KNZ_TC_MAX_DICT) ins_tok[p] = t;
+                    const uint32_t slot = h1[t] & mask;
+                    if (slot) atomicMin(&owner[slot], (int)t);
+                    p++;
+                }
+            }
+            made += tot;
+        }
+        return made;
     }
 };
 
 __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_forward_par_kernel(TextParArgs pa) {
     __shared__ uint32_t s_w[KNZ_TCP_THREADS / 64];
     __shared__ uint32_t s_flag;
+    __shared__ uint32_t s_txt[2 + 2 * 64 + 2];                               // letter flags of a tile: 64 masks of 64 positions behind the last mask of the previous tile
     const TextArgs& a = pa.a;
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     if (!a.active[b]) return;
@@ -118,24 +155,53 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_forward_par_kernel(T
 
     // ---- phase A: tokens (words of 2..31 letters in front of a delimiter), in order, with both hashes ------------------------------
     KNZ_TCP_STAMP(0);
+    // Tile of 4096 positions, thread tid looks at positions base + 1024 j + tid (j = 0..3): one ballot per wave and j is the "is a letter" mask
+    // of 64 consecutive positions; the masks go to LDS (with the last one of the previous tile in front), so the length of the letter run in
+    // front of a delimiter is a count of leading ones in a 32-bit window instead of a byte-by-byte walk back through memory.
     uint32_t nt = 0;
+    if (tid < 2) s_txt[tid] = 0;                                            // (positions in front of the block: not letters)
     for (int base = 0; base < count; base += 4 * KNZ_TCP_THREADS) {
-        const int p0 = base + 4 * (int)tid;
-        int wl[4];
-        uint32_t c = 0;
-        for (int j = 0; j < 4; j++) { wl[j] = p0 + j < count ? knz_tcp_word_len(src, p0 + j) : 0; c += wl[j] ? 1u : 0u; }
-        uint32_t tot;
-        uint32_t t = nt + knz_wg_scan_excl(c, s_w, tot);
+        uint32_t cur[4];
         for (int j = 0; j < 4; j++) {
-            if (!wl[j]) continue;
-            const int p = p0 + j, n = wl[j];
-            const uint8_t* w = src + p - n;
-            uint32_t h1 = knz_tc_hash_step(KNZ_TC_HASH1, w[0]), h2 = knz_tc_hash_step(KNZ_TC_HASH1, (uint32_t)w[0] ^ 0x20u);
-            for (int q = 1; q < n; q++) { const uint32_t h = (uint32_t)w[q] * KNZ_TC_HASH2; h1 = (h1 * KNZ_TC_HASH1) ^ h; h2 = (h2 * KNZ_TC_HASH1) ^ h; }
-            k.tok_end[t] = (uint32_t)p; k.len[t] = (uint8_t)n; k.h1[t] = h1; k.h2[t] = h2; k.ins[t] = 0;
-            t++;
+            const int p = base + j * KNZ_TCP_THREADS + (int)tid;
+            cur[j] = p < count ? src[p] : 0u;
+            const uint64_t m = wave_ballot(p < count && knz_tc_is_text(cur[j]));
+            if ((tid & 63) == 0) { const uint32_t wi = 2 + 2 * (uint32_t)(j * (KNZ_TCP_THREADS / 64) + (tid >> 6)); s_txt[wi] = (uint32_t)m; s_txt[wi + 1] = (uint32_t)(m >> 32); }
         }
-        nt += tot;
+        __syncthreads();
+        int wl[4];
+        uint32_t c012 = 0, c3 = 0;
+        for (int j = 0; j < 4; j++) {
+            const int idx = j * KNZ_TCP_THREADS + (int)tid, p = base + idx;
+            wl[j] = 0;
+            if (p < count && p > 0 && !knz_tc_is_text(cur[j]) && knz_tc_is_delim(cur[j])) {
+                // letter flags of the 32 positions in front of p: bit 31 = position p - 1 (s_txt bit 64 = the tile's first position)
+                const uint32_t lo = 64u + (uint32_t)idx - 32u, wq = lo >> 5, sh = lo & 31u;
+                const uint64_t two = ((uint64_t)s_txt[wq + 1] << 32) | s_txt[wq];
+                const uint32_t win = (uint32_t)(two >> sh);
+                const int n = (int)__clz((int)~win);                             // leading ones (0 when p - 1 is no letter, 32 = longer than 31)
+                if (n >= 2 && n <= 31) wl[j] = n;
+            }
+            if (j < 3) c012 += (wl[j] ? 1u : 0u) << (11 * j); else c3 = wl[j] ? 1u : 0u;
+        }
+        uint32_t tot012, tot3;
+        const uint32_t e012 = knz_wg_scan_excl(c012, s_w, tot012), e3 = knz_wg_scan_excl(c3, s_w, tot3);
+        const uint32_t tj[4] = {tot012 & 0x7FFu, (tot012 >> 11) & 0x7FFu, (tot012 >> 22) & 0x7FFu, tot3};
+        uint32_t first = nt;
+        for (int j = 0; j < 4; j++) {
+            if (wl[j]) {
+                const uint32_t t = first + (j < 3 ? (e012 >> (11 * j)) & 0x7FFu : e3);
+                const int p = base + j * KNZ_TCP_THREADS + (int)tid, n = wl[j];
+                const uint8_t* w = src + p - n;
+                uint32_t h1 = knz_tc_hash_step(KNZ_TC_HASH1, w[0]), h2 = knz_tc_hash_step(KNZ_TC_HASH1, (uint32_t)w[0] ^ 0x20u);
+                for (int q = 1; q < n; q++) { const uint32_t h = (uint32_t)w[q] * KNZ_TC_HASH2; h1 = (h1 * KNZ_TC_HASH1) ^ h; h2 = (h2 * KNZ_TC_HASH1) ^ h; }
+                k.tok_end[t] = (uint32_t)p; k.len[t] = (uint8_t)n; k.h1[t] = h1; k.h2[t] = h2; k.ins[t] = 0;
+            }
+            first += tj[j];
+        }
+        nt = first;
+        if (tid < 2) s_txt[tid] = s_txt[2 + 2 * 63 + tid];                   // the tile's last 64 flags lead the next tile
+        __syncthreads();
     }
     // static entries claim their slots (the later entry wins a shared slot: -1 - index, smallest value = largest index)
     for (uint32_t s = tid; s < nslots; s += KNZ_TCP_THREADS) k.owner[s] = KNZ_TCP_NIL;
@@ -147,6 +213,12 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_forward_par_kernel(T
     k.static0 = k.owner[0];
     __syncthreads();
 
+    // first guess: the first word of at least 3 letters per free slot (what the fixed point is when nothing is found under the other-case
+    // hash and the length-3 cut-off is not reached: two rounds less than starting from "nobody")
+    for (uint32_t t = tid; t < nt; t += KNZ_TCP_THREADS) { const uint32_t slot = k.h1[t] & k.mask; if (k.len[t] >= 3 && slot) atomicMin(&k.owner[slot], (int)t); }
+    __syncthreads();
+    for (uint32_t t = tid; t < nt; t += KNZ_TCP_THREADS) { const uint32_t slot = k.h1[t] & k.mask; k.ins[t] = (k.len[t] >= 3 && slot && k.owner[slot] == (int)t) ? 1 : 0; }
+    __syncthreads();
     // ---- phase B: which tokens enter the dictionary (fixed point, see the header) ---------------------------------------------------
     KNZ_TCP_STAMP(1);
     int rounds = 0;
@@ -154,24 +226,9 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_forward_par_kernel(T
     uint32_t madeLast = 0;                                                   // entries made under the guess the last round started from
     for (int round = 0; round < KNZ_TCP_MAX_ROUNDS && !settled; round++) {
         rounds = round + 1;
-        if (round) for (uint32_t s = tid; s < nslots; s += KNZ_TCP_THREADS) if (k.owner[s] >= 0) k.owner[s] = KNZ_TCP_NIL;
+        for (uint32_t s = tid; s < nslots; s += KNZ_TCP_THREADS) if (k.owner[s] >= 0) k.owner[s] = KNZ_TCP_NIL;
         __syncthreads();
-        uint32_t made = 0;
-        for (uint32_t base = 0; base < nt; base += KNZ_TCP_THREADS) {
-            const uint32_t t = base + tid;
-            const uint32_t v = t < nt ? k.ins[t] : 0u;
-            uint32_t tot;
-            const uint32_t p = made + knz_wg_scan_excl(v, s_w, tot);
-            if (t < nt) {
-                k.P[t] = p;
-                if (v) {
-                    if (p < KNZ_TC_MAX_DICT) k.ins_tok[p] = t;
-                    const uint32_t slot = k.h1[t] & k.mask;
-                    if (slot) atomicMin(&k.owner[slot], (int)t);
-                }
-            }
-            made += tot;
-        }
+        const uint32_t made = k.scan_round(nt, s_w);
         madeLast = made;
         if (tid == 0) s_flag = 0;
         __syncthreads();
@@ -183,8 +240,9 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_forward_par_kernel(T
             const int c1 = k.content(h1 & k.mask, t, p);
             int hit = KNZ_TCP_NIL;
             uint32_t via2 = 0;
-            if (k.match(c1, h1, n, w)) hit = c1;
-            else { const int c2 = k.content(h2 & k.mask, t, p); if (k.match(c2, h2, n, w)) { hit = c2; via2 = 1; } }
+            const bool wsafe = (int)k.tok_end[t] - n + 40 <= count;           // 8-byte reads stay inside the block
+            if (k.match(c1, h1, n, w, wsafe)) hit = c1;
+            else { const int c2 = k.content(h2 & k.mask, t, p); if (k.match(c2, h2, n, w, wsafe)) { hit = c2; via2 = 1; } }
             const bool qual = n > 3 || (n == 3 && k.staticSize + (int)p < 16384);
             const uint32_t nv = (hit == KNZ_TCP_NIL && qual && c1 == KNZ_TCP_NIL) ? 1u : 0u;
             if (nv != k.ins[t]) { k.ins[t] = (uint8_t)nv; changed = true; }
@@ -465,28 +523,17 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_inverse_par_kernel(T
     k.static0 = k.owner[0];
     __syncthreads();
 
+    for (uint32_t t = tid; t < nt; t += KNZ_TCP_THREADS) { const uint32_t slot = k.h1[t] & k.mask; if (slot) atomicMin(&k.owner[slot], (int)t); }   // first guess: the first word per free slot
+    __syncthreads();
+    for (uint32_t t = tid; t < nt; t += KNZ_TCP_THREADS) { const uint32_t slot = k.h1[t] & k.mask; k.ins[t] = (slot && k.owner[slot] == (int)t) ? 1 : 0; }
+    __syncthreads();
     // ---- phase III: entries ------------------------------------------------------------------------------------------------------------
     bool settled = false;
     uint32_t madeLast = 0;
     for (int round = 0; round < KNZ_TCP_MAX_ROUNDS && !settled; round++) {
-        if (round) for (uint32_t s = tid; s < nslots; s += KNZ_TCP_THREADS) if (k.owner[s] >= 0) k.owner[s] = KNZ_TCP_NIL;
+        for (uint32_t s = tid; s < nslots; s += KNZ_TCP_THREADS) if (k.owner[s] >= 0) k.owner[s] = KNZ_TCP_NIL;
         __syncthreads();
-        uint32_t made = 0;
-        for (uint32_t base = 0; base < nt; base += KNZ_TCP_THREADS) {
-            const uint32_t t = base + tid;
-            const uint32_t v = t < nt ? k.ins[t] : 0u;
-            uint32_t tot;
-            const uint32_t p = made + knz_wg_scan_excl(v, s_w, tot);
-            if (t < nt) {
-                k.P[t] = p;
-                if (v) {
-                    if (p < KNZ_TC_MAX_DICT) k.ins_tok[p] = t;
-                    const uint32_t slot = k.h1[t] & k.mask;
-                    if (slot) atomicMin(&k.owner[slot], (int)t);
-                }
-            }
-            made += tot;
-        }
+        const uint32_t made = k.scan_round(nt, s_w);
         madeLast = made;
         if (tid == 0) s_flag = 0;
         __syncthreads();

@@ -53,19 +53,23 @@ __device__ __forceinline__ uint32_t knz_utf_pack(uint32_t s, uint32_t b0, uint32
     return (4u << 19) | ((b0 & 0x07) << 18) | ((b1 & 0x3F) << 12) | ((b2 & 0x3F) << 6) | (b3 & 0x3F);
 }
 
-__global__ __launch_bounds__(64) void knz_utf_forward_kernel(UtfArgs a) {
+#define KNZ_UTF_FWD_THREADS 1024
+__global__ __launch_bounds__(KNZ_UTF_FWD_THREADS) void knz_utf_forward_kernel(UtfArgs a) {
     __shared__ uint32_t s_n;
+    __shared__ uint32_t s_bad, s_cont;
+    __shared__ int s_last;
     __shared__ uint64_t s_keys[1024];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;                                         // pass 1 (validation + histogram) runs on all 16 waves, the rest on wave 0
+    const int lane = tid & 63;
     const uint32_t b = blockIdx.x;
     if (!a.active[b]) return;
     const int count = (int)a.in_len[b];
     const uint8_t* src = (const uint8_t*)a.in_ptr[b];
     uint8_t* dst = (uint8_t*)a.out_ptr[b];
     const uint32_t dt = a.blk_dt ? a.blk_dt[b] : 0u;
-    if (count == 0) { if (lane == 0) { a.ok[b] = 1; a.out_len[b] = 0; } return; }
+    if (count == 0) { if (tid == 0) { a.ok[b] = 1; a.out_len[b] = 0; } return; }
     // :93-114: block size, output size, ctx["dataType"]
-    if (count < KNZ_UTF_MIN_BLOCK || (uint64_t)a.out_cap < (uint64_t)count + 8192 || (dt != KNZ_DT_UNDEFINED && dt != KNZ_DT_UTF8)) { if (lane == 0) { a.ok[b] = 0; a.out_len[b] = 0; } return; }
+    if (count < KNZ_UTF_MIN_BLOCK || (uint64_t)a.out_cap < (uint64_t)count + 8192 || (dt != KNZ_DT_UNDEFINED && dt != KNZ_DT_UTF8)) { if (tid == 0) { a.ok[b] = 0; a.out_len[b] = 0; } return; }
     int32_t* map = a.alias_map + ((size_t)b << KNZ_UTF_MAP_LOG);
     uint32_t* syms = a.symlist + (size_t)b * KNZ_UTF_MAX_SYMS;
     uint32_t* ranks = a.ranks + (size_t)b * KNZ_UTF_MAX_SYMS;
@@ -75,9 +79,9 @@ __global__ __launch_bounds__(64) void knz_utf_forward_kernel(UtfArgs a) {
     if (src[1] == 0xEF && src[2] == 0xBB && src[3] == 0xBF) start = 3;   // BigEndian.Uint32(src) & 0x00FFFFFF == 0xEFBBBF (:118)
     else while (start < 4 && knz_utf_size(src[start]) == 0) start++;
     const int end = count - 4;                                           // code points start in [start, end)
-    if (lane == 0) s_n = 0;
+    if (tid == 0) { s_n = 0; s_bad = 0; s_cont = 0; s_last = -1; }
     bool bad = false;
-    if (chainMode) {
+    if (chainMode && tid < 64) {
         // the reference's walk (:141-166), lane 0; marks the starts. (Only reachable with UTF twice in one sequence.)
         for (uint64_t i = lane; i < a.bits_stride; i += 64) cbits[i] = 0;
         wave_sync();
@@ -94,14 +98,17 @@ __global__ __launch_bounds__(64) void knz_utf_forward_kernel(UtfArgs a) {
         wave_sync();
         __threadfence();
         bad = wave_bcast((uint32_t)fail, 0) != 0;
+        if (bad && lane == 0) s_bad = 1;
     }
-    wave_sync();
+    __syncthreads();
+    if (s_bad) bad = true;
     // ---- pass 1: validation + histogram --------------------------------------------------------------------------------
     uint32_t cont = 0;                                                   // bytes in 80..BF inside [start, end) (sum2)
     int lastLead = -1;
     if (!bad) {
-        for (int p0 = start; p0 < end; p0 += 64) {
-            const int p = p0 + lane;
+        for (int p0 = start; p0 < end; p0 += KNZ_UTF_FWD_THREADS) {
+            if (wave_ballot(bad) != 0) break;                            // not UTF-8: the stage declines whatever follows (binary blocks stop within a row or two)
+            const int p = p0 + tid;
             if (p < end) {
                 const uint32_t b0 = src[p], b1 = src[p + 1], b2 = src[p + 2], b3 = src[p + 3];
                 const uint32_t s = knz_utf_size(b0);
@@ -132,11 +139,21 @@ __global__ __launch_bounds__(64) void knz_utf_forward_kernel(UtfArgs a) {
             }
         }
     }
-    wave_sync();
+    {   // the 16 waves' findings
+        const uint32_t cw = wave_reduce_add(cont);
+        int lw = lastLead;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const int o = (int)wave_shfl((uint32_t)lw, lane ^ d); lw = o > lw ? o : lw; }
+        const uint64_t wb = wave_ballot(bad);
+        if (lane == 0) { atomicAdd(&s_cont, cw); atomicMax(&s_last, lw); if (wb != 0) atomicOr(&s_bad, 1u); }
+    }
     __threadfence();
+    __syncthreads();
+    if (tid >= 64) return;
+    lastLead = s_last;
     const uint32_t n = s_n;
-    const uint32_t contAll = wave_reduce_add(cont);
-    if (wave_ballot(bad) != 0) bad = true;
+    const uint32_t contAll = s_cont;
+    bad = s_bad != 0;
     if (!chainMode && contAll < (uint32_t)((end - start) / 8)) bad = true;   // ad-hoc threshold (:518)
     const int maxTarget = count - count / 10;
     if (bad || n == 0 || n >= KNZ_UTF_MAX_SYMS || 3 * (int)n + 6 >= maxTarget) { if (lane == 0) { a.ok[b] = 0; a.out_len[b] = 0; } return; }
