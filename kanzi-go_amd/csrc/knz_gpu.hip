@@ -11,6 +11,7 @@
 #include "rank_inv.hip"
 #include "bwt.hip"
 #include "lz.hip"
+#include "lz_par.hip"
 #include "srt_lzp.hip"
 #include "text.hip"
 #include "text_par.hip"

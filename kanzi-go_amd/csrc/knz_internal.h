@@ -48,6 +48,7 @@ struct Handle {
     // transform pipeline (knz_transforms.inc)
     DevBuf xf_r1, xf_r2, xf_outptr, xf_outlen, xf_ok, xf_side, xf_active, xf_take, xf_sega, xf_segb, xf_gstart, xf_misc;
     DevBuf lz_hash, lz_tk, lz_mb, lz_ml;
+    DevBuf lz_k0, lz_k1, lz_v0, lz_v1, lz_cand, lz_cp, lz_holes, lz_gstart;     // second form of the LZ forward (lz_par.hip): sort buffers, candidates, common prefixes, hole bitmaps
     DevBuf a1_freqs, a1_tab, a1_ctxhdr, a1_ctxbits, a1_dtab, a1_info, a1_paybit, a1_f16, a1_ent, a1_cum;
     DevBuf sa_keys0, sa_keys1, sa_vals0, sa_vals1, sa_rank, sa_gs, sa_head, sa_unres, sa_pos, sa_tmp, sa_links, sa_sp;
     void* pinned = nullptr;           // small pinned host area for results

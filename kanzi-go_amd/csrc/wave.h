@@ -47,6 +47,15 @@ __device__ __forceinline__ uint32_t wave_shr1_keep0(uint32_t cur, uint32_t v) { 
 // hides a (wave-uniform) value in a VGPR: arithmetic on it is issued to the vector ALU, so that an SGPR written by a
 // v_readlane is consumed without the VALU -> SALU hand-over (~6 ns for a lone wave on gfx950, tools/gpu/lat_bench.hip)
 __device__ __forceinline__ uint32_t wave_in_vgpr(uint32_t x) { asm("" : "+v"(x)); return x; }
+// scalar loads that are issued where they stand and waited for together: the compiler gives every scalar load it schedules itself a wait
+// of its own as soon as a branch separates it from its use, which turns five independent reads of one step into five round trips.
+// p must be 4-byte aligned. The values are valid behind WAVE_SLOAD_WAIT(...) naming them.
+__device__ __forceinline__ uint64_t wave_sload_u64_async(const uint8_t* p) { uint64_t v; asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(v) : "s"(p) : "memory"); return v; }
+__device__ __forceinline__ uint32_t wave_sload_u32_async(const uint8_t* p) { uint32_t v; asm volatile("s_load_dword %0, %1, 0x0" : "=&s"(v) : "s"(p) : "memory"); return v; }
+#define WAVE_SLOAD_WAIT7(a, b, c, d, e, f, g) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e), "+s"(f), "+s"(g))
+// pins a wave-uniform value in an SGPR at this point of the program: the (scalar) load that produces it is issued here, not sunk into the
+// branch that first uses it (several such loads in a row then share one s_waitcnt)
+__device__ __forceinline__ uint32_t wave_pin_sgpr(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
 // v with lane L (compile-time) replaced by the wave-uniform value `val`
 template <int L> __device__ __forceinline__ uint32_t wave_writelane_c(uint32_t v, uint32_t val) {
     const int sv = __builtin_amdgcn_readfirstlane((int)val);
@@ -85,6 +94,7 @@ __device__ __forceinline__ void wg_spin_pause() { __builtin_amdgcn_s_sleep(16); 
 // the lanes one after another between rendezvous points and needs one here.)
 __device__ __forceinline__ void wave_order_lanes() {}
 __device__ __forceinline__ int32_t knz_wg_load_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int32_t knz_agent_load_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void knz_wg_max_i32(int32_t* p, int32_t v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wave_raise_priority() { __builtin_amdgcn_s_setprio(3); }
 #else
@@ -97,6 +107,7 @@ inline uint64_t knz_poll64(const uint64_t* p) { return *(const volatile uint64_t
 inline void wg_spin_pause() { hipemu::spin_pause(); }
 inline void wave_order_lanes() { hipemu::wave_barrier(); }
 inline int32_t knz_wg_load_i32(const int32_t* p) { return *(const volatile int32_t*)p; }
+inline int32_t knz_agent_load_i32(const int32_t* p) { return *(const volatile int32_t*)p; }
 inline void knz_wg_max_i32(int32_t* p, int32_t v) { if (*(volatile int32_t*)p < v) *(volatile int32_t*)p = v; }
 inline void wave_raise_priority() {}
 inline uint32_t knz_mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
@@ -131,6 +142,10 @@ inline uint32_t wave_shl1(uint32_t v) { const uint32_t r = wave_shfl(v, hipemu::
 inline uint32_t wave_shr1_old(uint32_t v, uint32_t old) { const uint32_t r = wave_shfl(v, hipemu::lane() - 1); return hipemu::lane() == 0 ? old : r; }
 inline uint32_t wave_shr1_keep0(uint32_t cur, uint32_t v) { const uint32_t r = wave_shfl(v, hipemu::lane() - 1); return hipemu::lane() == 0 ? cur : r; }
 inline uint32_t wave_in_vgpr(uint32_t x) { return x; }
+inline uint32_t wave_pin_sgpr(uint32_t x) { return x; }
+inline uint64_t wave_sload_u64_async(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+inline uint32_t wave_sload_u32_async(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+#define WAVE_SLOAD_WAIT7(a, b, c, d, e, f, g) do { } while (0)
 template <int L> inline uint32_t wave_writelane_c(uint32_t v, uint32_t val) { return hipemu::lane() == L ? val : v; }
 struct knz_u32x4 { uint32_t x, y, z, w; };
 inline uint32_t wave_sload_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }

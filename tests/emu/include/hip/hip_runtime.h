@@ -74,6 +74,7 @@ inline void __syncthreads() { hipemu::block_barrier(); }
 
 template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = (T)(o + v); return o; }
 template <typename T> inline T atomicOr(T* p, T v) { T o = *p; *p = (T)(o | v); return o; }
+template <typename T> inline T atomicAnd(T* p, T v) { T o = *p; *p = (T)(o & v); return o; }
 template <typename T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <typename T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <typename T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }

@@ -124,6 +124,13 @@ def test_own_sort_scan_select_kernels(be, monkeypatch):
     P.check_stream(be, "BWT", "NONE", 4096, 4096 * 5 + 77)
 
 
+def test_lz_first_form(be, monkeypatch):
+    """KNZ_LZ_CHAIN: the parse that keeps its own hash table (lz.hip), the cross-check of the table-free form that runs by default."""
+    monkeypatch.setenv("KNZ_LZ_CHAIN", "1")
+    P.check_transform(be, "LZ", max_len=60000)
+    P.check_transform(be, "LZX", max_len=60000)
+
+
 def test_text_transform_and_streams(be):
     P.check_text(be, n=40_000, bs_stream=1 << 14,
                  streams=(("TEXT", "NONE"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT+UTF", "HUFFMAN"), ("UTF+TEXT", "ANS1"), ("TEXT+TEXT", "FPAQ")))

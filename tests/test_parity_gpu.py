@@ -262,6 +262,13 @@ def test_utf_streams(be):
     P.check_utf_streams(be)
 
 
+def test_lz_first_form(be, monkeypatch):
+    """KNZ_LZ_CHAIN: the parse that keeps its own hash table (lz.hip), the cross-check of the table-free form that runs by default."""
+    monkeypatch.setenv("KNZ_LZ_CHAIN", "1")
+    P.check_transform(be, "LZ")
+    P.check_transform(be, "LZX")
+
+
 def test_text_transform_and_streams(be):
     P.check_text(be)
 
