@@ -386,7 +386,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic" if not emu else "synthetic (EMULATOR TEST HARNESS on CPU: not a measurement)",
-            "config": {"workload": f"BASELINE.json configs[{cfg_idx}]: -t {transform} -e {entropy} -b {bs >> 20}m on {corpus_name} "
+            "config": {"workload": (f"BASELINE.json configs[{cfg_idx}]" if args.config != "l5" else "kanzi-go preset -l 5 (README.md:79; not a BASELINE.json config)") +
+                                   f": -t {transform} -e {entropy} -b {bs >> 20}m on {corpus_name} "
                                    f"(one .knz stream of {size} B" + ("" if strong else f" = {world} copies of {base_size} B") + ", bench_corpus.py)",
                        "blocks": nblocks, "block_size": bs,
                        "parallelism": f"contiguous block ranges over {world} GPU(s) ({','.join(str(x) for x in counts)} blocks), segments gathered to rank 0"},
