@@ -389,22 +389,32 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             a.unit_src = h->unit_src.as<uint32_t>(); a.blk_status = h->blk_status.as<int32_t>();
             KNZ_LAUNCH_PROBED(knz_fpaq_encode_kernel, dim3(nblocks), dim3(64), 0, st, a);
         } else if (cfg.entropy == KNZ_E_ANS1) {
-            const uint32_t ns = nblocks * cpb;
-            if (h->a1_freqs.reserve((size_t)ns * 65536 * 4) || h->a1_tab.reserve((size_t)ns * 65536 * 8) ||
-                h->a1_ctxhdr.reserve((size_t)ns * 256 * KNZ_ANS1_CTXHDR_BYTES + 64) || h->a1_ctxbits.reserve((size_t)ns * 256 * 4) ||
-                h->a1_ent.reserve((size_t)ns * KNZ_ANS1_ENT_STRIDE * 16))
+            // bounded groups of blocks (like the UTF stage and the suffix sort): a chunk slot takes 768 KiB of count / coder tables, 112 KiB of
+            // context headers and the 64 MiB expanded-step stream; the workspace is sized to at most ~8 GiB of them, not to the batch
+            const size_t perSlot = (size_t)65536 * 12 + (size_t)256 * KNZ_ANS1_CTXHDR_BYTES + 1024 + KNZ_ANS1_ENT_STRIDE * 16;
+            const uint32_t slotsPerGroup = (uint32_t)std::max<size_t>(cpb, std::min<size_t>((size_t)nblocks * cpb, ((size_t)8 << 30) / perSlot));
+            uint32_t GB = std::max<uint32_t>(1, slotsPerGroup / cpb);                   // whole blocks per group
+            if (const char* e = getenv("KNZ_ANS1_GROUP_BLOCKS")) GB = std::max(1, atoi(e));   // (tests: several groups on small inputs)
+            const uint32_t gs = GB * cpb;
+            if (h->a1_freqs.reserve((size_t)gs * 65536 * 4) || h->a1_tab.reserve((size_t)gs * 65536 * 8) ||
+                h->a1_ctxhdr.reserve((size_t)gs * 256 * KNZ_ANS1_CTXHDR_BYTES + 64) || h->a1_ctxbits.reserve((size_t)gs * 256 * 4) ||
+                h->a1_ent.reserve((size_t)gs * KNZ_ANS1_ENT_STRIDE * 16))
                 return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
-            Ans1Args a;
-            a.blk_off = h->blk_off.as<uint64_t>(); a.blk_len = h->blk_len.as<uint32_t>(); a.chunks_per_block = cpb; a.nslots = ns;
-            a.scratch = h->scratch.as<uint8_t>(); a.unit_bits = h->unit_bits.as<uint32_t>(); a.unit_src = h->unit_src.as<uint32_t>();
-            a.freqs = h->a1_freqs.as<uint32_t>(); a.tab = h->a1_tab.as<uint2>(); a.ctx_hdr = h->a1_ctxhdr.as<uint8_t>();
-            a.ctx_bits = h->a1_ctxbits.as<uint32_t>(); a.blk_status = h->blk_status.as<int32_t>();
-            hipMemsetAsync(h->a1_freqs.p, 0, (size_t)ns * 65536 * 4, st);
-            KNZ_LAUNCH_PROBED(knz_ans1_hist_kernel, dim3(ns * KNZ_ANS1_HIST_WGS * KNZ_ANS1_HIST_SLICES), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(knz_ans1_stats_kernel, dim3(ns * 256), dim3(64), 0, st, a);
-            hipLaunchKernelGGL(knz_ans1_merge_kernel, dim3(ns), dim3(256), 0, st, a);
-            KNZ_LAUNCH_PROBED(knz_ans1_expand_kernel, dim3(ns, 128), dim3(256), 0, st, a, h->a1_ent.as<uint4>());
-            KNZ_LAUNCH_PROBED(knz_ans1_encode_kernel, dim3(ns), dim3(64), 0, st, a, (const uint4*)h->a1_ent.as<uint4>());
+            for (uint32_t b0 = 0; b0 < nblocks; b0 += GB) {
+                const uint32_t gb = std::min<uint32_t>(GB, nblocks - b0), ns = gb * cpb;
+                const size_t s0 = (size_t)b0 * cpb;
+                Ans1Args a;                                                                // the group's slice of every per-block / per-slot table
+                a.blk_off = h->blk_off.as<uint64_t>() + b0; a.blk_len = h->blk_len.as<uint32_t>() + b0; a.chunks_per_block = cpb; a.nslots = ns;
+                a.scratch = h->scratch.as<uint8_t>() + s0 * slotStride; a.unit_bits = h->unit_bits.as<uint32_t>() + s0 * 5; a.unit_src = h->unit_src.as<uint32_t>() + s0 * 5;
+                a.freqs = h->a1_freqs.as<uint32_t>(); a.tab = h->a1_tab.as<uint2>(); a.ctx_hdr = h->a1_ctxhdr.as<uint8_t>();
+                a.ctx_bits = h->a1_ctxbits.as<uint32_t>(); a.blk_status = h->blk_status.as<int32_t>() + b0;
+                hipMemsetAsync(h->a1_freqs.p, 0, (size_t)ns * 65536 * 4, st);
+                KNZ_LAUNCH_PROBED(knz_ans1_hist_kernel, dim3(ns * KNZ_ANS1_HIST_WGS * KNZ_ANS1_HIST_SLICES), dim3(256), 0, st, a);
+                hipLaunchKernelGGL(knz_ans1_stats_kernel, dim3(ns * 256), dim3(64), 0, st, a);
+                hipLaunchKernelGGL(knz_ans1_merge_kernel, dim3(ns), dim3(256), 0, st, a);
+                KNZ_LAUNCH_PROBED(knz_ans1_expand_kernel, dim3(ns, 128), dim3(256), 0, st, a, h->a1_ent.as<uint4>());
+                KNZ_LAUNCH_PROBED(knz_ans1_encode_kernel, dim3(ns), dim3(64), 0, st, a, (const uint4*)h->a1_ent.as<uint4>());
+            }
         } else if (cfg.entropy == KNZ_E_ANS0) {
             Ans0Args a;
             a.data = nullptr; a.blk_off = h->blk_off.as<uint64_t>(); a.blk_len = h->blk_len.as<uint32_t>();

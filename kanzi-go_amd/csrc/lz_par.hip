@@ -119,7 +119,9 @@ __global__ __launch_bounds__(64) void knz_lz_forward_par_kernel(LzParArgs pa) {
     // findMatchLZX(p, ref, maxMatch) from the common prefix cp (< 255): whole 8-byte steps only, the first difference ends it (:593-607)
     auto len_from_cp = [&](int cp, int maxMatch) -> int { const int whole = maxMatch & ~7; return cp < whole ? cp : whole; };
 
-#ifndef KNZ_HIP_EMU
+    // (cycle counts per part of the parse: a build with -DKNZ_LZ_PROFILE and KNZ_LZ_PROF=1 in the environment; the stamps cost ~12 % of this
+    // instruction-bound loop, so they are compiled out otherwise)
+#if defined(KNZ_LZ_PROFILE) && !defined(KNZ_HIP_EMU)
 #define KNZ_LZP_NOW() (pa.prof ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
 #else
 #define KNZ_LZP_NOW() 0ull

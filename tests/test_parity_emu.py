@@ -124,6 +124,13 @@ def test_own_sort_scan_select_kernels(be, monkeypatch):
     P.check_stream(be, "BWT", "NONE", 4096, 4096 * 5 + 77)
 
 
+def test_ans1_encode_in_groups(be, monkeypatch):
+    """The order-1 rANS encoder's workspace is sized to a group of blocks, not to the batch: 7 blocks through groups of 2."""
+    monkeypatch.setenv("KNZ_ANS1_GROUP_BLOCKS", "2")
+    P.check_stream(be, "NONE", "ANS1", 1 << 14, 7 * (1 << 14) - 100)
+    P.check_stream(be, "BWT+RANK+ZRLT", "ANS1", 1 << 14, 5 * (1 << 14) + 33)
+
+
 def test_lz_first_form(be, monkeypatch):
     """KNZ_LZ_CHAIN: the parse that keeps its own hash table (lz.hip), the cross-check of the table-free form that runs by default."""
     monkeypatch.setenv("KNZ_LZ_CHAIN", "1")

@@ -262,6 +262,12 @@ def test_utf_streams(be):
     P.check_utf_streams(be)
 
 
+def test_ans1_encode_in_groups(be, monkeypatch):
+    monkeypatch.setenv("KNZ_ANS1_GROUP_BLOCKS", "3")
+    P.check_stream(be, "NONE", "ANS1", 1 << 16, 10 * (1 << 16) - 100)
+    P.check_stream(be, "BWT+RANK+ZRLT", "ANS1", 1 << 20, 5 * (1 << 20) + 33)
+
+
 def test_lz_first_form(be, monkeypatch):
     """KNZ_LZ_CHAIN: the parse that keeps its own hash table (lz.hip), the cross-check of the table-free form that runs by default."""
     monkeypatch.setenv("KNZ_LZ_CHAIN", "1")
