@@ -141,14 +141,19 @@ __global__ __launch_bounds__(64) void knz_lz_forward_par_kernel(LzParArgs pa) {
         const uint8_t* pa_ = src + max(refA, 0);
         const uint8_t* pb_ = src + max(refB, 0);
         const uint8_t* pc_ = cp8 + srcIdx;
-        uint64_t l0 = wave_sload_u64_async((const uint8_t*)((uintptr_t)pp & ~(uintptr_t)3));
-        uint32_t l1 = wave_sload_u32_async((const uint8_t*)(((uintptr_t)pp & ~(uintptr_t)3) + 8));
-        uint32_t l2 = wave_sload_u32_async(cand8 + 4 * (size_t)srcIdx);
-        uint32_t l3 = wave_sload_u32_async((const uint8_t*)((uintptr_t)pc_ & ~(uintptr_t)3));
-        uint64_t l4 = wave_sload_u64_async((const uint8_t*)((uintptr_t)pa_ & ~(uintptr_t)3));
-        uint64_t l5 = wave_sload_u64_async((const uint8_t*)((uintptr_t)pb_ & ~(uintptr_t)3));
-        uint32_t l6 = 0;
-        WAVE_SLOAD_WAIT7(l0, l1, l2, l3, l4, l5, l6);
+        const uint8_t* y0 = (const uint8_t*)((uintptr_t)pp & ~(uintptr_t)3);
+        const uint8_t* y2 = cand8 + 4 * (size_t)srcIdx;
+        const uint8_t* y3 = (const uint8_t*)((uintptr_t)pc_ & ~(uintptr_t)3);
+        const uint8_t* y4 = (const uint8_t*)((uintptr_t)pa_ & ~(uintptr_t)3);
+        const uint8_t* y5 = (const uint8_t*)((uintptr_t)pb_ & ~(uintptr_t)3);
+        uint64_t l0 = wave_sload_u64_async(y0);
+        uint32_t l1 = wave_sload_u32_async(y0 + 8);
+        uint32_t l2 = wave_sload_u32_async(y2);
+        uint32_t l3 = wave_sload_u32_async(y3);
+        uint64_t l4 = wave_sload_u64_async(y4);
+        uint64_t l5 = wave_sload_u64_async(y5);
+        WAVE_SLOAD_WAIT5A(l0, l2, l3, l4, l5, y0, y2, y3, y4, y5);
+        l1 = wave_pin_sgpr(l1);                                             // (issued with the others, valid behind the same wait)
         const uint32_t shp = ((uint32_t)(uintptr_t)pp & 3u) * 8u;
         const uint64_t p = shp ? ((l0 >> shp) | ((uint64_t)l1 << (64 - shp))) : l0;
         const int raw0 = (int)l2, cp0 = (int)((l3 >> (8 * ((uint32_t)(uintptr_t)pc_ & 3u))) & 0xFFu);

@@ -53,6 +53,10 @@ __device__ __forceinline__ uint32_t wave_in_vgpr(uint32_t x) { asm("" : "+v"(x))
 __device__ __forceinline__ uint64_t wave_sload_u64_async(const uint8_t* p) { uint64_t v; asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(v) : "s"(p) : "memory"); return v; }
 __device__ __forceinline__ uint32_t wave_sload_u32_async(const uint8_t* p) { uint32_t v; asm volatile("s_load_dword %0, %1, 0x0" : "=&s"(v) : "s"(p) : "memory"); return v; }
 #define WAVE_SLOAD_WAIT7(a, b, c, d, e, f, g) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e), "+s"(f), "+s"(g))
+// same, naming the address registers of the loads as well: they stay untouched until the wait (to the compiler the asm load has consumed its
+// address when it is issued, and it re-used the pair for the next address; the loads that were still in flight then read the wrong place)
+#define WAVE_SLOAD_WAIT5A(a, b, c, d, e, p0, p1, p2, p3, p4) \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e) : "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4))
 // pins a wave-uniform value in an SGPR at this point of the program: the (scalar) load that produces it is issued here, not sunk into the
 // branch that first uses it (several such loads in a row then share one s_waitcnt)
 __device__ __forceinline__ uint32_t wave_pin_sgpr(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
@@ -146,6 +150,7 @@ inline uint32_t wave_pin_sgpr(uint32_t x) { return x; }
 inline uint64_t wave_sload_u64_async(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 inline uint32_t wave_sload_u32_async(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 #define WAVE_SLOAD_WAIT7(a, b, c, d, e, f, g) do { } while (0)
+#define WAVE_SLOAD_WAIT5A(a, b, c, d, e, p0, p1, p2, p3, p4) do { } while (0)
 template <int L> inline uint32_t wave_writelane_c(uint32_t v, uint32_t val) { return hipemu::lane() == L ? val : v; }
 struct knz_u32x4 { uint32_t x, y, z, w; };
 inline uint32_t wave_sload_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
