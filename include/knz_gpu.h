@@ -34,7 +34,10 @@ enum {
  * with the magic number of a compressed format or whose order-0 entropy is >= 973/1024 are emitted as copy blocks */
 enum { KNZ_FLAG_SKIP_BLOCKS = 1 };
 
-/* transform ids, v2/transform/Factory.go:31-53 (6 bits each, first transform in bits 47..42) */
+/* transform ids, v2/transform/Factory.go:31-53 (6 bits each, first transform in bits 47..42). KNZ_T_TEXT is DICT_TYPE ("TEXT"): which of
+ * its two stream formats is written / read follows knz_cfg.entropy (Factory.go:100-120: NONE, HUFFMAN, RANGE, ANS0 -> the byte-oriented one),
+ * its hash size follows knz_cfg.block_size (TextCodec.go:610-650, :1137-1188), as ctx["entropy"] / ctx["blockSize"] do in the reference; the data
+ * type it detects (ctx["dataType"]) reaches the UTF and LZ stages behind it in the same sequence. */
 enum { KNZ_T_NONE = 0, KNZ_T_BWT = 1, KNZ_T_LZ = 3, KNZ_T_ZRLT = 6, KNZ_T_MTFT = 7, KNZ_T_RANK = 8, KNZ_T_TEXT = 10, KNZ_T_SRT = 13, KNZ_T_LZP = 14, KNZ_T_LZX = 16, KNZ_T_UTF = 17 };
 /* entropy ids, v2/entropy/EntropyCodecFactory.go:26-42 */
 enum { KNZ_E_NONE = 0, KNZ_E_HUFFMAN = 1, KNZ_E_FPAQ = 2, KNZ_E_ANS0 = 5, KNZ_E_ANS1 = 8 };

@@ -21,6 +21,9 @@ rank, world = dist.get_rank(), dist.get_world_size()
 entropy, bs, n = sys.argv[5], int(sys.argv[6]), int(sys.argv[7])
 transform = sys.argv[8]
 data = P.corpus(n, 5)
+if transform.startswith('TEXT'):
+    import text_corpus
+    data = text_corpus.make_text(n, seed=5, utf8=0.02)
 nblocks = (n + bs - 1) // bs
 lo_b, hi_b = kd.block_range(nblocks, rank, world)
 lo, hi = lo_b * bs, min(hi_b * bs, n)
@@ -54,7 +57,8 @@ print("rank", rank, "ok")
 @pytest.mark.parametrize("cfg", [("HUFFMAN", 1 << 16, 5 * (1 << 16) + 777, 2, "NONE"), ("ANS0", 1 << 16, 2 * (1 << 16) + 5, 2, "NONE"),
                                  ("HUFFMAN", 1 << 16, 1000, 2, "NONE"),
                                  ("ANS1", 1 << 14, 4 * (1 << 14) + 4321, 2, "BWT+RANK+ZRLT"),      # configs[3] pipeline, uneven last rank (3 + 2 blocks, ragged tail)
-                                 ("ANS1", 1 << 14, 2 * (1 << 14) + 99, 3, "BWT+RANK+ZRLT")])       # 3 blocks over 3 ranks, the last one 99 bytes
+                                 ("ANS1", 1 << 14, 2 * (1 << 14) + 99, 3, "BWT+RANK+ZRLT"),        # 3 blocks over 3 ranks, the last one 99 bytes
+                                 ("ANS0", 1 << 14, 4 * (1 << 14) + 321, 2, "TEXT+UTF+BWT+RANK+ZRLT")])   # the -l 5 sequence on text, 3 + 2 blocks
 def test_two_ranks_gloo(cfg, tmp_path):
     entropy, bs, n, world, transform = cfg
     import knz
