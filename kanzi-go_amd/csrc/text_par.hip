@@ -390,13 +390,13 @@ __device__ __forceinline__ bool knz_ts_word_ref_end(uint32_t kind, const uint8_t
 // what the byte at p (state s in front of it) does to the decoder's wordRun flag (:1062-1075, :1093): 1 = it ends a reference to a word
 // (the flag is set), 2 = it is or ends an item that clears the flag (a literal that is not a letter, an escaped literal, a reference to a
 // one-letter escape entry), 0 = nothing (letters leave the flag alone; so do bytes inside an item)
-__device__ __forceinline__ uint32_t knz_ts_event(uint32_t kind, const uint8_t* src, uint32_t s, uint32_t c, int p) {
+__device__ __forceinline__ uint32_t knz_ts_event(uint32_t kind, uint32_t s, uint32_t c, uint32_t prev1, uint32_t prev2) {   // prev1 / prev2: the bytes at p - 1 / p - 2
     if (kind == 1) {
         if (s == 0) return (c == 0x0F || c == 0x0E || knz_tc_is_text(c)) ? 0u : 2u;
         if (s == 1) return c < 128 ? 1u : 0u;
         uint32_t idx;
-        if (s == 2) { if (c >= 128) return 0u; idx = (((uint32_t)src[p - 1] & 0x7F) << 7) | c; }
-        else idx = (((((uint32_t)src[p - 2] & 0x1F) << 7) | ((uint32_t)src[p - 1] & 0x7F)) << 7) | c;
+        if (s == 2) { if (c >= 128) return 0u; idx = ((prev1 & 0x7F) << 7) | c; }
+        else idx = ((((prev2 & 0x1F) << 7) | (prev1 & 0x7F)) << 7) | c;
         return (idx == KNZ_TC_STATIC || idx == KNZ_TC_STATIC + 1) ? 2u : 1u;
     }
     if (s == KNZ_TS_N) {
@@ -421,9 +421,23 @@ __device__ __forceinline__ int knz_tsp_word_len(uint32_t kind, const uint8_t* sr
     return (len >= 3 && len <= 31) ? len : 0;
 }
 
+// f(byte, position) for the bytes of [lo, hi) in order, 8 bytes per load: 1024 threads that each walk a stretch of their own touch 64 different
+// lines per load instruction, so the number of load instructions is what the walk costs
+template <typename F>
+__device__ __forceinline__ void knz_tsp_walk(const uint8_t* src, int lo, int hi, F f) {
+    int p = lo;
+    for (; p + 8 <= hi; p += 8) {
+        const uint64_t w = knz_vle64(src + p);
+#pragma unroll
+        for (int k = 0; k < 8; k++) f((uint32_t)(w >> (8 * k)) & 0xFFu, p + k);
+    }
+    for (; p < hi; p++) f((uint32_t)src[p], p);
+}
+
 __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_inverse_par_kernel(TextParArgs pa) {
     __shared__ uint32_t s_w[KNZ_TCP_THREADS / 64];
     __shared__ uint32_t s_flag;
+    __shared__ uint32_t s_txt[2 + 2 * 64 + 2];                               // literal-letter flags of a tile behind the last mask of the previous tile
     __shared__ uint16_t s_map[KNZ_TCP_THREADS];
     __shared__ uint8_t s_start[KNZ_TCP_THREADS];
     const TextArgs& a = pa.a;
@@ -448,19 +462,20 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_inverse_par_kernel(T
     if (tid == 0) s_flag = 0;
 
     // ---- phase I: parser state in front of every byte ------------------------------------------------------------------------------
+    KNZ_TCP_STAMP(0);
     const int seg = (m - 1 + KNZ_TCP_THREADS - 1) / KNZ_TCP_THREADS;
     const int lo = min(m, 1 + (int)tid * seg), hi = min(m, lo + seg);
     {
         uint32_t v0 = 0, v1 = 1, v2 = 2, v3 = 3, v4 = 4;                     // where each start state has got to
-        for (int p = lo; p < hi; p++) {
-            const uint32_t c = src[p];
-            v0 = knz_ts_next(kind, v0, c); v1 = knz_ts_next(kind, v1, c); v2 = knz_ts_next(kind, v2, c); v3 = knz_ts_next(kind, v3, c); v4 = knz_ts_next(kind, v4, c);
-            if ((v0 == v1) & (v1 == v2) & (v2 == v3) & (v3 == v4)) {          // the start state no longer matters: one walk for the rest
-                for (p++; p < hi; p++) v0 = knz_ts_next(kind, v0, src[p]);
-                v1 = v2 = v3 = v4 = v0;
-                break;
+        bool merged = false;                                                 // the start state no longer matters: one walk for the rest
+        knz_tsp_walk(src, lo, hi, [&](uint32_t c, int) {
+            v0 = knz_ts_next(kind, v0, c);
+            if (!merged) {
+                v1 = knz_ts_next(kind, v1, c); v2 = knz_ts_next(kind, v2, c); v3 = knz_ts_next(kind, v3, c); v4 = knz_ts_next(kind, v4, c);
+                merged = (v0 == v1) & (v1 == v2) & (v2 == v3) & (v3 == v4);
             }
-        }
+        });
+        if (merged) v1 = v2 = v3 = v4 = v0;
         s_map[tid] = (uint16_t)(v0 | (v1 << 3) | (v2 << 6) | (v3 << 9) | (v4 << 12));
     }
     __syncthreads();
@@ -470,9 +485,15 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_inverse_par_kernel(T
         if (s != KNZ_TS_N) s_flag = 1;                                       // the block ends inside an item
     }
     __syncthreads();
+    const uint32_t pv1 = lo >= 1 ? src[lo - 1] : 0u, pv2 = lo >= 2 ? src[lo - 2] : 0u;   // the two bytes in front of the stretch (index bytes of a reference that straddles it)
     {   // wordRun in front of every byte: the last setter / clearer wins, letters pass it on (so it can reach across any number of them)
-        uint32_t s = s_start[tid], ev = 0;
-        for (int p = lo; p < hi; p++) { const uint32_t c = src[p]; const uint32_t e = knz_ts_event(kind, src, s, c, p); ev = e ? e : ev; s = knz_ts_next(kind, s, c); }
+        uint32_t s = s_start[tid], ev = 0, p1 = pv1, p2 = pv2;
+        knz_tsp_walk(src, lo, hi, [&](uint32_t c, int) {
+            const uint32_t e = knz_ts_event(kind, s, c, p1, p2);
+            ev = e ? e : ev;
+            s = knz_ts_next(kind, s, c);
+            p2 = p1; p1 = c;
+        });
         s_map[tid] = (uint16_t)ev;
     }
     __syncthreads();
@@ -482,38 +503,82 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_inverse_par_kernel(T
     }
     __syncthreads();
     {
-        uint32_t s = s_start[tid] & 7u, wr = s_start[tid] >> 3;
-        for (int p = lo; p < hi; p++) {
-            const uint32_t c = src[p];
-            st[p] = (uint8_t)(s | (wr << 3));
-            const uint32_t e = knz_ts_event(kind, src, s, c, p);
+        uint32_t s = s_start[tid] & 7u, wr = s_start[tid] >> 3, p1 = pv1, p2 = pv2;
+        uint64_t acc = 0;                                                    // 8 state bytes per store
+        knz_tsp_walk(src, lo, hi, [&](uint32_t c, int p) {
+            const uint32_t v = s | (wr << 3);
+            const int k = (p - lo) & 7;
+            acc |= (uint64_t)v << (8 * k);
+            if (k == 7) { ((KnzPacked64*)(st + p - 7))->v = acc; acc = 0; }
+            const uint32_t e = knz_ts_event(kind, s, c, p1, p2);
             wr = e ? (e == 1 ? 1u : 0u) : wr;
             s = knz_ts_next(kind, s, c);
-        }
+            p2 = p1; p1 = c;
+        });
+        const int rest = (hi - lo) & 7;                                      // the last < 8 states of the stretch
+        for (int k = 0; k < rest; k++) st[hi - rest + k] = (uint8_t)(acc >> (8 * k));
         if (tid == 0) st[0] = 7;
     }
     __syncthreads();
     if (s_flag) { if (tid == 0) { a.ok[b] = -KNZ_ERR_PROCESS_BLOCK; a.out_len[b] = 0; a.tmode[b] = -3; } return; }
 
     // ---- phase II: literal words ------------------------------------------------------------------------------------------------------
+    KNZ_TCP_STAMP(1);
+    // As in the forward kernel: tile of 4096 positions, thread tid looks at positions base + 1024 j + tid, one ballot per wave and j = the
+    // "literal letter" flags (a letter read in the normal state) of 64 consecutive positions, kept in LDS behind the last mask of the tile before.
     uint32_t nt = 0;
+    if (tid < 2) s_txt[tid] = 0;
     for (int base = 0; base < m; base += 4 * KNZ_TCP_THREADS) {
-        const int p0 = base + 4 * (int)tid;
-        int wl[4], ws[4];
-        uint32_t c = 0;
-        for (int j = 0; j < 4; j++) { ws[j] = 0; wl[j] = (p0 + j < m && p0 + j >= 1) ? knz_tsp_word_len(kind, src, st, p0 + j, ws[j]) : 0; c += wl[j] ? 1u : 0u; }
-        uint32_t tot;
-        uint32_t t = nt + knz_wg_scan_excl(c, s_w, tot);
+        uint32_t cur[4], stv[4];
         for (int j = 0; j < 4; j++) {
-            if (!wl[j]) continue;
-            const int n = wl[j];
-            const uint8_t* w = src + ws[j];
-            uint32_t h1 = KNZ_TC_HASH1;
-            for (int q = 0; q < n; q++) h1 = knz_tc_hash_step(h1, w[q]);
-            k.tok_end[t] = (uint32_t)(ws[j] + n); k.len[t] = (uint8_t)n; k.h1[t] = h1; k.ins[t] = 0; k.h2[t] = (uint32_t)(p0 + j);   // h2: the delimiter's position
-            t++;
+            const int p = base + j * KNZ_TCP_THREADS + (int)tid;
+            cur[j] = p < m ? src[p] : 0u;
+            stv[j] = p < m ? st[p] : 7u;
+            const uint64_t mk = wave_ballot(p < m && (stv[j] & 7u) == KNZ_TS_N && knz_tc_is_text(cur[j]));
+            if ((tid & 63) == 0) { const uint32_t wi = 2 + 2 * (uint32_t)(j * (KNZ_TCP_THREADS / 64) + (tid >> 6)); s_txt[wi] = (uint32_t)mk; s_txt[wi + 1] = (uint32_t)(mk >> 32); }
         }
-        nt += tot;
+        __syncthreads();
+        int wl[4], ws[4];
+        uint32_t c012 = 0, c3 = 0;
+        for (int j = 0; j < 4; j++) {
+            const int idx = j * KNZ_TCP_THREADS + (int)tid, e = base + idx;
+            wl[j] = 0; ws[j] = 0;
+            if (e < m && e >= 1 && (stv[j] & 7u) == KNZ_TS_N && !knz_tc_is_text(cur[j]) && knz_tc_is_delim(cur[j])) {
+                // flags of the 33 positions in front of e (bit 32 = position e - 1): a run of 33 is too long whatever comes in front of it
+                const uint32_t lo33 = 64u + (uint32_t)idx - 33u, wq = lo33 >> 5, sh = lo33 & 31u;
+                const uint64_t two = ((uint64_t)s_txt[wq + 1] << 32) | s_txt[wq];
+                uint64_t win = two >> sh;
+                if (sh) win |= (uint64_t)s_txt[wq + 2] << (64 - sh);
+                win &= 0x1FFFFFFFFull;
+                const int run = (int)__clzll((long long)~(win << 31));             // leading ones from bit 32 down
+                if (run >= 3 && run <= 32) {
+                    int a0 = e - run;
+                    if (knz_ts_word_ref_end(kind, src, st, a0 - 1)) a0++;         // delimAnchor sits one byte behind a word reference (:1070)
+                    const int n = e - a0;
+                    if (n >= 3 && n <= 31) { wl[j] = n; ws[j] = a0; }
+                }
+            }
+            if (j < 3) c012 += (wl[j] ? 1u : 0u) << (11 * j); else c3 = wl[j] ? 1u : 0u;
+        }
+        uint32_t tot012, tot3;
+        const uint32_t e012 = knz_wg_scan_excl(c012, s_w, tot012), e3 = knz_wg_scan_excl(c3, s_w, tot3);
+        const uint32_t tj[4] = {tot012 & 0x7FFu, (tot012 >> 11) & 0x7FFu, (tot012 >> 22) & 0x7FFu, tot3};
+        uint32_t first = nt;
+        for (int j = 0; j < 4; j++) {
+            if (wl[j]) {
+                const uint32_t t = first + (j < 3 ? (e012 >> (11 * j)) & 0x7FFu : e3);
+                const int n = wl[j];
+                const uint8_t* w = src + ws[j];
+                uint32_t h1 = KNZ_TC_HASH1;
+                for (int q = 0; q < n; q++) h1 = knz_tc_hash_step(h1, w[q]);
+                k.tok_end[t] = (uint32_t)(ws[j] + n); k.len[t] = (uint8_t)n; k.h1[t] = h1; k.ins[t] = 0;
+                k.h2[t] = (uint32_t)(base + j * KNZ_TCP_THREADS + (int)tid);          // h2: the delimiter's position
+            }
+            first += tj[j];
+        }
+        nt = first;
+        if (tid < 2) s_txt[tid] = s_txt[2 + 2 * 63 + tid];
+        __syncthreads();
     }
     for (uint32_t s = tid; s < nslots; s += KNZ_TCP_THREADS) k.owner[s] = KNZ_TCP_NIL;
     __syncthreads();
@@ -528,6 +593,7 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_inverse_par_kernel(T
     for (uint32_t t = tid; t < nt; t += KNZ_TCP_THREADS) { const uint32_t slot = k.h1[t] & k.mask; k.ins[t] = (slot && k.owner[slot] == (int)t) ? 1 : 0; }
     __syncthreads();
     // ---- phase III: entries ------------------------------------------------------------------------------------------------------------
+    KNZ_TCP_STAMP(2);
     bool settled = false;
     uint32_t madeLast = 0;
     for (int round = 0; round < KNZ_TCP_MAX_ROUNDS && !settled; round++) {
@@ -554,6 +620,8 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_inverse_par_kernel(T
     if (!settled || (uint32_t)k.staticSize + madeLast >= KNZ_TC_MAX_DICT) return;       // the chain kernel takes the block
 
     // ---- phase IV: items -> bytes ------------------------------------------------------------------------------------------------------
+    KNZ_TCP_STAMP(3);
+    if (pa.prof && tid == 0) pa.prof[(size_t)b * 8 + 7] = nt;
     const bool crlf = (src[0] & 0x40) != 0;
     uint64_t outPos = 0;
     bool bad = false;
@@ -640,6 +708,7 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_inverse_par_kernel(T
     __syncthreads();
     if (bad) s_flag = 1;
     __syncthreads();
+    KNZ_TCP_STAMP(4);
     if (tid == 0) {
         const bool err = s_flag != 0 || (int64_t)outPos > dstEnd;
         a.ok[b] = err ? -KNZ_ERR_PROCESS_BLOCK : 1;
