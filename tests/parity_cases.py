@@ -707,7 +707,7 @@ def text_inputs(n=200_000):
 
 
 TEXT_STREAMS = (("TEXT", "NONE"), ("TEXT", "ANS1"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT+BWT+RANK+ZRLT", "ANS1"), ("TEXT+UTF", "HUFFMAN"),
-                ("UTF+TEXT", "ANS0"), ("TEXT+TEXT", "FPAQ"))
+                ("UTF+TEXT", "ANS0"), ("TEXT+TEXT", "FPAQ"), ("TEXT+UTF+BWT+SRT+ZRLT", "FPAQ"))      # the last one = the reference's -l 6 sequence
 
 
 def check_text(be, n=200_000, chain=False, streams=TEXT_STREAMS, bs_stream=1 << 16):
