@@ -93,6 +93,8 @@ int knz_decode_blocks(void* handle, knz_block* blocks, int n);
  * DEVICE pointers. Produces/consumes the complete .knz stream (header :429-519, blocks, end marker
  * :593-594). hip_stream is a hipStream_t (NULL = the handle's own stream). out_bytes is a host pointer.
  * header_input_size is ctx["fileSize"] written to the stream header (0 = unknown).
+ * Compressed streams are read as big-endian 32-bit words: d_src of the decode calls (and d_dst of the encode calls) must be 4-byte aligned
+ * and readable / writable up to the next multiple of 4 bytes behind n_bytes / dst_cap.
  */
 int knz_dev_compress(void* handle, const void* d_src, uint64_t n, int64_t header_input_size,
                      void* d_dst, uint64_t dst_cap, uint64_t* out_bytes, void* hip_stream);
