@@ -113,6 +113,14 @@ def test_full_size_config4_bwt_ans1(be):
     _full_size_stream(be, "BWT+RANK+ZRLT", "ANS1", 8 << 20, bench_corpus.s_silesia())
 
 
+@pytest.mark.timeout(900)
+def test_full_size_preset_l5(be):
+    """The reference's -l 5 preset at full size: -t TEXT+UTF+BWT+RANK+ZRLT -e ANS0 -b 4m on S-silesia (51 blocks; the TEXT stage applies to
+    the text members, declines with a data type on the others, UTF sees both outcomes)."""
+    import bench_corpus
+    _full_size_stream(be, "TEXT+UTF+BWT+RANK+ZRLT", "ANS0", 4 << 20, bench_corpus.s_silesia())
+
+
 @pytest.mark.timeout(1500)
 def test_config5_block_size_32m_fpaq(be):
     """BASELINE.json configs[4]'s block size: one 32 MiB block and a ragged second one of S-enwik through BWT+RANK+ZRLT / FPAQ
