@@ -46,6 +46,20 @@ int knzo_entropy_decode(uint32_t type, const uint8_t* bits, uint64_t nbytes, uin
     KNZO_CATCH
 }
 
+// DefaultOutputBitStream / DefaultInputBitStream on one small case: optional bit in front, WriteArray(arr, nbits), Close(), then ReadBits(read_len)
+// (the shape of bitstream/DefaultBitstream_test.go:476-528, whose expected values pin the bit order of a partial last byte)
+int knzo_bitstream_case(int prefix_bit, const uint8_t* arr, uint64_t nbits, uint32_t read_len, uint64_t* out) {
+    KNZO_TRY
+    BitWriter obs;
+    if (prefix_bit >= 0) obs.writeBit(prefix_bit);
+    obs.writeArray(arr, nbits);
+    obs.close();
+    BitReader ibs(obs.buf.data(), obs.buf.size());
+    *out = ibs.readBits(read_len);
+    return 0;
+    KNZO_CATCH
+}
+
 // ctx["blockSize"] / ctx["entropy"] of the calling thread for the single-object and single-block entry points below (the stream entry points
 // set them from their own arguments); block_size 0 / entropy 0xFFFFFFFF = key absent. Read by the TEXT transform only.
 int knzo_set_ctx(uint32_t block_size, uint32_t entropy_type) { tlsBlockSize = block_size; tlsEntropyType = entropy_type; return 0; }

@@ -483,3 +483,16 @@ def test_corrupt_stream_is_rejected():
     c[len(c) // 2] ^= 0x01  # payload: block checksum (or a codec sanity check) must catch it
     with pytest.raises(O.OracleError):
         O.decompress(bytes(c), len(data) + 16)
+
+
+def test_bitstream_partial_tail_cases_of_the_reference():
+    """bitstream/DefaultBitstream_test.go:476-528 TestBitStreamWriteArrayPartialTail: the two cases with their expected values
+    (aligned: WriteArray([0xAA], 1) reads back 1 in 1 bit; misaligned: WriteBit(0) + WriteArray([0xA0], 3) reads back 0b0101 in 4 bits)."""
+    import ctypes as C
+    L = O.lib()
+    L.knzo_bitstream_case.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+    for prefix, src, count, want, want_len in ((-1, 0xAA, 1, 0x1, 1), (0, 0xA0, 3, 0x5, 4)):
+        arr = (C.c_uint8 * 1)(src)
+        out = C.c_uint64()
+        assert L.knzo_bitstream_case(prefix, arr, count, want_len, C.byref(out)) == 0
+        assert out.value == want
