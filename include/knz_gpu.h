@@ -146,7 +146,8 @@ int knz_last_kernel_times(void* handle, char* names, int names_cap, float* ms, i
 /* Diagnostic counters of the last device batch. KNZ_COUNTER_HUF_SERIAL_CHUNKS: Huffman chunks the wave-parallel decoder
  * handed back to the serial (reference-order) decoder; 0 for any stream a kanzi encoder wrote. Returns 0 or an error code. */
 enum { KNZ_COUNTER_HUF_SERIAL_CHUNKS = 0, KNZ_COUNTER_POST_TRANSFORM_BYTES = 1 /* entropy coder input of the last encode batch */,
-       KNZ_COUNTER_TEXT_CHAIN_BLOCKS = 2 /* blocks of the last TEXT stage scanned by the one-lane kernel instead of the parallel one */ };
+       KNZ_COUNTER_TEXT_CHAIN_BLOCKS = 2 /* blocks of the last TEXT stage scanned by the one-lane kernel instead of the parallel one */,
+       KNZ_COUNTER_LZ_INV_SERIAL_BLOCKS = 3 /* blocks of the last LZ / LZX inverse stage decoded by the one-wave kernel instead of the parallel one */ };
 int knz_last_counter(void* handle, int id, uint64_t* value);
 
 /* 1 when a transform/entropy id has a device implementation in this build */

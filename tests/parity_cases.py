@@ -335,6 +335,72 @@ def check_transform(be, tname, max_len=1 << 30):
     c.close()
 
 
+def lz_inverse_inputs(big=False):
+    """Inputs whose LZ form carries every kind of length record: literal runs of 7+, 261+ and 65797+ bytes (1, 3 and 4 extension bytes,
+    LZCodec.go:193-212), match lengths that need 1- and 3-byte extensions, long chains of repeat distances, overlapping matches."""
+    rng = np.random.default_rng(99)
+    rnd = rng.integers(0, 256, 70100, dtype=np.uint8).tobytes()
+    yield "lit4", rnd + rnd[1000:31000] + bytes(70000) + corpus(30000)
+    yield "lit3", rnd[:300] + rnd[:300] + rnd[300:2000] + rnd[100:1500] + bytes(600) + rnd[2000:2300] * 7
+    per = rnd[:37]
+    yield "periodic", per * 4000 + rnd[:64] + per * 100 + bytes([1, 2, 3]) * 5000
+    rec = bytearray(corpus(400))
+    out = bytearray()
+    for i in range(600 if big else 150):                                       # records with small edits: repeat distances all the time
+        r = bytearray(rec)
+        r[int(rng.integers(0, 400))] = int(rng.integers(0, 256))
+        out += r
+    yield "records", bytes(out)
+    yield "text", corpus(600000 if big else 90000, seed=5)
+
+
+def check_lz_inverse_forms(be, monkeypatch, big=False):
+    """LZ / LZX inverse: the parallel form (lz_inv_par.hip, default) and the one-wave kernel (lz.hip, KNZ_LZ_INV_CHAIN) against the oracle's
+    forward output; well-formed blocks never reach the one-wave kernel (KNZ_COUNTER_LZ_INV_SERIAL_BLOCKS), damaged ones do and both
+    forms agree with the oracle on error-or-bytes."""
+    c = K.Codec("NONE", "NONE", 1 << 20, lib=be.lib)
+    rng = np.random.default_rng(5)
+    for tname in ("LZ", "LZX"):
+        t = K.ByteTransform(c, tname)
+        tid = _TID[tname]
+        for name, data in lz_inverse_inputs(big):
+            o = O.transform_forward(tid, data)
+            assert o is not None, (tname, name)
+            cap = len(data) + max(512, len(data) >> 4)
+            monkeypatch.delenv("KNZ_LZ_INV_CHAIN", raising=False)
+            assert t.inverse(o, cap) == data, (tname, name, "parallel")
+            assert c.last_counter(3) == 0, (tname, name)
+            monkeypatch.setenv("KNZ_LZ_INV_CHAIN", "1")
+            assert t.inverse(o, cap) == data, (tname, name, "one wave")
+            assert c.last_counter(3) == 1, (tname, name)
+            monkeypatch.delenv("KNZ_LZ_INV_CHAIN")
+            # damaged: flip bytes in the header / token / distance / length regions
+            for trial in range(6 if not big else 2):
+                bad = bytearray(o)
+                for _ in range(int(rng.integers(1, 4))):
+                    pos = int(rng.integers(0, 13)) if trial == 0 else int(rng.integers(0, len(bad)))
+                    bad[pos] ^= 1 << int(rng.integers(0, 8))
+                try:
+                    exp = O.transform_inverse(tid, bytes(bad), cap)
+                except O.OracleError:
+                    exp = None
+                got = []
+                for env in (None, "1"):
+                    if env:
+                        monkeypatch.setenv("KNZ_LZ_INV_CHAIN", env)
+                    try:
+                        got.append(t.inverse(bytes(bad), cap))
+                    except K.KnzError:
+                        got.append(None)
+                    monkeypatch.delenv("KNZ_LZ_INV_CHAIN", raising=False)
+                assert got[0] == got[1], (tname, name, trial, "the two device forms disagree on a damaged block")
+                if exp is None or got[0] is None:
+                    assert exp is None or got[0] is None or got[0] == exp
+                else:
+                    assert got[0] == exp, (tname, name, trial)
+    c.close()
+
+
 def check_rank_chain_variants(be, monkeypatch, max_len=1 << 30, bwt_len=150000):
     """Inverse RANK chain (rank_inv.hip): every kept variant of the step x the packed / three-register forms (the latter is
     what blocks > 8 MiB use), on inputs with ranks >= 64, all-zero words, ragged tails; against the oracle's forward."""

@@ -131,6 +131,11 @@ def test_ans1_encode_in_groups(be, monkeypatch):
     P.check_stream(be, "BWT+RANK+ZRLT", "ANS1", 1 << 14, 5 * (1 << 14) + 33)
 
 
+def test_lz_inverse_forms(be, monkeypatch):
+    """Parallel LZ inverse (token scans + source map, lz_inv_par.hip) and the one-wave kernel it leaves damaged blocks to."""
+    P.check_lz_inverse_forms(be, monkeypatch)
+
+
 def test_lz_first_form(be, monkeypatch):
     """KNZ_LZ_CHAIN: the parse that keeps its own hash table (lz.hip), the cross-check of the table-free form that runs by default."""
     monkeypatch.setenv("KNZ_LZ_CHAIN", "1")
