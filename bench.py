@@ -77,6 +77,8 @@ KERNEL_BYTES = {
     "knz_fpaq_encode_kernel": lambda n, m, c: m + c, "knz_fpaq_decode_kernel": lambda n, m, c: c + m,
     "knz_fpaq_probs_kernel": lambda n, m, c: m, "knz_fpaq_code_kernel": lambda n, m, c: m + c,
     "knz_lz_forward_kernel": lambda n, m, c: n + m, "knz_lz_inverse_kernel": lambda n, m, c: m + n,
+    "knz_lz_forward_par_kernel": lambda n, m, c: n + m, "knz_lzi_litext_chain_kernel": lambda n, m, c: m, "knz_lzi_jump_kernel": lambda n, m, c: 2 * n,
+    "knz_lzi_map_kernel": lambda n, m, c: m + n, "knz_lzi_gather_kernel": lambda n, m, c: m + n, "knz_lzi_b_apply_kernel": lambda n, m, c: m,
     "knz_lz_parse_kernel": lambda n, m, c: n + m, "knz_lz_candidates_kernel": lambda n, m, c: n,
     "knz_lzp_forward_kernel": lambda n, m, c: n + m, "knz_lzp_inverse_kernel": lambda n, m, c: m + n,
     "knz_srt_inverse_kernel": lambda n, m, c: 2 * n,
@@ -415,7 +417,8 @@ def main():
             roof.update({"kernel": dom, "achieved": round(ach, 3), "frac": round(ach / HBM_PEAK_GBS, 6),
                          "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
                          "timing": "HIP events around the kernel's launches on the launch stream (knz_last_kernel_times)",
-                         "kernel_ms_per_step": {k: round(v / K_, 3) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])[:12]}})
+                         "kernel_ms_per_step": {k: round(v / K_, 3) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])[:12]},
+                         "kernel_launches_per_step": {k: round(kern_launches[k] / K_, 2) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])[:12]}})
             if not args.no_pmc and world == 1 and not emu:
                 child = ["--config", args.config, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-verify", "--no-pmc", "--no-host-hook"]
                 for flag, val in (("--size", args.size), ("--block-size", args.block_size)):

@@ -13,6 +13,7 @@
 #include "lz.hip"
 #include "lz_par.hip"
 #include "lz_inv_par.hip"
+#include "lz_fwd_seg.hip"
 #include "srt_lzp.hip"
 #include "text.hip"
 #include "text_par.hip"
@@ -236,7 +237,7 @@ extern "C" int knz_last_kernel_times(void* handle, char* names, int names_cap, f
 
 extern "C" int knz_last_counter(void* handle, int id, uint64_t* value) {
     Handle* h = (Handle*)handle;
-    if (!h || !value || id < KNZ_COUNTER_HUF_SERIAL_CHUNKS || id > KNZ_COUNTER_LZ_INV_SERIAL_BLOCKS) return KNZ_ERR_INVALID_PARAM;
+    if (!h || !value || id < KNZ_COUNTER_HUF_SERIAL_CHUNKS || id > KNZ_COUNTER_LZ_FWD_ROUNDS) return KNZ_ERR_INVALID_PARAM;
     DeviceGuard dg(h);
     *value = 0;
     if (id == KNZ_COUNTER_POST_TRANSFORM_BYTES) { *value = h->post_bytes; return KNZ_OK; }
@@ -244,6 +245,16 @@ extern "C" int knz_last_counter(void* handle, int id, uint64_t* value) {
         uint32_t v = 0;
         if (h->text_cnt.p && hipMemcpy(&v, h->text_cnt.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return KNZ_ERR_UNKNOWN;
         *value = v;
+        return KNZ_OK;
+    }
+    if (id == KNZ_COUNTER_LZ_FWD_ROUNDS) { *value = h->lzs_rounds; return KNZ_OK; }
+    if (id == KNZ_COUNTER_LZ_FWD_SERIAL_BLOCKS) {
+        if (h->lzs_n == 0) return KNZ_OK;
+        std::vector<uint8_t> f(h->lzs_n);
+        if (hipMemcpy(f.data(), h->lzs_misc.p, f.size(), hipMemcpyDeviceToHost) != hipSuccess) return KNZ_ERR_UNKNOWN;
+        uint64_t n = 0;
+        for (uint8_t v : f) n += v == 2 ? 1 : 0;
+        *value = n;
         return KNZ_OK;
     }
     if (id == KNZ_COUNTER_LZ_INV_SERIAL_BLOCKS) {

@@ -1,0 +1,515 @@
+// LZ / LZX forward, third form: the parse of lz_par.hip cut into segments that run side by side (LZXCodec.Forward,
+// v2/transform/LZCodec.go:249-591).
+//
+// What the sequential parse carries from one position to the next is small: (srcIdx, anchor, repd[0], repd[1], repdIdx, srcInc)
+// (:316-324) and which of the earlier positions were jumped over by the miss acceleration (:356-358) and never hashed ("holes";
+// every other position's table entry is a function of the data: cand[] / cp8[] of lz_par.hip). It is also causal, and it forgets:
+// behind a match srcInc is 0, repdIdx is 1, anchor = srcIdx, and two parses that emit the same two matches in a row agree on
+// everything. So every segment of KNZ_LZS_SEG positions is parsed by a wave of its own from a GUESSED entry state, and the guesses
+// are iterated to the fixed point "entry state of a segment = exit state of the one in front of it, holes read = holes written":
+//   round:  parse the segments whose entry state is new (all of them in a block with holes) [knz_lzs_parse_kernel]
+//           new entry states: a sequential walk over the segments' (entry used, exit) pairs  [knz_lzs_relink_kernel]
+//           did the hole maps change?                                                       [knz_lzs_compare_kernel]
+// The first segment is exact in round 1, so segment k is exact after round k + 1 at the latest; in practice a trace started from a
+// wrong state meets the true one after a match or two and a block settles in 3-5 rounds. A fixed point IS the sequential parse (by
+// induction over the segments: exact entry state, exact holes in front of it), and only a fixed point is ever emitted; a block
+// that has not settled after KNZ_LZS_MAX_ROUNDS goes to the one-wave kernel of lz_par.hip (counter KNZ_COUNTER_LZ_FWD_SERIAL_BLOCKS).
+// Details that keep it exact:
+//   * a parse leaves its segment only when it is not skipping (srcInc < 64): a long stretch without matches is walked by ONE wave
+//     with the reference's growing stride (a 4 MiB stretch is ~23 K steps), the segments it runs over have nothing to do;
+//   * holes are two set-only bit maps, J (jumped over) and M (inside a later match: hashed again, :517-553), hole = J & ~M, so
+//     that no clear can race with a set; a segment reads its own generation for the positions it has passed itself and the
+//     previous round's maps for everything in front of its entry anchor;
+//   * tokens are written as descriptors (literal start, literal length, match length, distance, flag bits); literals, token bytes,
+//     distances and length extensions are laid out afterwards by prefix sums over all tokens of the block [knz_lzs_emit_*].
+#pragma once
+#include "bits.h"
+
+#define KNZ_LZS_SEG 16384u
+#define KNZ_LZS_MAX_ROUNDS 48
+#define KNZ_LZS_NEVER 0xFFFFFFFFu
+
+struct LzSegArgs {
+    LzParArgs pa;                  // source blocks, cand[], cp8[] (pa.holes unused here)
+    uint32_t seg_size, segs;       // positions per segment, segments per block covered by the grid
+    uint32_t tok_cap;              // token descriptors per segment
+    uint32_t* entry;               // [nblocks][segs][5] srcIdx, anchor, repd0, repd1, srcInc | repdIdx << 31
+    uint32_t* used;                // the entry state the segment's last parse started from (srcIdx = KNZ_LZS_NEVER: none yet)
+    uint32_t* exit_;               // what that parse ended with
+    uint32_t* ntok;                // [nblocks][segs]
+    uint8_t* need;                 // [nblocks][segs] parse in this round
+    uint4* tok;                    // [nblocks][segs][tok_cap] {literal start, literal length, match length | flag << 24, distance}
+    uint32_t* Jp; uint32_t* Mp; uint32_t* Jn; uint32_t* Mn;     // hole maps of the previous / this round, [nblocks][map_stride]
+    uint32_t* Cp; uint32_t* Cn;    // coarse maps [nblocks][2048]: the region holds (or held) jumped-over positions
+    uint32_t* Sp; uint32_t* Sn;    // [nblocks][2] any jumped-over position, the largest one
+    uint64_t map_stride;
+    uint8_t* blk_state;            // [nblocks] 0 running, 1 settled, 2 left to the one-wave kernel, 3 not a block for this stage, 4 declined before any parse (answered by the one-wave kernel)
+    uint32_t* blk_flags;           // [nblocks][4] round results: entries changed, maps changed, rounds taken
+};
+
+__device__ __forceinline__ void knz_lzs_geom(const LzArgs& a, uint32_t b, int count, int& srcEnd, int& maxDist, int& minMatch, uint32_t& flag, bool& decline) {
+    srcEnd = count - 16 - 2;
+    maxDist = KNZ_LZ_MAX_DIST2; flag = 1;
+    if (srcEnd < 4 * KNZ_LZ_MAX_DIST1) { maxDist = KNZ_LZ_MAX_DIST1; flag = 0; }
+    const uint32_t dt = a.blk_dt ? a.blk_dt[b] : 0u;
+    decline = dt == 9u;                                                   // DT_SMALL_ALPHABET (:306-308)
+    minMatch = dt == 6u /* DT_DNA */ ? 6 : 4;
+    flag |= ((minMatch - 2) & 7) << 1;
+}
+
+// one thread per block: does the block take part, initial entry states
+__global__ __launch_bounds__(64) void knz_lzs_init_kernel(LzSegArgs g) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const LzArgs& a = g.pa.a;
+    if (b >= a.nblocks) return;
+    g.blk_flags[4 * b] = g.blk_flags[4 * b + 1] = g.blk_flags[4 * b + 2] = g.blk_flags[4 * b + 3] = 0;
+    g.Sp[2 * b] = g.Sp[2 * b + 1] = g.Sn[2 * b] = g.Sn[2 * b + 1] = 0;
+    uint8_t st = 3;
+    if (a.active[b]) {
+        const int count = (int)a.in_len[b];
+        const uint32_t maxEnc = count <= 1024 ? (uint32_t)count + 16 : (uint32_t)count + (uint32_t)count / 64;   // MaxEncodedLen :935-941
+        int srcEnd, maxDist, minMatch; uint32_t flag; bool decline;
+        knz_lzs_geom(a, b, count, srcEnd, maxDist, minMatch, flag, decline);
+        // blocks the stage declines before it parses anything (:256-263, :306-308) are answered by the one-wave kernel
+        st = (a.out_cap < maxEnc || count < KNZ_LZ_MIN_BLOCK || decline) ? 4 : ((((uintptr_t)a.in_ptr[b]) & 3) != 0 ? 2 : 0);
+        if (st == 0) {
+            const uint32_t ns = srcEnd > 0 ? ((uint32_t)srcEnd + g.seg_size - 1) / g.seg_size : 0;
+            for (uint32_t s = 0; s < g.segs; s++) {
+                const size_t si = (size_t)b * g.segs + s;
+                uint32_t* e = g.entry + 5 * si;
+                // first guess: the state right behind a match that ended at the segment start, repeat distances unknown
+                e[0] = s * g.seg_size; e[1] = s * g.seg_size; e[2] = (uint32_t)count; e[3] = (uint32_t)count; e[4] = s ? 0x80000000u : 0u;
+                g.used[5 * si] = KNZ_LZS_NEVER;
+                g.ntok[si] = 0;
+                g.need[si] = s < ns ? 1 : 0;
+            }
+        }
+    }
+    g.blk_state[b] = st;
+}
+
+__global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
+    __shared__ uint32_t s_coarse[2048];
+    const LzArgs& a = g.pa.a;
+    const int lane = threadIdx.x;
+    const bool writer = lane == 0;
+    const uint32_t b = blockIdx.y, s = blockIdx.x;
+    if (g.blk_state[b] != 0) return;
+    const size_t si = (size_t)b * g.segs + s;
+    if (!g.need[si]) return;
+    const int count = (int)a.in_len[b];
+    const uint8_t* src = (const uint8_t*)a.in_ptr[b];
+    int srcEnd, maxDist, minMatch; uint32_t hdrFlag; bool decline;
+    knz_lzs_geom(a, b, count, srcEnd, maxDist, minMatch, hdrFlag, decline);
+    const int segEnd = (int)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
+    const uint32_t* E = g.entry + 5 * si;
+    int srcIdx = (int)E[0], anchor = (int)E[1], repd0 = (int)E[2], repd1 = (int)E[3], srcInc = (int)(E[4] & 0x7FFFFFFFu), repdIdx = (int)(E[4] >> 31);
+    if (writer) { uint32_t* U = g.used + 5 * si; U[0] = E[0]; U[1] = E[1]; U[2] = E[2]; U[3] = E[3]; U[4] = E[4]; }
+    const int eSrc = srcIdx, eAnchor = anchor;                                // where this segment's own knowledge of the holes begins
+    const uint8_t* cand8 = (const uint8_t*)(g.pa.cand + g.pa.gstart[b]);
+    const uint8_t* cp8 = g.pa.cp8 + g.pa.gstart[b];
+    const uint32_t* Jp = g.Jp + (size_t)b * g.map_stride; const uint32_t* Mp = g.Mp + (size_t)b * g.map_stride;
+    uint32_t* Jn = g.Jn + (size_t)b * g.map_stride; uint32_t* Mn = g.Mn + (size_t)b * g.map_stride;
+    uint32_t* Cn = g.Cn + (size_t)b * 2048;
+    unsigned cs = 6;
+    while (((uint32_t)count >> cs) >= 65536u) cs++;
+    { const uint32_t* Cp = g.Cp + (size_t)b * 2048; for (int i = lane; i < 2048; i += 64) s_coarse[i] = Cp[i]; }
+    wave_sync();
+    bool anyHoles = g.Sp[2 * b] != 0;
+    int maxHole = anyHoles ? (int)g.Sp[2 * b + 1] : -1;
+    uint32_t ntok = 0;
+    uint4* tokOut = g.tok + si * g.tok_cap;
+    bool overflow = false;
+
+#define KNZ_LZS_CAND(P) ((int)wave_sload_u32(cand8 + 4 * (size_t)(P)))
+#define KNZ_LZS_CP(P) ((int)((wave_sload_u32((const uint8_t*)((uintptr_t)(cp8 + (P)) & ~(uintptr_t)3)) >> (8 * ((uintptr_t)(cp8 + (P)) & 3))) & 0xFFu))
+    auto is_hole = [&](int q) -> bool {
+        if (!((s_coarse[(uint32_t)q >> (cs + 5)] >> (((uint32_t)q >> cs) & 31)) & 1u)) return false;
+        const uint32_t w = (uint32_t)q >> 5, m = 1u << (q & 31);
+        uint32_t bits;
+        if (q >= eAnchor) {                                                   // own generation (written by this wave: device-scope loads, the bits are set by atomics at L2)
+            const uint32_t j = q >= eSrc ? wave_bcast((uint32_t)knz_agent_load_i32((const int32_t*)Jn + w), 0) : Jp[w];
+            bits = j & ~wave_bcast((uint32_t)knz_agent_load_i32((const int32_t*)Mn + w), 0);
+        } else bits = Jp[w] & ~Mp[w];
+        return (bits & m) != 0;
+    };
+    auto true_cand = [&](int raw) -> int {
+        int q = raw;
+        if (anyHoles) while (q > 0 && q <= maxHole && is_hole(q)) q = KNZ_LZS_CAND(q);
+        return q;
+    };
+    auto len_from_cp = [&](int cp, int maxMatch) -> int { const int whole = maxMatch & ~7; return cp < whole ? cp : whole; };
+
+    while (srcIdx < srcEnd) {
+        if (srcIdx >= segEnd && srcInc < 64) break;                           // hand over only when not skipping
+        int bestLen = 0;
+        const int srcIdx1 = srcIdx + 1;
+        const int nextPos = srcIdx1 + (srcInc >> 6);
+        const int maxMatch = min(srcEnd - srcIdx1, KNZ_LZ_MAX_MATCH);
+        const int minRef = max(srcIdx - maxDist, 0);
+        const int refA = srcIdx1 - (repdIdx ? repd1 : repd0), refB = srcIdx1 - (repdIdx ? repd0 : repd1);
+        const uint8_t* pp = src + srcIdx;
+        const uint8_t* pa_ = src + max(refA, 0);
+        const uint8_t* pb_ = src + max(refB, 0);
+        const uint8_t* pc_ = cp8 + srcIdx;
+        const uint8_t* y0 = (const uint8_t*)((uintptr_t)pp & ~(uintptr_t)3);
+        const uint8_t* y2 = cand8 + 4 * (size_t)srcIdx;
+        const uint8_t* y3 = (const uint8_t*)((uintptr_t)pc_ & ~(uintptr_t)3);
+        const uint8_t* y4 = (const uint8_t*)((uintptr_t)pa_ & ~(uintptr_t)3);
+        const uint8_t* y5 = (const uint8_t*)((uintptr_t)pb_ & ~(uintptr_t)3);
+        uint64_t l0 = wave_sload_u64_async(y0);
+        uint32_t l1 = wave_sload_u32_async(y0 + 8);
+        uint32_t l2 = wave_sload_u32_async(y2);
+        uint32_t l3 = wave_sload_u32_async(y3);
+        uint64_t l4 = wave_sload_u64_async(y4);
+        uint64_t l5 = wave_sload_u64_async(y5);
+        WAVE_SLOAD_WAIT5A(l0, l2, l3, l4, l5, y0, y2, y3, y4, y5);
+        l1 = wave_pin_sgpr(l1);
+        const uint32_t shp = ((uint32_t)(uintptr_t)pp & 3u) * 8u;
+        const uint64_t p = shp ? ((l0 >> shp) | ((uint64_t)l1 << (64 - shp))) : l0;
+        const int raw0 = (int)l2, cp0 = (int)((l3 >> (8 * ((uint32_t)(uintptr_t)pc_ & 3u))) & 0xFFu);
+        const uint32_t vA = (uint32_t)(l4 >> (((uint32_t)(uintptr_t)pa_ & 3u) * 8u)), vB = (uint32_t)(l5 >> (((uint32_t)(uintptr_t)pb_ & 3u) * 8u));
+        const int ref0 = true_cand(raw0);
+        int ref = refA;
+        if (ref > minRef && (uint32_t)(p >> 8) == vA) {
+            bestLen = knz_lz_match_wave(src, srcIdx1, ref, maxMatch, lane);
+        } else {
+            ref = refB;
+            if (ref > minRef && (uint32_t)(p >> 8) == vB) bestLen = knz_lz_match_wave(src, srcIdx1, ref, maxMatch, lane);
+        }
+        if (bestLen < minMatch) {
+            ref = ref0;
+            bool found = false;
+            if (ref > minRef) {
+                const int mm = min(srcEnd - srcIdx, KNZ_LZ_MAX_MATCH);
+                if (ref == raw0 && cp0 < 255) { if (cp0 >= 4) { bestLen = len_from_cp(cp0, mm); found = bestLen >= minMatch; } }
+                else if ((uint32_t)p == knz_sle32(src + ref)) { bestLen = knz_lz_match_wave(src, srcIdx, ref, mm, lane); found = bestLen >= minMatch; }
+            }
+            if (!found) {
+                if (nextPos > srcIdx1) {                                      // positions jumped over: not hashed until a match covers them
+                    for (int q0 = srcIdx1; q0 < nextPos; q0 += 64) {
+                        const int q = q0 + lane;
+                        if (q < nextPos) {
+                            atomicOr(&Jn[q >> 5], 1u << (q & 31));
+                            atomicOr(&s_coarse[(uint32_t)q >> (cs + 5)], 1u << (((uint32_t)q >> cs) & 31));
+                            atomicOr(&Cn[(uint32_t)q >> (cs + 5)], 1u << (((uint32_t)q >> cs) & 31));
+                        }
+                    }
+                    wave_sync_lds();
+                    wave_order_lanes();
+                    if (writer) { atomicOr(&g.Sn[2 * b], 1u); atomicMax(&g.Sn[2 * b + 1], (uint32_t)(nextPos - 1)); }
+                    anyHoles = true;
+                    maxHole = max(maxHole, nextPos - 1);
+                }
+                srcIdx = nextPos;
+                srcInc++;
+                repdIdx = 0;
+                continue;
+            }
+            if (ref != srcIdx - repd0 && ref != srcIdx - repd1) {          // checkNext (:362-398)
+                {
+                    const int raw1 = KNZ_LZS_CAND(srcIdx1), cp1 = KNZ_LZS_CP(srcIdx1);
+                    const int ref1 = true_cand(raw1);
+                    if (ref1 > minRef + 1 && !(ref1 == raw1 && cp1 < 255 && cp1 < bestLen) &&
+                        knz_sle32(src + srcIdx1 + bestLen - 3) == knz_sle32(src + ref1 + bestLen - 3)) {
+                        const int bestLen1 = (ref1 == raw1 && cp1 < 255) ? len_from_cp(cp1, maxMatch) : knz_lz_match_wave(src, srcIdx1, ref1, maxMatch, lane);
+                        if (bestLen1 >= bestLen) { ref = ref1; bestLen = bestLen1; srcIdx = srcIdx1; }
+                    }
+                }
+                if (a.extra) {
+                    const int srcIdx2 = srcIdx1 + 1;
+                    const int raw2 = KNZ_LZS_CAND(srcIdx2), cp2 = KNZ_LZS_CP(srcIdx2);
+                    const int ref2 = true_cand(raw2);
+                    const int mm2 = min(srcEnd - srcIdx2, KNZ_LZ_MAX_MATCH);
+                    if (ref2 > minRef + 2 && !(ref2 == raw2 && cp2 < 255 && cp2 < bestLen) &&
+                        knz_sle32(src + srcIdx2 + bestLen - 3) == knz_sle32(src + ref2 + bestLen - 3)) {
+                        const int bestLen2 = (ref2 == raw2 && cp2 < 255) ? len_from_cp(cp2, mm2) : knz_lz_match_wave(src, srcIdx2, ref2, mm2, lane);
+                        if (bestLen2 >= bestLen) { ref = ref2; bestLen = bestLen2; srcIdx = srcIdx2; }
+                    }
+                }
+            }
+            for (;;) {                                                        // extend backwards (:400-405): 64 bytes per round
+                const int room = min(srcIdx - anchor, ref - minRef);
+                const bool same = lane < room && src[srcIdx - 1 - lane] == src[ref - 1 - lane];
+                const uint64_t stop = wave_ballot(!same);
+                const int k = stop ? (int)(__ffsll((unsigned long long)stop) - 1) : 64;
+                bestLen += k; ref -= k; srcIdx -= k;
+                if (k < 64) break;
+            }
+            if (bestLen > KNZ_LZ_MAX_MATCH) {
+                srcIdx += bestLen - KNZ_LZ_MAX_MATCH;
+                ref += bestLen - KNZ_LZ_MAX_MATCH;
+                bestLen = KNZ_LZ_MAX_MATCH;
+            }
+        } else {
+            if ((uint8_t)p == (uint8_t)knz_sle32(src + ref - 1) && bestLen < KNZ_LZ_MAX_MATCH) { bestLen++; ref--; }
+            else srcIdx++;
+        }
+        srcInc = 0;
+        const int dist = srcIdx - ref;
+        uint32_t tflag;
+        if (dist == repd0) tflag = 0x00;
+        else if (dist == repd1) tflag = 0x04;
+        else tflag = dist >= 65536 ? 0x18 : (dist >= 256 ? 0x10 : 0x08);
+        repd1 = repd0;
+        repd0 = dist;
+        repdIdx = 1;
+        if (ntok < g.tok_cap) { if (writer) { uint4 t; t.x = (uint32_t)anchor; t.y = (uint32_t)(srcIdx - anchor); t.z = (uint32_t)bestLen | (tflag << 24); t.w = (uint32_t)dist; tokOut[ntok] = t; } }
+        else overflow = true;
+        ntok++;
+        anchor = srcIdx + bestLen;
+        // the reference hashes every position of the match now (:517-553): jumped-over positions under it are holes no longer
+        if (anyHoles && srcIdx + 1 <= maxHole) {
+            const int hi = min(anchor, maxHole + 1);
+            for (int q0 = srcIdx + 1; q0 < hi; q0 += 64) { const int q = q0 + lane; if (q < hi) atomicOr(&Mn[q >> 5], 1u << (q & 31)); }
+            wave_order_lanes();
+        }
+        srcIdx = anchor;
+    }
+    if (writer) {
+        uint32_t* X = g.exit_ + 5 * si;
+        X[0] = (uint32_t)srcIdx; X[1] = (uint32_t)anchor; X[2] = (uint32_t)repd0; X[3] = (uint32_t)repd1; X[4] = (uint32_t)srcInc | ((uint32_t)repdIdx << 31);
+        g.ntok[si] = overflow ? KNZ_LZS_NEVER : ntok;
+    }
+#undef KNZ_LZS_CAND
+#undef KNZ_LZS_CP
+}
+
+// one thread per block: the entry states of the next round. The exit of a segment is known for the entry state its last parse started
+// from; a segment whose entry state lies at or behind its end has nothing to parse and hands the state on unchanged. If any live
+// segment of the block needs a new parse (new entry state, or the hole maps moved), all of them run again, so that the next
+// generation of the maps is complete.
+__global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_t round) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const LzArgs& a = g.pa.a;
+    if (b >= a.nblocks || g.blk_state[b] != 0) return;
+    const int count = (int)a.in_len[b];
+    const int srcEnd = count - 18;
+    const uint32_t ns = srcEnd > 0 ? ((uint32_t)srcEnd + g.seg_size - 1) / g.seg_size : 0;
+    const bool mapsChanged = g.blk_flags[4 * b + 1] != 0;
+    g.blk_flags[4 * b + 1] = 0;
+    uint32_t cur[5] = {0, 0, (uint32_t)count, (uint32_t)count, 0};
+    bool changed = false, overflow = false;
+    for (uint32_t s = 0; s < ns; s++) {
+        const size_t si = (size_t)b * g.segs + s;
+        uint32_t* E = g.entry + 5 * si;
+        const uint32_t* U = g.used + 5 * si;
+        const uint32_t* X = g.exit_ + 5 * si;
+        for (int k = 0; k < 5; k++) E[k] = cur[k];
+        const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
+        if (cur[0] >= segEnd) continue;                                       // nothing to parse here: the state passes through
+        const bool same = U[0] == cur[0] && U[1] == cur[1] && U[2] == cur[2] && U[3] == cur[3] && U[4] == cur[4];
+        if (!same) changed = true;
+        else if (g.ntok[si] == KNZ_LZS_NEVER) overflow = true;
+        if (U[0] != KNZ_LZS_NEVER) for (int k = 0; k < 5; k++) cur[k] = X[k];   // exact when `same`, the best guess otherwise
+    }
+    const bool again = changed || mapsChanged;
+    // a block that has never had a jumped-over position has empty maps whatever its segments do: only the segments whose entry state is
+    // new run again. With holes, every live segment runs again, so that the next generation of the maps is complete.
+    const bool holey = (g.Sp[2 * b] | g.Sn[2 * b]) != 0;
+    for (uint32_t s = 0; s < ns; s++) {
+        const size_t si = (size_t)b * g.segs + s;
+        const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
+        const uint32_t* E = g.entry + 5 * si;
+        const uint32_t* U = g.used + 5 * si;
+        const bool same = U[0] == E[0] && U[1] == E[1] && U[2] == E[2] && U[3] == E[3] && U[4] == E[4];
+        g.need[si] = (again && E[0] < segEnd && (holey || !same)) ? 1 : 0;
+    }
+    g.blk_flags[4 * b] = cur[1];                                              // anchor behind the last match (used when the block has settled)
+    g.blk_flags[4 * b + 2] = round + 1;
+    if (overflow) g.blk_state[b] = 2;
+    else if (!again) g.blk_state[b] = 1;
+    else if (round + 1 >= KNZ_LZS_MAX_ROUNDS) g.blk_state[b] = 2;
+}
+
+// did the hole maps of this round differ from the previous round's? grid (ceil(words / 256), nblocks)
+__global__ __launch_bounds__(256) void knz_lzs_compare_kernel(LzSegArgs g, uint32_t words) {
+    const uint32_t b = blockIdx.y;
+    if (g.blk_state[b] != 0) return;
+    const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    bool diff = false;
+    if (w < words) {
+        const size_t i = (size_t)b * g.map_stride + w;
+        diff = g.Jp[i] != g.Jn[i] || g.Mp[i] != g.Mn[i];
+    }
+    if (wave_ballot(diff) != 0 && (threadIdx.x & 63) == 0) g.blk_flags[4 * b + 1] = 1;
+}
+
+// ---- layout of a settled block (:425-591) ------------------------------------------------------------------------------------
+struct LzsSizes { uint32_t lit, dist, ml; bool special; };
+__device__ __forceinline__ uint32_t knz_lzs_len_size(uint32_t length) { return length < 254u ? 1u : (length < 65536u + 254u ? 3u : 4u); }   // emitLengthLZ :193-212
+__device__ __forceinline__ LzsSizes knz_lzs_sizes(const uint4& t, uint32_t minMatch) {
+    LzsSizes z;
+    const uint32_t litLen = t.y, bestLen = t.z & 0xFFFFFFu, fl = t.z >> 24;
+    z.special = litLen >= (1u << 24);                                         // "too many literals" (:493-495): left to the one-wave kernel
+    z.lit = litLen + (litLen >= 7 ? knz_lzs_len_size(litLen - 7) : 0u);
+    z.dist = fl == 0x08 ? 1u : (fl == 0x10 ? 2u : (fl == 0x18 ? 3u : 0u));
+    const uint32_t mLen = bestLen - minMatch, th = fl < 8 ? 3u : 7u;
+    z.ml = mLen >= th ? knz_lzs_len_size(mLen - th) : 0u;
+    return z;
+}
+__device__ __forceinline__ bool knz_lzs_live(const LzSegArgs& g, uint32_t b, uint32_t s, int srcEnd) {
+    const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
+    return (int)(s * (uint64_t)g.seg_size) < srcEnd && g.entry[5 * ((size_t)b * g.segs + s)] < segEnd;
+}
+
+// per segment: tokens, literal-stream bytes, distance bytes, length-extension bytes; grid (segs, nblocks)
+__global__ __launch_bounds__(256) void knz_lzs_emit_count_kernel(LzSegArgs g, uint32_t* segsum) {
+    __shared__ uint32_t s_w[4];
+    const LzArgs& a = g.pa.a;
+    const uint32_t b = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    if (g.blk_state[b] != 1) return;
+    const int count = (int)a.in_len[b];
+    int srcEnd, maxDist, minMatch; uint32_t hf; bool decline;
+    knz_lzs_geom(a, b, count, srcEnd, maxDist, minMatch, hf, decline);
+    const size_t si = (size_t)b * g.segs + s;
+    const uint32_t n = knz_lzs_live(g, b, s, srcEnd) ? g.ntok[si] : 0u;
+    const uint4* tk = g.tok + si * g.tok_cap;
+    uint32_t lit = 0, dist = 0, ml = 0;
+    bool special = false;
+    for (uint32_t i = tid; i < n; i += 256) { const LzsSizes z = knz_lzs_sizes(tk[i], (uint32_t)minMatch); lit += z.lit; dist += z.dist; ml += z.ml; special |= z.special; }
+    lit = knz_lzi_wg_sum(lit, s_w); dist = knz_lzi_wg_sum(dist, s_w); ml = knz_lzi_wg_sum(ml, s_w);
+    if (special) g.blk_state[b] = 2;
+    if (tid == 0) { uint32_t* S = segsum + 4 * si; S[0] = n; S[1] = lit; S[2] = dist; S[3] = ml; }
+}
+
+// one wave per block: exclusive sums over the segments, the decisions of :559-561 and :586-588, the header
+__global__ __launch_bounds__(64) void knz_lzs_emit_offsets_kernel(LzSegArgs g, uint32_t* segsum, uint32_t* blkout) {
+    const LzArgs& a = g.pa.a;
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    if (g.blk_state[b] != 1) return;
+    const int count = (int)a.in_len[b];
+    int srcEnd, maxDist, minMatch; uint32_t hf; bool decline;
+    knz_lzs_geom(a, b, count, srcEnd, maxDist, minMatch, hf, decline);
+    const uint32_t ns = srcEnd > 0 ? ((uint32_t)srcEnd + g.seg_size - 1) / g.seg_size : 0;
+    uint32_t c[4] = {0, 0, 0, 0};
+    for (uint32_t s0 = 0; s0 < ns; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        uint32_t* S = segsum + 4 * ((size_t)b * g.segs + s);
+        uint32_t v[4] = {0, 0, 0, 0};
+        if (s < ns) { v[0] = S[0]; v[1] = S[1]; v[2] = S[2]; v[3] = S[3]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t incl = wave_scan_incl(v[q]);
+            if (s < ns) S[q] = c[q] + incl - v[q];
+            c[q] += wave_shfl(incl, 63);
+        }
+    }
+    if (lane != 0) return;
+    const uint32_t anchor = g.blk_flags[4 * b];
+    const uint32_t litLen = (uint32_t)count - anchor;
+    uint32_t dstIdx = 13u + c[1];
+    const uint32_t tkIdx = c[0], mIdx = c[2], mLenIdx = c[3];
+    const uint32_t tkCap = (uint32_t)(count / 5 > 256 ? count / 5 : 256);
+    uint32_t* O = blkout + 8 * (size_t)b;
+    int status = 1;
+    if (tkIdx >= tkCap) { g.blk_state[b] = 2; return; }                       // the reference's token buffer would overflow: the one-wave kernel reports it
+    if ((uint64_t)dstIdx + litLen + tkIdx + mIdx >= (uint64_t)count) status = 0;   // "no compression" (:559-561)
+    else {
+        const uint32_t litStart = dstIdx;                                     // the last literals (:563-573)
+        dstIdx += (litLen >= 7 ? knz_lzs_len_size(litLen - 7) : 0u) + litLen;
+        const uint32_t total = dstIdx + (tkIdx + 1) + mIdx + mLenIdx;
+        O[0] = litStart; O[1] = dstIdx; O[2] = dstIdx + tkIdx + 1; O[3] = dstIdx + tkIdx + 1 + mIdx; O[4] = anchor; O[5] = litLen; O[6] = tkIdx;
+        uint8_t* dst = (uint8_t*)a.out_ptr[b];
+        const uint32_t v0 = dstIdx, v1 = tkIdx + 1, v2 = mIdx;
+        for (int k = 0; k < 4; k++) { dst[k] = (uint8_t)(v0 >> (8 * k)); dst[4 + k] = (uint8_t)(v1 >> (8 * k)); dst[8 + k] = (uint8_t)(v2 >> (8 * k)); }
+        dst[12] = (uint8_t)hf;
+        if (total > (uint32_t)(count - count / 100)) status = 0;             // :586-588
+        a.out_len[b] = status == 1 ? total : 0;
+    }
+    O[7] = (uint32_t)status;
+    a.ok[b] = status;
+    if (status != 1) a.out_len[b] = 0;
+}
+
+// per segment: the bytes of its tokens at their places; grid (segs, nblocks). Tiles of 256 tokens: sizes, prefix sums, then the token /
+// distance / length bytes by one thread per token and the literals by all threads over the tile's byte range.
+__global__ __launch_bounds__(256) void knz_lzs_emit_write_kernel(LzSegArgs g, const uint32_t* segsum, const uint32_t* blkout) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_off[257], s_src[256], s_len[256];
+    const LzArgs& a = g.pa.a;
+    const uint32_t b = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    if (g.blk_state[b] != 1) return;
+    const uint32_t* O = blkout + 8 * (size_t)b;
+    if (O[7] != 1) return;
+    const int count = (int)a.in_len[b];
+    int srcEnd, maxDist, minMatch; uint32_t hf; bool decline;
+    knz_lzs_geom(a, b, count, srcEnd, maxDist, minMatch, hf, decline);
+    const size_t si = (size_t)b * g.segs + s;
+    const uint32_t n = knz_lzs_live(g, b, s, srcEnd) ? g.ntok[si] : 0u;
+    if (n == 0) return;
+    const uint4* tk = g.tok + si * g.tok_cap;
+    const uint32_t* S = segsum + 4 * si;
+    const uint8_t* src = (const uint8_t*)a.in_ptr[b];
+    uint8_t* dst = (uint8_t*)a.out_ptr[b];
+    uint32_t tkPos = O[1] + S[0], litPos = 13u + S[1], mPos = O[2] + S[2], mlPos = O[3] + S[3];
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        const uint32_t i = i0 + tid;
+        uint4 t; t.x = t.y = t.z = t.w = 0;
+        LzsSizes z; z.lit = z.dist = z.ml = 0; z.special = false;
+        if (i < n) { t = tk[i]; z = knz_lzs_sizes(t, (uint32_t)minMatch); }
+        const uint32_t eLit = knz_lzi_wg_scan_excl(z.lit, s_w), eDist = knz_lzi_wg_scan_excl(z.dist, s_w), eMl = knz_lzi_wg_scan_excl(z.ml, s_w);
+        const uint32_t litLen = t.y, bestLen = t.z & 0xFFFFFFu, fl = t.z >> 24, dist = t.w;
+        const uint32_t extSz = litLen >= 7 ? knz_lzs_len_size(litLen - 7) : 0u;
+        s_off[tid] = litPos + eLit + extSz; s_src[tid] = t.x; s_len[tid] = i < n ? litLen : 0u;
+        if (i < n) {
+            const uint32_t mLen = bestLen - (uint32_t)minMatch, th = fl < 8 ? 3u : 7u;
+            const uint32_t token = fl + (mLen >= th ? th : mLen);
+            dst[tkPos + i] = (uint8_t)((litLen >= 7 ? (7u << 5) : (litLen << 5)) | token);
+            if (litLen >= 7) (void)knz_lz_emit_length(dst + litPos + eLit, (int)(litLen - 7), true);
+            uint8_t* m = dst + mPos + eDist;
+            if (fl == 0x18) { m[0] = (uint8_t)(dist >> 16); m[1] = (uint8_t)(dist >> 8); m[2] = (uint8_t)dist; }
+            else if (fl == 0x10) { m[0] = (uint8_t)(dist >> 8); m[1] = (uint8_t)dist; }
+            else if (fl == 0x08) m[0] = (uint8_t)dist;
+            if (mLen >= th) (void)knz_lz_emit_length(dst + mlPos + eMl, (int)(mLen - th), true);
+        }
+        const uint32_t nt = min(256u, n - i0);
+        // totals of the tile (all threads took part in the scans above)
+        __shared__ uint32_t s_tot[3];
+        if (tid == 255) { s_tot[0] = eLit + z.lit; s_tot[1] = eDist + z.dist; s_tot[2] = eMl + z.ml; }
+        __syncthreads();
+        // literals of the tile: every wave takes 64 tokens, its lanes walk their byte range
+        {
+            const uint32_t w = tid >> 6, lane = tid & 63, t0 = w * 64;
+            if (t0 < nt) {
+                const uint32_t tn = min(64u, nt - t0);
+                for (uint32_t k = 0; k < tn; k++) {
+                    const uint32_t len = s_len[t0 + k];
+                    if (len == 0) continue;
+                    const uint8_t* sp = src + s_src[t0 + k];
+                    uint8_t* dp = dst + s_off[t0 + k];
+                    for (uint32_t o = lane; o < len; o += 64) dp[o] = sp[o];
+                }
+            }
+        }
+        litPos += s_tot[0]; mPos += s_tot[1]; mlPos += s_tot[2];
+        __syncthreads();
+    }
+}
+
+// the last literals of a block (:563-573): one workgroup per block
+__global__ __launch_bounds__(256) void knz_lzs_emit_tail_kernel(LzSegArgs g, const uint32_t* blkout) {
+    const LzArgs& a = g.pa.a;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    if (g.blk_state[b] != 1) return;
+    const uint32_t* O = blkout + 8 * (size_t)b;
+    if (O[7] != 1) return;
+    const uint8_t* src = (const uint8_t*)a.in_ptr[b];
+    uint8_t* dst = (uint8_t*)a.out_ptr[b];
+    const uint32_t anchor = O[4], litLen = O[5];
+    uint32_t p = O[0];
+    const uint32_t ext = litLen >= 7 ? knz_lzs_len_size(litLen - 7) : 0u;
+    if (tid == 0) {
+        dst[O[1] + O[6]] = (uint8_t)(litLen >= 7 ? (7u << 5) : (litLen << 5));
+        if (litLen >= 7) (void)knz_lz_emit_length(dst + p, (int)(litLen - 7), true);
+    }
+    p += ext;
+    for (uint32_t o = tid; o < litLen; o += 256) dst[p + o] = src[anchor + o];
+}
+
+// blocks the one-wave kernel has to take (mask for its `active` argument)
+__global__ __launch_bounds__(64) void knz_lzs_serial_mask_kernel(LzSegArgs g, uint8_t* mask) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= g.pa.a.nblocks) return;
+    mask[b] = (g.blk_state[b] == 2 || g.blk_state[b] == 4) ? 1 : 0;
+}

@@ -17,7 +17,8 @@
 //     literal (its position in the literal stream is known from the prefix sums) or the copy of an EARLIER output byte: a
 //     per-byte source map (4 bytes per output byte) is resolved by following the map (workgroups are dispatched in ascending
 //     order, so most sources are already final when a byte is visited; what is not follows at most 8 hops per pass and writes
-//     back where it got to, which shortens every later path through it), then one gather pass reads the literal bytes.
+//     back where it got to, which shortens every later path through it: two such passes), then one gather pass reads the literal
+//     bytes (and follows whatever is still open to its end: every path ends at a literal).
 // A block takes this path only if it is well formed (every cursor ends where the header says, every distance passes the
 // reference's sanity checks :732-735, the literal cursor reaches the end of the literals at the last token and not before);
 // any other block - damaged streams - is left to the one-wave kernel of lz.hip, which keeps the reference's behaviour token by
@@ -46,8 +47,7 @@ struct LziArgs {
     uint32_t* t_d;                 // pass A: match-length extensions in front of the token ; pass B: output position of its literals ([nTok] = total)
     uint32_t* seg;                 // [nblocks][segs][8]
     uint32_t* lx_g;                // per literal-length extension: t_a of its token
-    uint32_t* lx_c;                // extension bytes + extension values in front of it ([n] = total)
-    uint32_t* lx_v;                // its value | size << 28
+    uint32_t* lx_c;                // extension bytes + extension values in front of it ([n] = total): size and value of one = the difference
     uint32_t* ml_val;              // values of the match-length extension records, in order
     uint32_t* map; uint64_t map_stride;
     uint32_t* unfinished;
@@ -192,34 +192,72 @@ __global__ __launch_bounds__(256) void knz_lzi_a_apply_kernel(LziArgs g) {
 }
 
 // ---- literal lengths >= 7: the extension sits in the literal stream at the literal cursor (:657-661), so its position depends on
-// every extension in front of it: one wave per block walks them (everything is wave-uniform: scalar loads and scalar arithmetic)
+// every extension in front of it: one wave per block walks them. The chain is  C -> byte at (13 + g[i] + C) -> C + 1 + byte : the
+// literal region is staged through a 32 KiB LDS window by all lanes (the chain only moves forward), the g[i] come 1024 at a time,
+// and a step is one dependent LDS read plus a handful of wave-uniform vector instructions. The chain stores C in front of every
+// extension (64 steps per coalesced store); its size and value are recovered from the differences, which is unambiguous for
+// the records an encoder writes (emitLengthLZ :193-212: 1 byte below 254, 3 bytes below 65790, else 4): anything else leaves
+// the block to the one-wave kernel.
+#define KNZ_LZI_WIN 32768u
+__device__ __forceinline__ void knz_lzi_ext_from_diff(uint32_t d, uint32_t& sz, uint32_t& val) {
+    sz = d < 255u ? 1u : (d < 65793u ? 3u : 4u);
+    val = d - sz;
+}
 __global__ __launch_bounds__(64) void knz_lzi_litext_chain_kernel(LziArgs g) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_lit[KNZ_LZI_WIN];
+    __shared__ __attribute__((aligned(16))) uint32_t s_g[1024];
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
     uint32_t* G = g.geo + 16 * (size_t)b;
     if (!G[LZI_PAR]) return;
-    const uint32_t E = G[LZI_NLEXT], tk0 = G[LZI_TK0];
+    const uint32_t E = G[LZI_NLEXT], tk0 = G[LZI_TK0], count = G[LZI_COUNT];
     const uint8_t* src = (const uint8_t*)g.a.in_ptr[b];
     const size_t tb = g.tok_base[b];
     const uint32_t* lg = g.lx_g + tb;
     uint32_t* lc = g.lx_c + tb;
-    uint32_t* lv = g.lx_v + tb;
-    uint32_t C = 0;
-    bool bad = false;
-    for (uint32_t i = 0; i < E; i++) {
-        const uint32_t pos = 13u + wave_sload_u32((const uint8_t*)(lg + i)) + C;
-        if (pos + 4 > tk0) {                                                  // an extension that leaves the literal region: not a stream the encoder wrote
-            if (pos >= tk0) { bad = true; break; }
+    uint32_t C = 0, wlo = 0, whi = 0, hist = 0;
+    bool bad = ((uintptr_t)src & 15) != 0;                                   // (the pipeline's regions are 16-byte aligned)
+    for (uint32_t i0 = 0; i0 < E && !bad; i0 += 1024) {
+        const uint32_t n = min(1024u, E - i0);
+        wave_sync();
+        for (uint32_t j = lane; j < 1024; j += 64) s_g[j] = j < n ? lg[i0 + j] : 0u;
+        wave_sync();
+        // four steps per trip: their g values arrive as one 16-byte LDS read ahead of the chain, which leaves the byte at the cursor as the
+        // only dependent LDS access of a step
+        for (uint32_t j4 = 0; j4 < n && !bad; j4 += 4) {
+            const uint4 gq = *(const uint4*)(s_g + j4);
+            const uint32_t gv[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t j = j4 + (uint32_t)u;
+                if (j >= n || bad) break;
+                const uint32_t pos = 13u + gv[u] + C;
+                if (pos + 4 > whi) {                                           // (pos only grows: it never falls in front of the window)
+                    if (pos >= tk0) { bad = true; break; }
+                    wlo = pos & ~15u; whi = wlo + KNZ_LZI_WIN;
+                    wave_sync();
+                    for (uint32_t o = lane * 16; o < KNZ_LZI_WIN; o += 1024) {
+                        uint4 v; v.x = v.y = v.z = v.w = 0;
+                        if (wlo + o < count) v = *(const uint4*)(src + wlo + o);   // (whole 16-byte words: the regions carry that much slack behind count)
+                        *(uint4*)(s_lit + o) = v;
+                    }
+                    wave_sync();
+                }
+                const uint32_t o = pos - wlo;
+                const uint32_t b0 = s_lit[o];
+                uint32_t d = b0 + 1u;
+                if (b0 >= 254) {
+                    const uint32_t b1 = s_lit[o + 1], b2 = s_lit[o + 2], b3 = s_lit[o + 3];
+                    if (b0 == 254) d = 3u + 254u + (b1 << 8) + b2;
+                    else { const uint32_t y = (b1 << 16) + (b2 << 8) + b3; if (y < 65535u) { bad = true; break; } d = 4u + 255u + y; }
+                }
+                if (pos + (d < 255u ? 1u : (d < 65793u ? 3u : 4u)) > tk0) { bad = true; break; }
+                hist = lane == (j & 63u) ? C : hist;
+                C += d;
+                if (C >= 0x40000000u) { bad = true; break; }
+            }
+            if ((j4 & 63u) == 60u && !bad) lc[i0 + (j4 & ~63u) + lane] = hist;   // 64 steps done (n is a whole number of such rows except in the last chunk)
         }
-        const uint32_t w = knz_sle32(src + pos);
-        const uint32_t b0 = w & 0xFFu;
-        uint32_t val, sz;
-        if (b0 < 254) { val = b0; sz = 1; }
-        else if (b0 == 254) { val = 254u + (((w >> 8) & 0xFFu) << 8) + ((w >> 16) & 0xFFu); sz = 3; }
-        else { val = 255u + (((w >> 8) & 0xFFu) << 16) + (((w >> 16) & 0xFFu) << 8) + (w >> 24); sz = 4; }
-        if (pos + sz > tk0) { bad = true; break; }
-        if (lane == 0) { lc[i] = C; lv[i] = val | (sz << 28); }
-        C += sz + val;
-        if (C >= 0x40000000u) { bad = true; break; }
+        if (!bad && (n & 63u) != 0 && lane < (n & 63u)) lc[i0 + (n & ~63u) + lane] = hist;
     }
     if (lane == 0) { if (bad) G[LZI_PAR] = 0; else lc[E] = C; }
 }
@@ -345,7 +383,8 @@ __device__ __forceinline__ void knz_lzi_b_tokens(const LziArgs& g, uint32_t b, c
     for (uint32_t j = 0; j < T.n; j++) {
         const LziTok k = knz_lzi_token((uint32_t)(w >> (8 * j)) & 0xFFu, k0 + j == nTok - 1);
         const size_t i = tb + k0 + j;
-        T.lit[j] = k.lext ? 7u + (g.lx_v[tb + g.t_c[i]] & 0x0FFFFFFFu) : k.lit;
+        if (k.lext) { const uint32_t x = g.t_c[i]; uint32_t sz, val; knz_lzi_ext_from_diff(g.lx_c[tb + x + 1] - g.lx_c[tb + x], sz, val); T.lit[j] = 7u + val; }
+        else T.lit[j] = k.lit;
         T.rep[j] = (uint8_t)k.rep;
         T.mlen[j] = k.rep == 3 ? 0u : k.mbase + minMatch + (k.mext ? g.ml_val[tb + g.t_d[i]] : 0u);
         uint32_t d = 0;
@@ -462,7 +501,7 @@ __global__ __launch_bounds__(256) void knz_lzi_b_apply_kernel(LziArgs g) {
         uint32_t spos = 13u + g.t_a[i] + g.lx_c[tb + lxi];
         // (is this token one that carries an extension? its literal field says so: recompute from the token byte)
         const uint32_t tokByte = ((const uint8_t*)g.a.in_ptr[b])[tk0 + k];
-        if ((tokByte >> 5) == 7u) spos += g.lx_v[tb + lxi] >> 28;
+        if ((tokByte >> 5) == 7u) { uint32_t sz, val; knz_lzi_ext_from_diff(g.lx_c[tb + lxi + 1] - g.lx_c[tb + lxi], sz, val); spos += sz; }
         const uint32_t lit = T.lit[j];
         // the reference stops at the first token whose literals reach srcEnd (:672-674) and wants the cursor at the end of the literals then (:771)
         if ((uint64_t)spos + lit > tk0) bad = true;
@@ -560,7 +599,7 @@ __global__ __launch_bounds__(256) void knz_lzi_jump_kernel(LziArgs g) {
             else for (uint32_t j = 0; j < n; j++) map[p0 + j] = v[j];
         }
     }
-    if (wave_ballot(open) != 0 && (threadIdx.x & 63) == 0) atomicOr(g.unfinished, 1u);
+    (void)open;
 }
 
 __global__ __launch_bounds__(256) void knz_lzi_gather_kernel(LziArgs g) {
@@ -576,10 +615,13 @@ __global__ __launch_bounds__(256) void knz_lzi_gather_kernel(LziArgs g) {
     const uint32_t n = min(4u, total - p0);
     if (n == 4 && (((uintptr_t)dst) & 3) == 0) {
         const uint4 q = *(const uint4*)(map + p0);
-        const uint32_t w = (uint32_t)src[q.x & 0x7FFFFFFFu] | ((uint32_t)src[q.y & 0x7FFFFFFFu] << 8) | ((uint32_t)src[q.z & 0x7FFFFFFFu] << 16) |
-                           ((uint32_t)src[q.w & 0x7FFFFFFFu] << 24);
+        uint32_t v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) while (!(v[j] & KNZ_LZI_LIT)) v[j] = map[v[j]];     // (whatever the jump passes left open: every path ends at a literal)
+        const uint32_t w = (uint32_t)src[v[0] & 0x7FFFFFFFu] | ((uint32_t)src[v[1] & 0x7FFFFFFFu] << 8) | ((uint32_t)src[v[2] & 0x7FFFFFFFu] << 16) |
+                           ((uint32_t)src[v[3] & 0x7FFFFFFFu] << 24);
         *(uint32_t*)(dst + p0) = w;
     } else {
-        for (uint32_t j = 0; j < n; j++) dst[p0 + j] = src[map[p0 + j] & 0x7FFFFFFFu];
+        for (uint32_t j = 0; j < n; j++) { uint32_t x = map[p0 + j]; while (!(x & KNZ_LZI_LIT)) x = map[x]; dst[p0 + j] = src[x & 0x7FFFFFFFu]; }
     }
 }

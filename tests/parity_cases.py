@@ -401,6 +401,56 @@ def check_lz_inverse_forms(be, monkeypatch, big=False):
     c.close()
 
 
+def lz_forward_inputs(big=False):
+    """Blocks that make the segment-parallel parse work: long stretches without matches (the miss acceleration jumps over positions:
+    holes), matches found from inside such stretches, repeat distances across segment borders, text, records."""
+    import bench_corpus as bc
+    rng = np.random.default_rng(17)
+    n = 600_000 if big else 24_000
+    yield "exe", bc._segment("exe", n, 2).tobytes()
+    yield "records", bc._segment("records", n // 2, 4).tobytes()
+    yield "mix", (bc._segment("exe", n // 3, 5).tobytes() + rng.integers(0, 256, n // 4, dtype=np.uint8).tobytes() + bc._segment("text", n // 4, 7).tobytes() +
+                  bytes(n // 16) + rng.integers(0, 256, n // 8, dtype=np.uint8).tobytes() + bc._segment("text", n // 8, 7).tobytes())
+    if big:
+        yield "img16", bc._segment("img16", n // 2, 3).tobytes()
+        yield from lz_inverse_inputs(big)
+    else:
+        per = rng.integers(0, 256, 37, dtype=np.uint8).tobytes()
+        yield "periodic", per * 300 + rng.integers(0, 256, 64, dtype=np.uint8).tobytes() + per * 40 + bytes([1, 2, 3]) * 900
+
+
+def check_lz_forward_forms(be, monkeypatch, big=False, segs=(256, 1024)):
+    """LZ / LZX forward: the segment-parallel parse (lz_fwd_seg.hip, default) with small segments so that every input spans many of them,
+    the one-wave table-free parse (lz_par.hip, KNZ_LZ_ONE_WAVE) and the first form (lz.hip, KNZ_LZ_CHAIN): all three == the oracle, and the
+    segment-parallel one settles on its own (KNZ_COUNTER_LZ_FWD_SERIAL_BLOCKS == 0)."""
+    c = K.Codec("NONE", "NONE", 4 << 20, lib=be.lib)
+    keys = ("KNZ_LZ_SEG", "KNZ_LZ_ONE_WAVE", "KNZ_LZ_CHAIN")
+    for tname in ("LZ", "LZX"):
+        t = K.ByteTransform(c, tname)
+        tid = _TID[tname]
+        for name, data in lz_forward_inputs(big):
+            o = O.transform_forward(tid, data)
+            envs = [("KNZ_LZ_SEG", str(sg)) for sg in segs]
+            if big or tname == "LZ":
+                envs += [("KNZ_LZ_SEG", ""), ("KNZ_LZ_ONE_WAVE", "1"), ("KNZ_LZ_CHAIN", "1")]
+            for env in envs:
+                for k in keys:
+                    monkeypatch.delenv(k, raising=False)
+                if env[1]:
+                    monkeypatch.setenv(*env)
+                g = t.forward(data)
+                assert g == o, (tname, name, env)
+                if env[0] == "KNZ_LZ_SEG":
+                    # (records locked onto different repeat distances settle one segment per round: with tiny segments such a block may run
+                    # out of rounds and go to the one-wave kernel, which is exact too; at the default segment size everything here settles)
+                    if not env[1]:
+                        assert c.last_counter(4) == 0, (tname, name, env, "left to the one-wave kernel")
+                    assert 1 <= c.last_counter(5) <= 48, (tname, name, env, c.last_counter(5))
+    for k in keys:
+        monkeypatch.delenv(k, raising=False)
+    c.close()
+
+
 def check_rank_chain_variants(be, monkeypatch, max_len=1 << 30, bwt_len=150000):
     """Inverse RANK chain (rank_inv.hip): every kept variant of the step x the packed / three-register forms (the latter is
     what blocks > 8 MiB use), on inputs with ranks >= 64, all-zero words, ragged tails; against the oracle's forward."""

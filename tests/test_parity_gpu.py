@@ -281,8 +281,21 @@ def test_lz_inverse_forms(be, monkeypatch):
     P.check_lz_inverse_forms(be, monkeypatch, big=True)
 
 
+def test_lz_forward_forms(be, monkeypatch):
+    """Segment-parallel LZ parse (fixed point over segment entry states and hole maps, lz_fwd_seg.hip) against the two one-wave forms."""
+    P.check_lz_forward_forms(be, monkeypatch, big=True, segs=(1024, 4096))
+
+
+def test_lz_streams_small_segments(be, monkeypatch):
+    """Whole streams with the parse cut into 512-position segments: many blocks x many segments, ragged last block."""
+    monkeypatch.setenv("KNZ_LZ_SEG", "512")
+    P.check_stream(be, "LZ", "ANS0", 1 << 16, 300000)
+    P.check_stream(be, "LZX", "HUFFMAN", 1 << 15, 150000)
+    P.check_stream(be, "LZ", "NONE", 4096, 4096 * 5 + 100)
+
+
 def test_lz_first_form(be, monkeypatch):
-    """KNZ_LZ_CHAIN: the parse that keeps its own hash table (lz.hip), the cross-check of the table-free form that runs by default."""
+    """KNZ_LZ_CHAIN: the parse that keeps its own hash table (lz.hip), the cross-check of the table-free forms."""
     monkeypatch.setenv("KNZ_LZ_CHAIN", "1")
     P.check_transform(be, "LZ")
     P.check_transform(be, "LZX")
