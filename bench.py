@@ -51,7 +51,7 @@ CONFIGS = {
     "lz": ("LZ", "ANS0", 4 << 20, 2, "silesia"),
     "bwt": ("BWT+RANK+ZRLT", "ANS1", 8 << 20, 3, "silesia"),
     "l5": ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0", 4 << 20, 3, "silesia"),    # the reference's `-l 5` preset itself (the published 225 / 533 MB/s)
-    "fpaq": ("BWT+RANK+ZRLT", "FPAQ", 32 << 20, 4, "enwik"),   # configs[4]: S-enwik, 10^9 B with --size 1000000000 (default here: 2 x 10^8)
+    "fpaq": ("BWT+RANK+ZRLT", "FPAQ", 32 << 20, 4, "enwik"),   # configs[4]: S-enwik, 10^9 B = 30 blocks (the stated size; --size shrinks it for debugging)
 }
 
 # what the reference publishes for the nearest shipped preset (other hardware; context only)
@@ -213,7 +213,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="bwt", choices=sorted(CONFIGS))
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N>1: split one fixed job (strong) or one corpus copy per GPU (weak)")
-    ap.add_argument("--size", type=int, default=0, help="override the corpus size (debug; fpaq: 1000000000 = BASELINE configs[4])")
+    ap.add_argument("--size", type=int, default=0, help="override the corpus size (debug; the defaults are the BASELINE sizes: 211957760 / 10^9 for fpaq)")
     ap.add_argument("--block-size", type=int, default=0, help="override the block size (debug)")
     ap.add_argument("--transform", default="", help="override the transform sequence of the config, e.g. LZP or BWT+SRT+ZRLT (debug)")
     ap.add_argument("--entropy", default="", help="override the entropy codec of the config (debug)")
@@ -257,7 +257,7 @@ def main():
     bs = args.block_size or bs
 
     if corpus == "enwik":
-        base_size = args.size or 200_000_000
+        base_size = args.size or 1_000_000_000
         base = bench_corpus.s_enwik(base_size)
         corpus_name = "S-enwik"
     else:
@@ -366,10 +366,17 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
+    rank_kernel_max = None
     if world > 1:
         tt = torch.tensor([elapsed, t_enc, t_dec], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, t_enc, t_dec = [float(x) for x in tt.tolist()]
+        # the slowest rank's time per kernel: what the SCALE line's shape is made of (a chain kernel is flat in the number of blocks a rank owns)
+        names = sorted(kern_ms)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {k: kern_ms[k] for k in names})
+        allk = sorted(set().union(*[set(g) for g in gathered]))
+        rank_kernel_max = {k: max(g.get(k, 0.0) for g in gathered) for k in allk}
 
     ok_roundtrip = bool(torch.equal(d_back[:n_my], d_src[:n_my])) if n_my else True
     if world > 1:                                            # every rank's decode must have come back right
@@ -433,6 +440,22 @@ def main():
                     roof["traffic"] = int(tr[dom])
                     roof["traffic_over_algorithmic"] = round(tr[dom] / max(alg, 1), 3)
         out["roofline"] = roof
+        if rank_kernel_max:
+            out["kernel_ms_per_step_max_over_ranks"] = {k: round(v / K_, 3) for k, v in sorted(rank_kernel_max.items(), key=lambda kv: -kv[1])[:10]}
+        if not emu:
+            # blocks the parallel kernels handed to their exact one-wave fallbacks in the last batch (0 on everything an encoder wrote so far)
+            fb = {}
+            toks = transform.split("+")
+            if "TEXT" in toks:
+                fb["text_chain_blocks"] = int(codec.last_counter(2))
+            if "LZ" in toks or "LZX" in toks:
+                fb["lz_inverse_one_wave_blocks"] = int(codec.last_counter(3))
+                fb["lz_forward_one_wave_blocks"] = int(codec.last_counter(4))
+                fb["lz_forward_rounds"] = int(codec.last_counter(5))
+            if fb:
+                out["fallback_counters_last_batch"] = fb
+        if entropy == "FPAQ":
+            out["chain_bound"] = True          # one binary arithmetic-coding chain per block by format (DESIGN.md "FPAQ"): flat in the block count
         if entropy == "HUFFMAN" and not emu:
             # the single-launch walk + decode hands a chunk to the serial kernel when a decoder gives up waiting for its walker:
             # 0 for every stream a kanzi encoder wrote unless the dispatch order went against the kernel

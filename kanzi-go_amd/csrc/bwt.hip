@@ -379,6 +379,7 @@ __global__ __launch_bounds__(1024) void knz_bwt_inv_rank_kernel(BwtRankArgs r) {
     uint32_t* sa = r.sp_succ + base; uint32_t* sb = r.sp_succ2 + base;
     uint32_t* da = r.sp_dist + base; uint32_t* db = r.sp_dist2 + base;
     if (tid == 0) s_bad = 0;
+    __syncthreads();                                                          // (the flag is cleared before any thread can raise it)
     for (uint32_t i = tid; i < n; i += 1024) {
         const uint32_t s = sa[i];
         da[i] = r.sp_len[base + i];

@@ -75,17 +75,19 @@ struct TcpBlock {
         const int v = owner[slot];
         return (v < 0 || (uint32_t)v < t) ? v : KNZ_TCP_NIL;
     }
-    // entry `code` is the word (hash h, length n, letters at w): pe.hash == h && length equal && sameWords from the second letter on
-    __device__ __forceinline__ bool match(int code, uint32_t h, int n, const uint8_t* w, bool wsafe) const {
-        if (code == KNZ_TCP_NIL) return false;
+    // is entry `code` the word (hash h, length n, letters at w)? 0: pe.hash != h or another length (the reference then looks at the second
+    // slot, :783-788); 1: yes; 2: hash and length agree but sameWords (from the second letter on, :791-795) fails: a hash collision, the
+    // word counts as not found and the second slot is NOT consulted
+    __device__ __forceinline__ int match(int code, uint32_t h, int n, const uint8_t* w, bool wsafe) const {
+        if (code == KNZ_TCP_NIL) return 0;
         const uint8_t* e;
         if (code < 0) {
             const uint32_t idx = (uint32_t)(-1 - code);
-            if (idx >= KNZ_TC_STATIC) return false;                       // codec 1's escape entries: one letter
-            if (stat[idx] != h || (int)(stat[KNZ_TC_STATIC + idx] >> 24) != n) return false;
+            if (idx >= KNZ_TC_STATIC) return 0;                           // codec 1's escape entries: one letter
+            if (stat[idx] != h || (int)(stat[KNZ_TC_STATIC + idx] >> 24) != n) return 0;
             e = letters + stat[2 * KNZ_TC_STATIC + idx];
         } else {
-            if (h1[code] != h || (int)len[code] != n) return false;
+            if (h1[code] != h || (int)len[code] != n) return 0;
             e = src + tok_end[code] - n;                                   // (an earlier word of the block: readable wherever w is)
         }
         if (wsafe) {                                                         // 8 bytes at a time (both sides readable up to 7 bytes past the word)
@@ -93,12 +95,12 @@ struct TcpBlock {
                 uint64_t x = knz_vle64(e + k) ^ knz_vle64(w + k);
                 if (k == 0) x &= ~(uint64_t)0xFF;                                // the first letter is not compared (:793)
                 if (n - k < 8) x &= ((uint64_t)1 << (8 * (n - k))) - 1;
-                if (x) return false;
+                if (x) return 2;
             }
-            return true;
+            return 1;
         }
-        for (int k = 1; k < n; k++) if (e[k] != w[k]) return false;
-        return true;
+        for (int k = 1; k < n; k++) if (e[k] != w[k]) return 2;
+        return 1;
     }
     // P[] of the current guess, the table of who made the r-th entry and the slot owners (atomicMin), 4 tokens per thread and step;
     // returns the number of entries made
@@ -241,8 +243,9 @@ __global__ __launch_bounds__(KNZ_TCP_THREADS) void knz_text_forward_par_kernel(T
             int hit = KNZ_TCP_NIL;
             uint32_t via2 = 0;
             const bool wsafe = (int)k.tok_end[t] - n + 40 <= count;           // 8-byte reads stay inside the block
-            if (k.match(c1, h1, n, w, wsafe)) hit = c1;
-            else { const int c2 = k.content(h2 & k.mask, t, p); if (k.match(c2, h2, n, w, wsafe)) { hit = c2; via2 = 1; } }
+            const int m1 = k.match(c1, h1, n, w, wsafe);
+            if (m1 == 1) hit = c1;
+            else if (m1 == 0) { const int c2 = k.content(h2 & k.mask, t, p); if (k.match(c2, h2, n, w, wsafe) == 1) { hit = c2; via2 = 1; } }
             const bool qual = n > 3 || (n == 3 && k.staticSize + (int)p < 16384);
             const uint32_t nv = (hit == KNZ_TCP_NIL && qual && c1 == KNZ_TCP_NIL) ? 1u : 0u;
             if (nv != k.ins[t]) { k.ins[t] = (uint8_t)nv; changed = true; }

@@ -888,6 +888,23 @@ def check_text(be, n=200_000, chain=False, streams=TEXT_STREAMS, bs_stream=1 << 
         c.close()
 
 
+def check_text_foreign_handle(be, n=60_000):
+    """A stream is decoded with what ITS header says: TEXT streams (whose format follows ctx["entropy"] and whose hash size follows
+    ctx["blockSize"], Factory.go:100-120, TextCodec.go:610-650) decoded through handles opened with another entropy codec and block size."""
+    import text_corpus
+    data = text_corpus.make_text(n, seed=11)
+    for (tr, en, bs), (tr2, en2, bs2) in ((("TEXT", "ANS1", 1 << 15), ("NONE", "HUFFMAN", 1 << 20)), (("TEXT+UTF", "HUFFMAN", 1 << 14), ("TEXT", "FPAQ", 1 << 22)),
+                                           (("TEXT", "NONE", 1 << 16), ("BWT", "ANS1", 1 << 13))):
+        exp = O.compress(data, tr, en, bs)
+        c = K.Codec(tr2, en2, bs2, lib=be.lib)
+        sp, ks = be.to_dev(exp, 4)
+        out, kout = be.empty(n + 4096)
+        nd = c.dev_decompress(sp, len(exp), out, n + 4096)
+        assert nd == n, (tr, en, bs, tr2, en2, bs2)
+        assert be.to_host(kout, nd) == data, (tr, en, bs, tr2, en2, bs2)
+        c.close()
+
+
 def check_text_damaged(be, trials=60, n=20_000, seed=1):
     """TEXT inverse on damaged input: byte flips, truncations and spliced index bytes in valid encodings. Whatever the reference's scan does
     with them (fail, or decode to something else) both device paths must do as well: same bytes or an error where the oracle fails."""

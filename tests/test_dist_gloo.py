@@ -58,7 +58,10 @@ print("rank", rank, "ok")
                                  ("HUFFMAN", 1 << 16, 1000, 2, "NONE"),
                                  ("ANS1", 1 << 14, 4 * (1 << 14) + 4321, 2, "BWT+RANK+ZRLT"),      # configs[3] pipeline, uneven last rank (3 + 2 blocks, ragged tail)
                                  ("ANS1", 1 << 14, 2 * (1 << 14) + 99, 3, "BWT+RANK+ZRLT"),        # 3 blocks over 3 ranks, the last one 99 bytes
-                                 ("ANS0", 1 << 14, 4 * (1 << 14) + 321, 2, "TEXT+UTF+BWT+RANK+ZRLT")])   # the -l 5 sequence on text, 3 + 2 blocks
+                                 ("ANS0", 1 << 14, 4 * (1 << 14) + 321, 2, "TEXT+UTF+BWT+RANK+ZRLT"),    # the -l 5 sequence on text, 3 + 2 blocks
+                                 # the bench's block -> rank map: 26 blocks (25 full + a short one, like S-silesia at -b 8m) over 4 ranks = 7,7,6,6
+                                 ("ANS1", 1 << 12, 25 * (1 << 12) + 1095, 4, "BWT+RANK+ZRLT"),
+                                 ("ANS0", 1 << 12, 25 * (1 << 12) + 1095, 4, "LZ")])                      # the pipeline that scales (configs[2]), same map
 def test_two_ranks_gloo(cfg, tmp_path):
     entropy, bs, n, world, transform = cfg
     import knz

@@ -136,6 +136,10 @@ def test_lz_inverse_forms(be, monkeypatch):
     P.check_lz_inverse_forms(be, monkeypatch)
 
 
+def test_text_stream_through_foreign_handle(be):
+    P.check_text_foreign_handle(be)
+
+
 def test_lz_forward_forms(be, monkeypatch):
     """Segment-parallel LZ parse (fixed point over segment entry states and hole maps, lz_fwd_seg.hip) against the two one-wave forms."""
     P.check_lz_forward_forms(be, monkeypatch, segs=(256,))
