@@ -378,10 +378,53 @@ struct Ans1DecArgs {
     int32_t* blk_status;
 };
 
-// Parses the chunk header at reader position r (decodeHeader :605-710). When freq16 != nullptr the frequencies of
-// context k are stored at freq16[k*256 + sym]; returns false on an invalid header. Used by the walker too.
+// One context of a chunk header (decodeHeader :605-710: alphabet, then the frequencies in groups of 6 / 8 behind their bit width).
+// f != nullptr: the frequencies are stored at f[sym] (f zeroed by the caller); f == nullptr: position walk only, the frequency bits are
+// skipped a group at a time (their values are checked by whoever parses the context for real). Returns false on an invalid header.
 template <typename R>
-__device__ static bool knz_ans1_parse_header(R& r, uint16_t* freq16, uint32_t& lrOut, int& totalAlpha) {
+__device__ static bool knz_ans1_parse_ctx(R& r, uint16_t* f, uint32_t llr, uint32_t scale, int& countOut) {
+    uint8_t alpha[256];
+    int count = 0;
+    if (r.read(1) == 0) {
+        if (r.read(1) == 1) count = 0;
+        else { count = 256; if (f) for (int i = 0; i < 256; i++) alpha[i] = (uint8_t)i; }
+    } else {
+        const uint32_t lastMask = r.read(5);
+        for (uint32_t mm = 0; mm <= lastMask; mm++) {
+            const uint32_t mask = r.read(8);
+            if (f) { for (int j = 0; j < 8; j++) if ((mask >> j) & 1) alpha[count++] = (uint8_t)(8 * mm + j); }
+            else count += __popc(mask);                        // position walk only: the symbols themselves are not needed
+        }
+    }
+    countOut = count;
+    if (count == 0) return true;
+    const int chk = count < 64 ? 6 : 8;
+    uint32_t sum = 0;
+    for (int i = 1; i < count; i += chk) {
+        const uint32_t logMax = r.read(llr);
+        if ((1u << logMax) > scale) return false;
+        const int endj = min(i + chk, count);
+        if (!f) { r.seek(r.tell() + (uint64_t)(endj - i) * logMax); continue; }
+        for (int j = i; j < endj; j++) {
+            uint32_t fr = 1;
+            if (logMax > 0) { fr = 1 + r.read(logMax); if (fr >= scale) return false; }
+            f[alpha[j]] = (uint16_t)fr;
+            sum += fr;
+        }
+    }
+    if (f) {
+        if (scale <= sum) return false;
+        f[alpha[0]] = (uint16_t)(scale - sum);
+    }
+    return true;
+}
+
+// Parses the chunk header at reader position r. When freq16 != nullptr the frequencies of context k are stored at freq16[k*256 + sym].
+// When ctxpos != nullptr (the walker: every lane runs the same parse, `store` = the lane that writes) the bit position of every context's
+// header is left in ctxpos[0..255] and the position behind the last one in ctxpos[256]: the table kernel then parses the 256 contexts side
+// by side. Returns false on an invalid header.
+template <typename R>
+__device__ static bool knz_ans1_parse_header(R& r, uint16_t* freq16, uint32_t& lrOut, int& totalAlpha, uint64_t* ctxpos, bool store) {
     const uint32_t lr = 8 + r.read(3);
     lrOut = lr;
     if (lr > 16) return false;
@@ -389,46 +432,21 @@ __device__ static bool knz_ans1_parse_header(R& r, uint16_t* freq16, uint32_t& l
     while ((1u << llr) <= lr) llr++;
     const uint32_t scale = 1u << lr;
     totalAlpha = 0;
-    uint8_t alpha[256];
     for (int k = 0; k < 256; k++) {
+        if (ctxpos && store) ctxpos[k] = r.tell();
         int count = 0;
-        if (r.read(1) == 0) {
-            if (r.read(1) == 1) count = 0;
-            else { count = 256; if (freq16) for (int i = 0; i < 256; i++) alpha[i] = (uint8_t)i; }
-        } else {
-            const uint32_t lastMask = r.read(5);
-            for (uint32_t mm = 0; mm <= lastMask; mm++) {
-                const uint32_t mask = r.read(8);
-                if (freq16) { for (int j = 0; j < 8; j++) if ((mask >> j) & 1) alpha[count++] = (uint8_t)(8 * mm + j); }
-                else count += __popc(mask);                    // position walk only: the symbols themselves are not needed
-            }
-        }
-        if (count == 0) continue;
-        uint16_t* f = freq16 ? freq16 + (size_t)k * 256 : nullptr;
-        const int chk = count < 64 ? 6 : 8;
-        uint32_t sum = 0;
-        for (int i = 1; i < count; i += chk) {
-            const uint32_t logMax = r.read(llr);
-            if ((1u << logMax) > scale) return false;
-            const int endj = min(i + chk, count);
-            for (int j = i; j < endj; j++) {
-                uint32_t fr = 1;
-                if (logMax > 0) { fr = 1 + r.read(logMax); if (fr >= scale) return false; }
-                if (f) f[alpha[j]] = (uint16_t)fr;
-                sum += fr;
-            }
-        }
-        if (scale <= sum) return false;
-        if (f) f[alpha[0]] = (uint16_t)(scale - sum);
+        if (!knz_ans1_parse_ctx(r, freq16 ? freq16 + (size_t)k * 256 : nullptr, llr, scale, count)) return false;
         totalAlpha += count;
     }
+    if (ctxpos && store) ctxpos[256] = r.tell();
     return true;
 }
 
 // one workgroup per chunk: lane 0 parses the 256 context headers, then all threads fill the slot table
-__global__ __launch_bounds__(256) void knz_ans1_dec_tables_kernel(Ans1DecArgs a, uint16_t* freq16, uint16_t* cum16) {
+__global__ __launch_bounds__(256) void knz_ans1_dec_tables_kernel(Ans1DecArgs a, uint16_t* freq16, uint16_t* cum16, const uint64_t* ctx_bit) {
     __shared__ int s_mode;
     __shared__ uint32_t s_lr;
+    __shared__ int s_total, s_badctx;
     const int tid = threadIdx.x;
     const uint32_t slotId = blockIdx.x;
     const uint32_t b = slotId / a.chunks_per_block, k = slotId % a.chunks_per_block;
@@ -440,12 +458,34 @@ __global__ __launch_bounds__(256) void knz_ans1_dec_tables_kernel(Ans1DecArgs a,
     uint16_t* f16 = freq16 + (size_t)slotId * 65536;
     for (int i = tid; i < 65536; i += 256) f16[i] = 0;
     __syncthreads();
+    // the walker left the bit position of every context header (round 3): thread = context parses its own; without them (tests of the
+    // single entropy object come through the same walker, so this is the only caller) thread 0 parses all 256 in a row
+    const uint64_t* cpos = ctx_bit ? ctx_bit + (size_t)slotId * 257 : nullptr;
+    if (cpos) {
+        if (tid == 0) { s_total = 0; s_badctx = 0; }
+        __syncthreads();
+        KnzStreamReader r0;
+        r0.init(a.stream, a.nbytes, a.chunk_bit[slotId]);
+        const uint32_t lr = 8 + r0.read(3);
+        uint32_t llr = 3;
+        while ((1u << llr) <= lr) llr++;
+        if (lr <= 16) {
+            KnzStreamReader r;
+            r.init(a.stream, a.nbytes, cpos[tid]);
+            int count = 0;
+            if (!knz_ans1_parse_ctx(r, f16 + (size_t)tid * 256, llr, 1u << lr, count) || r.tell() != cpos[tid + 1]) s_badctx = 1;
+            if (count) atomicAdd(&s_total, count);
+        } else if (tid == 0) s_badctx = 1;
+        if (tid == 0) s_lr = lr;
+        __syncthreads();
+    }
     if (tid == 0) {
         KnzStreamReader r;
-        r.init(a.stream, a.nbytes, a.chunk_bit[slotId]);
-        uint32_t lr = 0; int total = 0;
+        r.init(a.stream, a.nbytes, cpos ? cpos[256] : a.chunk_bit[slotId]);
+        uint32_t lr = cpos ? s_lr : 0; int total = cpos ? s_total : 0;
         int m = 3;
-        if (!knz_ans1_parse_header(r, f16, lr, total) || total == 0 || lr != KNZ_ANS1_LR) m = -1;   // encoder only produces lr 11
+        if (cpos ? (s_badctx != 0 || total == 0 || lr != KNZ_ANS1_LR)
+                 : (!knz_ans1_parse_header(r, f16, lr, total, nullptr, false) || total == 0 || lr != KNZ_ANS1_LR)) m = -1;   // encoder only produces lr 11
         else {
             const uint32_t sz = knz_read_varint(r);
             if (sz >= (1u << 27)) m = -1;
@@ -610,6 +650,99 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds_kernel(Ans1DecArgs a, 
             for (uint32_t i = l; i < m; i += 16) qdst[base + i] = s_ob[g][i];
             wave_sync();
         }
+    }
+    if (lane == 0) {
+        for (uint32_t i = end4; i < n; i++)
+            dst[i] = (uint8_t)(knz_fetch32(a.stream, (int64_t)(paybit + 16ull * cnt + 8ull * (i - end4)), (int64_t)limit) >> 24);
+    }
+}
+
+// The same decoder with the per-step bookkeeping taken off the chain (round 3). The loop above spends 75 instructions per step of
+// 4 symbols, of which the two 16-way searches and the state update are ~40: the rest was (a) ten scalar instructions that pull the
+// four "needs a word" bits out of the ballot (each one a VALU -> SALU hand-over), (b) a predicated byte store per symbol, (c) the
+// "ring low?" and "256 symbols decoded?" tests on every step. Here: tiles of 256 steps with the ring topped up and the output
+// flushed between tiles only; the rank of a state among the states that refill in the same step (refill order st3, st2, st1, st0,
+// :918-949) is a popcount of the ballot under per-lane masks (vector ALU only); four decoded symbols are collected in a register
+// and leave as one LDS dword; the renormalisation word is read unconditionally and selected.
+#define KNZ_ANS1_PAYRING2 4096                        // words: a tile of 256 steps consumes at most 1024
+__global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a, const uint16_t* cum16) {
+    __shared__ uint16_t s_cum[256 * KNZ_ANS1_CUM_STRIDE];
+    __shared__ uint16_t s_pay[KNZ_ANS1_PAYRING2];
+    __shared__ uint32_t s_ob[4][64];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    const uint32_t slotId = blockIdx.x;
+    const uint64_t limit = a.nbytes << 3;
+    const uint32_t b = slotId / a.chunks_per_block, k = slotId % a.chunks_per_block;
+    if (a.info[(size_t)slotId * 8] != 3 || a.blk_status[b] != 0) return;
+    const uint32_t preLen = a.blk_pre_len[b];
+    const uint32_t n = min(KNZ_ANS1_CHUNK, preLen - k * KNZ_ANS1_CHUNK);
+    uint8_t* dst = (uint8_t*)a.blk_out_off[b] + (size_t)k * KNZ_ANS1_CHUNK;
+    const uint64_t paybit = a.paybit[slotId];
+    {
+        const uint32_t* src = (const uint32_t*)(cum16 + (size_t)slotId * 256 * KNZ_ANS1_CUM_STRIDE);   // 131,584 B, 4-byte aligned
+        for (uint32_t i = lane; i < 256 * KNZ_ANS1_CUM_STRIDE / 2; i += 64) ((uint32_t*)s_cum)[i] = src[i];
+    }
+    uint32_t st = a.info[(size_t)slotId * 8 + 1 + g];
+    const uint32_t end4 = n & ~3u;
+    const uint32_t q = end4 >> 2;
+    uint8_t* qdst = dst + (size_t)g * q;
+    uint32_t ctx = 0, cnt = 0;
+    uint32_t payHi = 0;                                                  // words [payHi - ring, payHi) are staged
+    // ballot bits of the states that refill BEFORE this one in a step (the higher ones), and of all four states (lane 16 g' speaks for state g')
+    const uint64_t allm = 0x0001000100010001ull;
+    const uint64_t higher = g == 3 ? 0ull : (allm & ~(((uint64_t)1 << (16 * (g + 1))) - 1));
+    const uint32_t hLo = (uint32_t)higher, hHi = (uint32_t)(higher >> 32), aLo = (uint32_t)allm, aHi = (uint32_t)(allm >> 32);
+    const uint32_t sh = 16u * (uint32_t)g;
+    wave_sync();
+    for (uint32_t t0 = 0; t0 < q; t0 += 256) {
+        const uint32_t tn = min(256u, q - t0);
+        while (cnt + 1024 + 4 > payHi) {                                 // top the ring up (a quarter at a time: what is still unread stays)
+            wave_sync();
+            for (uint32_t j = lane; j < KNZ_ANS1_PAYRING2 / 4; j += 64) {
+                const uint32_t wi = payHi + j;
+                s_pay[wi & (KNZ_ANS1_PAYRING2 - 1)] = (uint16_t)(knz_fetch32(a.stream, (int64_t)(paybit + 16ull * wi), (int64_t)limit) >> 16);
+            }
+            payHi += KNZ_ANS1_PAYRING2 / 4;
+            wave_sync();
+        }
+        uint32_t acc = 0;
+        // one step of the four states; SHIFT = where the symbol goes in the collected word
+        auto step = [&](uint32_t shift) {
+            const uint32_t slot = st & (KNZ_ANS1_SCALE - 1);
+            const uint16_t* cq = s_cum + ctx * KNZ_ANS1_CUM_STRIDE;
+            // 16 x 16 search: largest s with cum[s] <= slot (an absent symbol shares its cum with the next present one)
+            const uint32_t mA = (uint32_t)(wave_ballot(cq[16 * l] <= slot) >> sh) & 0xFFFFu;
+            const uint32_t gi = (uint32_t)__popc(mA) - 1;
+            const uint32_t mB = (uint32_t)(wave_ballot(cq[16 * gi + l] <= slot) >> sh) & 0xFFFFu;
+            const uint32_t sym = 16 * gi + (uint32_t)__popc(mB) - 1;
+            const uint32_t lo = cq[sym], hi = cq[sym + 1];
+            const uint32_t fr = min(hi - lo, (uint32_t)KNZ_ANS1_SCALE - 1);     // decSymbol.reset :972-977
+            st = fr * (st >> KNZ_ANS1_LR) + slot - lo;                          // (:846-858)
+            ctx = sym;
+            acc |= sym << shift;
+            const bool need = st < (1u << 15);
+            const uint64_t nb = wave_ballot(need);
+            const uint32_t nlo = (uint32_t)nb, nhi = (uint32_t)(nb >> 32);
+            const uint32_t r = cnt + (uint32_t)__popc(nlo & hLo) + (uint32_t)__popc(nhi & hHi);   // refill order st3, st2, st1, st0 (:918-949)
+            const uint32_t w = wave_in_vgpr(s_pay[r & (KNZ_ANS1_PAYRING2 - 1)]);                    // read whether needed or not: no branch around it
+            st = need ? ((st << 16) | w) : st;
+            cnt += (uint32_t)__popc(nlo & aLo) + (uint32_t)__popc(nhi & aHi);
+        };
+        const uint32_t t4 = tn >> 2;
+        for (uint32_t tq = 0; tq < t4; tq++) {
+            step(0); step(8); step(16); step(24);
+            s_ob[g][tq] = acc;                                                  // (all 16 lanes of the state hold the same word)
+            acc = 0;
+        }
+        for (uint32_t t = 4 * t4; t < tn; t++) step(8 * (t & 3));
+        if (tn & 3) s_ob[g][tn >> 2] = acc;
+        wave_sync();
+        {
+            const uint8_t* ob = (const uint8_t*)s_ob[g];
+            for (uint32_t i = l; i < tn; i += 16) qdst[t0 + i] = ob[i];
+        }
+        wave_sync();
     }
     if (lane == 0) {
         for (uint32_t i = end4; i < n; i++)

@@ -104,7 +104,7 @@ __device__ __forceinline__ uint32_t knz_read_varint(R& r) {
 }
 
 template <typename R>
-__device__ static bool knz_ans1_parse_header(R& r, uint16_t* freq16, uint32_t& lrOut, int& totalAlpha);
+__device__ static bool knz_ans1_parse_header(R& r, uint16_t* freq16, uint32_t& lrOut, int& totalAlpha, uint64_t* ctxpos, bool store);
 
 struct WalkStreamArgs {
     const uint8_t* stream; uint64_t nbytes;
@@ -167,6 +167,7 @@ struct WalkBlocksArgs {
     uint64_t* out_off;            // [nblocks] out_base + b * out_stride
     uint64_t out_base, out_stride, out_cap;
     uint32_t stream_block_size;
+    uint64_t* ans1_ctx_bit;       // [nblocks * CPB][257] rANS order 1: bit position of every context header of a chunk (+ the end), or null
 };
 
 // Skips one signed Exp-Golomb code (ExpGolombCodec.go:159-190): '1' or L zeros, 1, L+1 bits.

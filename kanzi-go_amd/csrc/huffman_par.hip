@@ -724,7 +724,7 @@ __device__ __forceinline__ void knz_walk_block_body(const WalkBlocksArgs& a, con
                 r.seek(r.tell() + 56 + 8ull * szb);
             } else if (entropy == KNZ_E_ANS1) {
                 uint32_t lr; int total;
-                if (!knz_ans1_parse_header(r, nullptr, lr, total) || total == 0) { status = KNZ_ERR_PROCESS_BLOCK; break; }
+                if (!knz_ans1_parse_header(r, nullptr, lr, total, a.ans1_ctx_bit ? a.ans1_ctx_bit + ((size_t)b * cpb + k) * 257 : nullptr, writer) || total == 0) { status = KNZ_ERR_PROCESS_BLOCK; break; }
                 const uint32_t szb = knz_read_varint(r);
                 if (szb >= (1u << 27)) status = KNZ_ERR_PROCESS_BLOCK;
                 r.seek(r.tell() + 128 + 8ull * szb);

@@ -54,7 +54,7 @@ struct Handle {
     size_t lzs_n = 0;                 // blocks covered by lzs_misc's state bytes in the last LZ forward stage
     uint32_t lzs_rounds = 0;          // rounds its fixed point took
     size_t lzi_serial_n = 0;          // blocks covered by lzi_serial in the last LZ inverse stage (1 = went to the one-wave kernel)
-    DevBuf a1_freqs, a1_tab, a1_ctxhdr, a1_ctxbits, a1_dtab, a1_info, a1_paybit, a1_f16, a1_ent, a1_cum;
+    DevBuf a1_freqs, a1_tab, a1_ctxhdr, a1_ctxbits, a1_dtab, a1_info, a1_paybit, a1_f16, a1_ent, a1_cum, a1_ctxpos;
     DevBuf sa_keys0, sa_keys1, sa_vals0, sa_vals1, sa_rank, sa_gs, sa_head, sa_unres, sa_pos, sa_tmp, sa_links, sa_sp;
     void* pinned = nullptr;           // small pinned host area for results
     int32_t* pinned_status = nullptr; // pinned per-block tables of the last encode batch (grow-only)

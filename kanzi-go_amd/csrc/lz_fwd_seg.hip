@@ -28,6 +28,7 @@
 #define KNZ_LZS_SEG 16384u
 #define KNZ_LZS_MAX_ROUNDS 48
 #define KNZ_LZS_NEVER 0xFFFFFFFFu
+#define KNZ_LZS_COARSE 512u                          // words of the coarse hole map (one bit per 2^cs positions)
 
 struct LzSegArgs {
     LzParArgs pa;                  // source blocks, cand[], cp8[] (pa.holes unused here)
@@ -40,7 +41,7 @@ struct LzSegArgs {
     uint8_t* need;                 // [nblocks][segs] parse in this round
     uint4* tok;                    // [nblocks][segs][tok_cap] {literal start, literal length, match length | flag << 24, distance}
     uint32_t* Jp; uint32_t* Mp; uint32_t* Jn; uint32_t* Mn;     // hole maps of the previous / this round, [nblocks][map_stride]
-    uint32_t* Cp; uint32_t* Cn;    // coarse maps [nblocks][2048]: the region holds (or held) jumped-over positions
+    uint32_t* Cp; uint32_t* Cn;    // coarse maps [nblocks][KNZ_LZS_COARSE]: the region holds (or held) jumped-over positions
     uint32_t* Sp; uint32_t* Sn;    // [nblocks][2] any jumped-over position, the largest one
     uint64_t map_stride;
     uint8_t* blk_state;            // [nblocks] 0 running, 1 settled, 2 left to the one-wave kernel, 3 not a block for this stage, 4 declined before any parse (answered by the one-wave kernel)
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(64) void knz_lzs_init_kernel(LzSegArgs g) {
 }
 
 __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
-    __shared__ uint32_t s_coarse[2048];
+    __shared__ uint32_t s_coarse[KNZ_LZS_COARSE];                       // 2 KiB: the waves of a CU are limited by their wave slots, not by LDS
     const LzArgs& a = g.pa.a;
     const int lane = threadIdx.x;
     const bool writer = lane == 0;
@@ -110,10 +111,10 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
     const uint8_t* cp8 = g.pa.cp8 + g.pa.gstart[b];
     const uint32_t* Jp = g.Jp + (size_t)b * g.map_stride; const uint32_t* Mp = g.Mp + (size_t)b * g.map_stride;
     uint32_t* Jn = g.Jn + (size_t)b * g.map_stride; uint32_t* Mn = g.Mn + (size_t)b * g.map_stride;
-    uint32_t* Cn = g.Cn + (size_t)b * 2048;
+    uint32_t* Cn = g.Cn + (size_t)b * KNZ_LZS_COARSE;
     unsigned cs = 6;
-    while (((uint32_t)count >> cs) >= 65536u) cs++;
-    { const uint32_t* Cp = g.Cp + (size_t)b * 2048; for (int i = lane; i < 2048; i += 64) s_coarse[i] = Cp[i]; }
+    while (((uint32_t)count >> cs) >= 32u * KNZ_LZS_COARSE) cs++;
+    { const uint32_t* Cp = g.Cp + (size_t)b * KNZ_LZS_COARSE; for (int i = lane; i < (int)KNZ_LZS_COARSE; i += 64) s_coarse[i] = Cp[i]; }
     wave_sync();
     bool anyHoles = g.Sp[2 * b] != 0;
     int maxHole = anyHoles ? (int)g.Sp[2 * b + 1] : -1;

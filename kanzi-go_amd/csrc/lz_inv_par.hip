@@ -46,7 +46,7 @@ struct LziArgs {
     uint32_t* t_c;                 // pass A: literal-length extensions in front of the token ; pass B: its literal length
     uint32_t* t_d;                 // pass A: match-length extensions in front of the token ; pass B: output position of its literals ([nTok] = total)
     uint32_t* seg;                 // [nblocks][segs][8]
-    uint32_t* lx_g;                // per literal-length extension: t_a of its token
+    uint32_t* lx_g;                // per literal-length extension: 13 + t_a of its token
     uint32_t* lx_c;                // extension bytes + extension values in front of it ([n] = total): size and value of one = the difference
     uint32_t* ml_val;              // values of the match-length extension records, in order
     uint32_t* map; uint64_t map_stride;
@@ -186,79 +186,74 @@ __global__ __launch_bounds__(256) void knz_lzi_a_apply_kernel(LziArgs g) {
         const LziTok k = knz_lzi_token((uint32_t)(w >> (8 * j)) & 0xFFu, k0 + j == nTok - 1);
         const size_t i = tb + k0 + j;
         g.t_a[i] = a; g.t_b[i] = d; g.t_c[i] = c; g.t_d[i] = m;
-        if (k.lext) g.lx_g[tb + c] = a;
+        if (k.lext) g.lx_g[tb + c] = 13u + a;
         a += k.lit; d += k.dbytes; c += k.lext; m += k.mext;
     }
 }
 
 // ---- literal lengths >= 7: the extension sits in the literal stream at the literal cursor (:657-661), so its position depends on
-// every extension in front of it: one wave per block walks them. The chain is  C -> byte at (13 + g[i] + C) -> C + 1 + byte : the
-// literal region is staged through a 32 KiB LDS window by all lanes (the chain only moves forward), the g[i] come 1024 at a time,
-// and a step is one dependent LDS read plus a handful of wave-uniform vector instructions. The chain stores C in front of every
-// extension (64 steps per coalesced store); its size and value are recovered from the differences, which is unambiguous for
-// the records an encoder writes (emitLengthLZ :193-212: 1 byte below 254, 3 bytes below 65790, else 4): anything else leaves
-// the block to the one-wave kernel.
-#define KNZ_LZI_WIN 32768u
+// every extension in front of it: one wave per block walks them. The chain is  C -> byte at (13 + g[i] + C) -> C + 1 + byte  and it is
+// kept on the scalar unit: the g[i] arrive through the scalar cache eight at a time; the literal region is held as two 256-byte
+// windows in two vector registers (lane L = dword L; the window behind the current one is loaded while the current one is walked),
+// so that the byte at the cursor is one v_readlane and three scalar instructions away, with no memory access on the chain at all.
+// The chain stores C in front of every extension (64 steps per coalesced store); size and value of an extension are recovered from
+// the differences, which is unambiguous for the records an encoder writes (emitLengthLZ :193-212: 1 byte below 254, 3 bytes below
+// 65790, else 4): anything else leaves the block to the one-wave kernel.
 __device__ __forceinline__ void knz_lzi_ext_from_diff(uint32_t d, uint32_t& sz, uint32_t& val) {
     sz = d < 255u ? 1u : (d < 65793u ? 3u : 4u);
     val = d - sz;
 }
 __global__ __launch_bounds__(64) void knz_lzi_litext_chain_kernel(LziArgs g) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_lit[KNZ_LZI_WIN];
-    __shared__ __attribute__((aligned(16))) uint32_t s_g[1024];
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
     uint32_t* G = g.geo + 16 * (size_t)b;
     if (!G[LZI_PAR]) return;
-    const uint32_t E = G[LZI_NLEXT], tk0 = G[LZI_TK0], count = G[LZI_COUNT];
+    const uint32_t E = wave_uniform(G[LZI_NLEXT]), tk0 = wave_uniform(G[LZI_TK0]), count = wave_uniform(G[LZI_COUNT]);
     const uint8_t* src = (const uint8_t*)g.a.in_ptr[b];
     const size_t tb = g.tok_base[b];
-    const uint32_t* lg = g.lx_g + tb;
+    const uint8_t* lg = (const uint8_t*)(g.lx_g + tb);
     uint32_t* lc = g.lx_c + tb;
-    uint32_t C = 0, wlo = 0, whi = 0, hist = 0;
-    bool bad = ((uintptr_t)src & 15) != 0;                                   // (the pipeline's regions are 16-byte aligned)
-    for (uint32_t i0 = 0; i0 < E && !bad; i0 += 1024) {
-        const uint32_t n = min(1024u, E - i0);
-        wave_sync();
-        for (uint32_t j = lane; j < 1024; j += 64) s_g[j] = j < n ? lg[i0 + j] : 0u;
-        wave_sync();
-        // four steps per trip: their g values arrive as one 16-byte LDS read ahead of the chain, which leaves the byte at the cursor as the
-        // only dependent LDS access of a step
-        for (uint32_t j4 = 0; j4 < n && !bad; j4 += 4) {
-            const uint4 gq = *(const uint4*)(s_g + j4);
-            const uint32_t gv[4] = {gq.x, gq.y, gq.z, gq.w};
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t j = j4 + (uint32_t)u;
-                if (j >= n || bad) break;
-                const uint32_t pos = 13u + gv[u] + C;
-                if (pos + 4 > whi) {                                           // (pos only grows: it never falls in front of the window)
-                    if (pos >= tk0) { bad = true; break; }
-                    wlo = pos & ~15u; whi = wlo + KNZ_LZI_WIN;
-                    wave_sync();
-                    for (uint32_t o = lane * 16; o < KNZ_LZI_WIN; o += 1024) {
-                        uint4 v; v.x = v.y = v.z = v.w = 0;
-                        if (wlo + o < count) v = *(const uint4*)(src + wlo + o);   // (whole 16-byte words: the regions carry that much slack behind count)
-                        *(uint4*)(s_lit + o) = v;
-                    }
-                    wave_sync();
-                }
-                const uint32_t o = pos - wlo;
-                const uint32_t b0 = s_lit[o];
-                uint32_t d = b0 + 1u;
-                if (b0 >= 254) {
-                    const uint32_t b1 = s_lit[o + 1], b2 = s_lit[o + 2], b3 = s_lit[o + 3];
-                    if (b0 == 254) d = 3u + 254u + (b1 << 8) + b2;
-                    else { const uint32_t y = (b1 << 16) + (b2 << 8) + b3; if (y < 65535u) { bad = true; break; } d = 4u + 255u + y; }
-                }
-                if (pos + (d < 255u ? 1u : (d < 65793u ? 3u : 4u)) > tk0) { bad = true; break; }
-                hist = lane == (j & 63u) ? C : hist;
-                C += d;
-                if (C >= 0x40000000u) { bad = true; break; }
-            }
-            if ((j4 & 63u) == 60u && !bad) lc[i0 + (j4 & ~63u) + lane] = hist;   // 64 steps done (n is a whole number of such rows except in the last chunk)
+    uint32_t C = 0, hist = 0;
+    bool bad = ((uintptr_t)src & 3) != 0;                                    // (the pipeline's regions are 16-byte aligned)
+    // windows: w0 = the 64 dwords at wlo, w1 = the 64 dwords behind them (zero behind the end of the block)
+    auto load_win = [&](uint32_t at) -> uint32_t { const uint32_t o = at + 4 * lane; return o < count ? *(const uint32_t*)(src + o) : 0u; };
+    uint32_t wlo = 12;                                                        // the literals start at 13
+    uint32_t w0 = bad ? 0u : load_win(wlo), w1 = bad ? 0u : load_win(wlo + 256);
+    // one step. What a damaged stream can do to the walk (a cursor behind the literals, a sum that wraps) is not tested per step: the
+    // window loads are bounded by the block, the walk takes exactly E steps, and pass B checks every token's literal range against the
+    // end of the literals (a block that fails there goes to the one-wave kernel).
+    auto step = [&](uint32_t gj, uint32_t j) {
+        const uint32_t pos = gj + C;                                           // (g[] holds 13 + the short literal bytes in front)
+        uint32_t o = pos - wlo;
+        if (__builtin_expect(o >= 256, 0)) {                                   // (pos only grows: the cursor never falls in front of the window)
+            if (o < 512) { w0 = w1; wlo += 256; }
+            else { wlo = pos & ~3u; w0 = load_win(wlo); }                      // a jump over the whole next window
+            w1 = load_win(wlo + 256);
+            o = pos - wlo;
         }
-        if (!bad && (n & 63u) != 0 && lane < (n & 63u)) lc[i0 + (n & ~63u) + lane] = hist;
+        const uint32_t dw = wave_readlane(w0, o >> 2);
+        const uint32_t b0 = (dw >> (8 * (o & 3))) & 0xFFu;
+        uint32_t d = b0 + 1u;
+        if (__builtin_expect(b0 >= 254, 0)) {                                  // rare: the three / four byte forms, read where they stand
+            uint32_t b1 = 0, b2 = 0, b3 = 0;
+            if (pos + 4 <= count) { b1 = wave_uniform(src[pos + 1]); b2 = wave_uniform(src[pos + 2]); b3 = wave_uniform(src[pos + 3]); } else bad = true;
+            if (b0 == 254) d = 3u + 254u + (b1 << 8) + b2;
+            else { const uint32_t y = (b1 << 16) + (b2 << 8) + b3; if (y < 65535u) bad = true; d = 4u + 255u + y; }
+        }
+        hist = lane == j ? C : hist;
+        C += d;
+    };
+    for (uint32_t i0 = 0; i0 < E && !bad; i0 += 64) {
+        const uint32_t n = min(64u, E - i0);
+        uint32_t j = 0;
+        for (; j + 4 <= n; j += 4) {                                           // the g[i] through the scalar cache, four at a time
+            const uint8_t* gp = lg + 4 * (size_t)(i0 + j);
+            const uint32_t g0 = wave_sload_u32(gp), g1 = wave_sload_u32(gp + 4), g2 = wave_sload_u32(gp + 8), g3 = wave_sload_u32(gp + 12);
+            step(g0, j); step(g1, j + 1); step(g2, j + 2); step(g3, j + 3);
+        }
+        for (; j < n; j++) step(wave_sload_u32(lg + 4 * (size_t)(i0 + j)), j);
+        if (lane < n) lc[i0 + lane] = hist;
     }
+    if (C >= 0x40000000u) bad = true;
     if (lane == 0) { if (bad) G[LZI_PAR] = 0; else lc[E] = C; }
 }
 

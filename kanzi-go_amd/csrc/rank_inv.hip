@@ -320,6 +320,15 @@ __device__ __forceinline__ void knz_rank_chain_block_v(const uint8_t* src, uint8
     uint32_t i0 = 0;
     if ((((uintptr_t)src) & 3) == 0) {                                          // (the pipeline's own regions are 16-byte aligned)
         const uint32_t ng = n >> 4;                                             // whole groups of 16 ranks
+        // decoded symbols leave 64 at a time as one 64-byte row (round 3; 16 single bytes per group cost 1.5x the traffic: every line was
+        // written in four partial pieces). Four groups are collected in one register, group q in byte q of lanes 0..15; a 4 x 4 byte
+        // transpose inside every quad of lanes (two DPP moves + two byte permutes) turns that into four consecutive symbols per lane:
+        // lane 4a + b then holds the dword 4b + a of the row.
+        const bool rows = (((uintptr_t)dst) & 3) == 0;
+        const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
+        const uint32_t rowSlot = 4u * ((uint32_t)lane & 3u) + (((uint32_t)lane >> 2) & 3u);
+        uint32_t racc = 0, rsh = 0;
+        const uint32_t ngRows = rows ? (ng & ~3u) : 0u;                         // groups that lie in whole rows
         knz_u32x4 nxt = {0, 0, 0, 0};
         if (ng) nxt = wave_sload_u32x4(src);
         for (uint32_t g = 0; g < ng; g++) {
@@ -336,7 +345,16 @@ __device__ __forceinline__ void knz_rank_chain_block_v(const uint8_t* src, uint8
                 c.template word<0>(cur.x, i, ob); c.template word<1>(cur.y, i + 4, ob);
                 c.template word<2>(cur.z, i + 8, ob); c.template word<3>(cur.w, i + 12, ob);
             }
-            if (lane < 16) dst[i + lane] = (uint8_t)ob;
+            if (g < ngRows) {
+                racc |= (ob & 0xFFu) << rsh;
+                rsh += 8;
+                if (rsh == 32) {
+                    const uint32_t t = knz_byte_perm(wave_quad_xor1(racc), racc, sel1);
+                    const uint32_t o = knz_byte_perm(wave_quad_xor2(t), t, sel2);
+                    if (lane < 16) ((uint32_t*)(dst + (i - 48)))[rowSlot] = o;
+                    racc = 0; rsh = 0;
+                }
+            } else if (lane < 16) dst[i + lane] = (uint8_t)ob;
         }
         i0 = 16 * ng;
     }

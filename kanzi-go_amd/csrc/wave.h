@@ -101,6 +101,11 @@ __device__ __forceinline__ int32_t knz_wg_load_i32(const int32_t* p) { return __
 __device__ __forceinline__ int32_t knz_agent_load_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void knz_wg_max_i32(int32_t* p, int32_t v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wave_raise_priority() { __builtin_amdgcn_s_setprio(3); }
+// value of lane ^ 1 / lane ^ 2 (DPP quad_perm [1,0,3,2] / [2,3,0,1]) and the byte permute of two registers (v_perm_b32: selector byte 0..3 =
+// byte of lo, 4..7 = byte of hi)
+__device__ __forceinline__ uint32_t wave_quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t wave_quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t knz_byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 #else
 // ------------------------------------------------------------------ emulator (tests only)
 inline void wave_spin_pause() { hipemu::spin_pause(); }
@@ -114,6 +119,12 @@ inline int32_t knz_wg_load_i32(const int32_t* p) { return *(const volatile int32
 inline int32_t knz_agent_load_i32(const int32_t* p) { return *(const volatile int32_t*)p; }
 inline void knz_wg_max_i32(int32_t* p, int32_t v) { if (*(volatile int32_t*)p < v) *(volatile int32_t*)p = v; }
 inline void wave_raise_priority() {}
+inline uint32_t knz_byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+    const uint64_t both = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) r |= (uint32_t)((both >> (8 * ((sel >> (8 * i)) & 7u))) & 0xFFu) << (8 * i);
+    return r;
+}
 inline uint32_t knz_mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 inline uint32_t wave_uniform(uint32_t v) { return v; }
 inline int lane_id() { return hipemu::lane(); }
@@ -136,6 +147,8 @@ inline uint64_t wave_ballot(bool p) {
     return r;
 }
 inline uint32_t wave_bcast(uint32_t v, int src) { return wave_shfl(v, src); }
+inline uint32_t wave_quad_xor1(uint32_t v) { return wave_shfl(v, hipemu::lane() ^ 1); }
+inline uint32_t wave_quad_xor2(uint32_t v) { return wave_shfl(v, hipemu::lane() ^ 2); }
 inline uint32_t wave_readlane(uint32_t v, uint32_t src) { return wave_shfl(v, (int)src); }
 inline void wave_sync() { hipemu::wave_barrier(); }
 inline void wave_sync_lds() { hipemu::wave_barrier(); }

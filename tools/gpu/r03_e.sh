@@ -1,0 +1,9 @@
+#!/bin/bash
+mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_parity_gpu.py -x -q -k "rank or RANK or config4" > gpurun_out/e_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/e_pytest.log
+timeout 600 python bench.py --steps 3 --warmup 1 --no-pmc --no-cpu-baseline --no-host-hook > gpurun_out/e_bench_bwt.json 2> gpurun_out/e_bench_bwt.err; echo "bwt rc=$?"
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/e_bench_bwt.json').read().strip().splitlines()[-1])
+print(d['value'], d['encode_MBps'], d['decode_MBps'], d.get('bit_exact_vs_oracle'), d['roofline']['kernel_ms_per_step'], d['roofline']['all_stage_ms'])
+PY
