@@ -34,6 +34,7 @@ struct LzSegArgs {
     LzParArgs pa;                  // source blocks, cand[], cp8[] (pa.holes unused here)
     uint32_t seg_size, segs;       // positions per segment, segments per block covered by the grid
     uint32_t tok_cap;              // token descriptors per segment
+    uint32_t warm;                 // positions in front of its segment the first guess of a parse starts at
     uint32_t* entry;               // [nblocks][segs][5] srcIdx, anchor, repd0, repd1, srcInc | repdIdx << 31
     uint32_t* used;                // the entry state the segment's last parse started from (srcIdx = KNZ_LZS_NEVER: none yet)
     uint32_t* exit_;               // what that parse ended with
@@ -78,8 +79,11 @@ __global__ __launch_bounds__(64) void knz_lzs_init_kernel(LzSegArgs g) {
             for (uint32_t s = 0; s < g.segs; s++) {
                 const size_t si = (size_t)b * g.segs + s;
                 uint32_t* e = g.entry + 5 * si;
-                // first guess: the state right behind a match that ended at the segment start, repeat distances unknown
-                e[0] = s * g.seg_size; e[1] = s * g.seg_size; e[2] = (uint32_t)count; e[3] = (uint32_t)count; e[4] = s ? 0x80000000u : 0u;
+                // first guess: the state right behind a match that ended `warm` positions in front of the segment, repeat distances unknown: by
+                // the time such a parse crosses into the segment it has usually met the true one (the positions it passes on the way belong to
+                // the segment in front; what it writes there is replaced in the next round, when every segment gets its real entry state)
+                const uint32_t at = s ? s * g.seg_size - min(g.warm, g.seg_size) : 0u;
+                e[0] = at; e[1] = at; e[2] = (uint32_t)count; e[3] = (uint32_t)count; e[4] = s ? 0x80000000u : 0u;
                 g.used[5 * si] = KNZ_LZS_NEVER;
                 g.ntok[si] = 0;
                 g.need[si] = s < ns ? 1 : 0;

@@ -328,12 +328,12 @@ __device__ __forceinline__ void knz_rank_chain_block_v(const uint8_t* src, uint8
         const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
         const uint32_t rowSlot = 4u * ((uint32_t)lane & 3u) + (((uint32_t)lane >> 2) & 3u);
         uint32_t racc = 0, rsh = 0;
-        const uint32_t ngRows = rows ? (ng & ~3u) : 0u;                         // groups that lie in whole rows
+        const uint32_t ngRows = rows ? (ng & ~3u) : 0u;                         // groups that lie in whole rows: the loop takes these, the last < 64 ranks go byte by byte below
         knz_u32x4 nxt = {0, 0, 0, 0};
-        if (ng) nxt = wave_sload_u32x4(src);
-        for (uint32_t g = 0; g < ng; g++) {
+        if (ngRows) nxt = wave_sload_u32x4(src);
+        for (uint32_t g = 0; g < ngRows; g++) {
             const knz_u32x4 cur = nxt;
-            if (g + 1 < ng) nxt = wave_sload_u32x4(src + 16 * (size_t)(g + 1));  // one group ahead of the chain
+            if (g + 1 < ngRows) nxt = wave_sload_u32x4(src + 16 * (size_t)(g + 1));  // one group ahead of the chain
             const uint32_t i = 16 * g;
             uint32_t ob = 0;
             const uint32_t any = cur.x | cur.y | cur.z | cur.w;
@@ -345,18 +345,16 @@ __device__ __forceinline__ void knz_rank_chain_block_v(const uint8_t* src, uint8
                 c.template word<0>(cur.x, i, ob); c.template word<1>(cur.y, i + 4, ob);
                 c.template word<2>(cur.z, i + 8, ob); c.template word<3>(cur.w, i + 12, ob);
             }
-            if (g < ngRows) {
-                racc |= (ob & 0xFFu) << rsh;
-                rsh += 8;
-                if (rsh == 32) {
-                    const uint32_t t = knz_byte_perm(wave_quad_xor1(racc), racc, sel1);
-                    const uint32_t o = knz_byte_perm(wave_quad_xor2(t), t, sel2);
-                    if (lane < 16) ((uint32_t*)(dst + (i - 48)))[rowSlot] = o;
-                    racc = 0; rsh = 0;
-                }
-            } else if (lane < 16) dst[i + lane] = (uint8_t)ob;
+            racc |= (ob & 0xFFu) << rsh;
+            rsh += 8;
+            if (rsh == 32) {
+                const uint32_t t = knz_byte_perm(wave_quad_xor1(racc), racc, sel1);
+                const uint32_t o = knz_byte_perm(wave_quad_xor2(t), t, sel2);
+                if (lane < 16) ((uint32_t*)(dst + (i - 48)))[rowSlot] = o;
+                racc = 0; rsh = 0;
+            }
         }
-        i0 = 16 * ng;
+        i0 = 16 * ngRows;
     }
     for (uint32_t i = i0; i < n; i++) {                                         // the last < 16 ranks (or an unaligned source): byte by byte
         const uint32_t s = c.step_any(wave_uniform(src[i]), i);
