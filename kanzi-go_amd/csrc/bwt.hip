@@ -26,7 +26,10 @@ __device__ __forceinline__ uint32_t knz_bwt_block_of(const uint32_t* gstart, uin
     return lo;
 }
 
-// round 0 keys: (block:10 bits | 6 symbols x 9 bits: symbol+1, 0 = past the end of the block)
+// round 0 keys: (block | 6 symbols x 8 bits, zero behind the end of the block): 48 + log2(blocks) bits to sort. A suffix shorter than 6
+// symbols shares its key with the suffixes that go on with zeros there; inside that group it is the smallest, and the doubling rounds put it
+// there (knz_bwt_subkeys_kernel). (Rounds 1-2 of this project used 9-bit symbols to tell the two apart at once: a whole radix pass more over
+// every suffix for the sake of five suffixes per block.)
 __global__ __launch_bounds__(256) void knz_bwt_init_kernel(BwtGeom g, uint32_t total, uint64_t* keys, uint32_t* vals) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(256) void knz_bwt_init_kernel(BwtGeom g, uint32_t t
     const uint8_t* src = (const uint8_t*)g.in_ptr[b];
     uint64_t k = (uint64_t)b;
 #pragma unroll
-    for (int j = 0; j < 6; j++) k = (k << 9) | (loc + j < n ? (uint64_t)src[loc + j] + 1 : 0);
+    for (int j = 0; j < 6; j++) k = (k << 8) | (loc + j < n ? (uint64_t)src[loc + j] : 0);
     keys[i] = k;
     vals[i] = i;
 }
@@ -60,15 +63,18 @@ __global__ __launch_bounds__(256) void knz_bwt_ranks_kernel(const uint32_t* sa, 
 
 // subset keys for a doubling round: (group start, rank of suffix i+h inside the same block, 0 past the end)
 __global__ __launch_bounds__(256) void knz_bwt_subkeys_kernel(BwtGeom g, const uint32_t* pos, uint32_t m, const uint32_t* sa, const uint32_t* gs,
-                                                              const uint32_t* rank, uint32_t h, uint64_t* keys, uint32_t* vals) {
+                                                              const uint32_t* rank, uint32_t h, uint32_t bits, uint64_t* keys, uint32_t* vals) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= m) return;
     const uint32_t j = pos[k];
     const uint32_t i = sa[j];
     const uint32_t b = knz_bwt_block_of(g.gstart, g.nblocks, i);
     const uint32_t end = g.gstart[b + 1];
-    const uint64_t r2 = (uint64_t)i + h < end ? rank[i + h] : 0;
-    keys[k] = ((uint64_t)gs[j] << 32) | r2;
+    // second key: the rank of the suffix h symbols on, lifted over h; a suffix that ends within those h symbols is smaller than every member of
+    // its group that goes on, and among such suffixes the shorter one is the smaller (they can only share a group when they end in zeros:
+    // round 0 pads with zeros): its length - 1, which is < h
+    const uint64_t r2 = (uint64_t)i + h < end ? (uint64_t)rank[i + h] + h : (uint64_t)(end - 1 - i);
+    keys[k] = ((uint64_t)gs[j] << bits) | r2;                       // r2 <= total + h < 2^bits (the caller sizes `bits` for that)
     vals[k] = i;
 }
 
