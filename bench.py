@@ -173,7 +173,7 @@ def host_hook_rate(K, codec_args, data, bs):
             "what": "knz_encode_blocks + knz_decode_blocks, all blocks of the stream in pageable host memory (H2D and D2H inside the timed call)"}
 
 
-def pmc_traffic(argv_child, timeout_s=420):
+def pmc_traffic(argv_child, timeout_s=900):
     """HBM bytes per launch for every knz_ kernel: two rocprofv3 passes of THIS command (--kernel-trace --pmc FETCH_SIZE, then
     WRITE_SIZE: separate passes as MI355X_MICROARCH.md prescribes), rocpd databases read with tools/pmc_traffic.py.
     gfx950 correction from the same guide: fetch bytes = 2 * FETCH_SIZE * 1024, WRITE_SIZE (KB) as is."""
@@ -427,7 +427,9 @@ def main():
                          "kernel_ms_per_step": {k: round(v / K_, 3) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])[:12]},
                          "kernel_launches_per_step": {k: round(kern_launches[k] / K_, 2) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])[:12]}})
             if not args.no_pmc and world == 1 and not emu:
-                child = ["--config", args.config, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-verify", "--no-pmc", "--no-host-hook"]
+                # (fpaq: one 10^9-byte step is ~35 s of two serial chains per block; its counter passes run a single step)
+                child = ["--config", args.config, "--steps", "1" if args.config == "fpaq" else "2", "--warmup", "0" if args.config == "fpaq" else "1",
+                         "--no-cpu-baseline", "--no-verify", "--no-pmc", "--no-host-hook"]
                 for flag, val in (("--size", args.size), ("--block-size", args.block_size)):
                     if val:
                         child += [flag, str(val)]
