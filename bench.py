@@ -91,6 +91,14 @@ KERNEL_BYTES = {
 }
 
 
+# rocprofv3's FETCH_SIZE on gfx950 tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md, HBM section: "exactly half of the bytes of a wide
+# coalesced streaming read ... other access widths are uncalibrated: calibrate on a known byte count in your own access pattern"). Default factor 2
+# (vector loads of 16 B per lane). Kernels that read their input through the SCALAR cache fetch 64-byte lines that are tallied in full: calibrated on
+# knz_rank_inverse_chain_kernel, which reads its n input bytes exactly once with s_load_dwordx4 and stores n bytes: raw FETCH_SIZE = 1.001 n, raw
+# WRITE_SIZE = 1.000 n (profiles/r03_final_config4_bench.json). With the factor 2 that kernel showed "1.50x algorithmic" in round 2: an artefact.
+FETCH_FACTOR = {"knz_rank_inverse_chain_kernel": 1.0}
+
+
 def kernel_key(name):
     m = re.search(r"knz_\w+", name)
     return m.group(0) if m else name
@@ -198,8 +206,11 @@ def pmc_traffic(argv_child, timeout_s=900):
         for k in set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"]):
             f, w = res["FETCH_SIZE"].get(k, 0.0), res["WRITE_SIZE"].get(k, 0.0)
             key = kernel_key(k)
-            out[key] = out.get(key, 0) + int(2 * f * 1024 + w * 1024)
-        return out, "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command (2 steps each), per-launch averages"
+            fac = FETCH_FACTOR.get(key, 2.0)
+            o = out.setdefault(key, {"bytes": 0, "fetch_KB_raw": 0.0, "write_KB_raw": 0.0, "fetch_factor": fac})
+            o["bytes"] += int(fac * f * 1024 + w * 1024); o["fetch_KB_raw"] += round(f, 1); o["write_KB_raw"] += round(w, 1)
+        return out, ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per-launch averages; bytes = fetch_factor x "
+                     "FETCH_SIZE + WRITE_SIZE (factor 2 = the guide's gfx950 correction for wide vector loads, 1 = calibrated scalar-cache reads)")
     except Exception as e:   # noqa: BLE001 (a profiler problem must not cost the bench line)
         return None, f"rocprofv3 pass failed: {e}"
     finally:
@@ -439,8 +450,9 @@ def main():
                 tr, how = pmc_traffic(child)
                 roof["traffic_source"] = how
                 if tr is not None and dom in tr:
-                    roof["traffic"] = int(tr[dom])
-                    roof["traffic_over_algorithmic"] = round(tr[dom] / max(alg, 1), 3)
+                    roof["traffic"] = int(tr[dom]["bytes"])
+                    roof["traffic_over_algorithmic"] = round(tr[dom]["bytes"] / max(alg, 1), 3)
+                    roof["traffic_counters"] = {k: tr[dom][k] for k in ("fetch_KB_raw", "write_KB_raw", "fetch_factor")}
         out["roofline"] = roof
         if rank_kernel_max:
             out["kernel_ms_per_step_max_over_ranks"] = {k: round(v / K_, 3) for k, v in sorted(rank_kernel_max.items(), key=lambda kv: -kv[1])[:10]}
