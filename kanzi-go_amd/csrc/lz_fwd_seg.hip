@@ -46,7 +46,8 @@ struct LzSegArgs {
     uint32_t* Sp; uint32_t* Sn;    // [nblocks][2] any jumped-over position, the largest one
     uint64_t map_stride;
     uint8_t* blk_state;            // [nblocks] 0 running, 1 settled, 2 left to the one-wave kernel, 3 not a block for this stage, 4 declined before any parse (answered by the one-wave kernel)
-    uint32_t* blk_flags;           // [nblocks][4] round results: entries changed, maps changed, rounds taken
+    uint32_t* blk_flags;           // [nblocks][4] round results: entries changed, maps changed, rounds taken, first map word that moved
+    uint32_t* rprof;               // diagnostics (KNZ_LZS_PROF) or null: [round][nblocks][2] first segment with a new entry state, first map word that moved
 };
 
 __device__ __forceinline__ void knz_lzs_geom(const LzArgs& a, uint32_t b, int count, int& srcEnd, int& maxDist, int& minMatch, uint32_t& flag, bool& decline) {
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(64) void knz_lzs_init_kernel(LzSegArgs g) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     const LzArgs& a = g.pa.a;
     if (b >= a.nblocks) return;
-    g.blk_flags[4 * b] = g.blk_flags[4 * b + 1] = g.blk_flags[4 * b + 2] = g.blk_flags[4 * b + 3] = 0;
+    g.blk_flags[4 * b] = g.blk_flags[4 * b + 1] = g.blk_flags[4 * b + 2] = 0; g.blk_flags[4 * b + 3] = 0xFFFFFFFFu;
     g.Sp[2 * b] = g.Sp[2 * b + 1] = g.Sn[2 * b] = g.Sn[2 * b + 1] = 0;
     uint8_t st = 3;
     if (a.active[b]) {
@@ -308,6 +309,19 @@ __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_
         else if (g.ntok[si] == KNZ_LZS_NEVER) overflow = true;
         if (U[0] != KNZ_LZS_NEVER) for (int k = 0; k < 5; k++) cur[k] = X[k];   // exact when `same`, the best guess otherwise
     }
+    if (g.rprof) {
+        uint32_t firstSeg = ns;
+        for (uint32_t s = 0; s < ns; s++) {
+            const size_t si = (size_t)b * g.segs + s;
+            const uint32_t* E = g.entry + 5 * si;
+            const uint32_t* U = g.used + 5 * si;
+            const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
+            if (E[0] < segEnd && !(U[0] == E[0] && U[1] == E[1] && U[2] == E[2] && U[3] == E[3] && U[4] == E[4])) { firstSeg = s; break; }
+        }
+        uint32_t* R = g.rprof + ((size_t)round * a.nblocks + b) * 2;
+        R[0] = firstSeg | (ns << 16); R[1] = g.blk_flags[4 * b + 3];
+    }
+    g.blk_flags[4 * b + 3] = 0xFFFFFFFFu;
     const bool again = changed || mapsChanged;
     // a block that has never had a jumped-over position has empty maps whatever its segments do: only the segments whose entry state is
     // new run again. With holes, every live segment runs again, so that the next generation of the maps is complete.
@@ -337,7 +351,11 @@ __global__ __launch_bounds__(256) void knz_lzs_compare_kernel(LzSegArgs g, uint3
         const size_t i = (size_t)b * g.map_stride + w;
         diff = g.Jp[i] != g.Jn[i] || g.Mp[i] != g.Mn[i];
     }
-    if (wave_ballot(diff) != 0 && (threadIdx.x & 63) == 0) g.blk_flags[4 * b + 1] = 1;
+    const uint64_t dm = wave_ballot(diff);
+    if (dm != 0 && (threadIdx.x & 63) == 0) {
+        g.blk_flags[4 * b + 1] = 1;
+        atomicMin(&g.blk_flags[4 * b + 3], w + (uint32_t)(__ffsll((unsigned long long)dm) - 1));   // (diagnostics: the first word that moved)
+    }
 }
 
 // ---- layout of a settled block (:425-591) ------------------------------------------------------------------------------------
