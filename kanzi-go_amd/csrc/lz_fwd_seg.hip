@@ -7,9 +7,10 @@
 // behind a match srcInc is 0, repdIdx is 1, anchor = srcIdx, and two parses that emit the same two matches in a row agree on
 // everything. So every segment of KNZ_LZS_SEG positions is parsed by a wave of its own from a GUESSED entry state, and the guesses
 // are iterated to the fixed point "entry state of a segment = exit state of the one in front of it, holes read = holes written":
-//   round:  parse the segments whose entry state is new (all of them in a block with holes) [knz_lzs_parse_kernel]
-//           new entry states: a sequential walk over the segments' (entry used, exit) pairs  [knz_lzs_relink_kernel]
-//           did the hole maps change?                                                       [knz_lzs_compare_kernel]
+//   round:  parse the segments whose entry state is new, or that asked about holes which moved     [knz_lzs_parse_kernel]
+//           keep the map stretches of the segments that did not run                                [knz_lzs_carry_kernel]
+//           where did the hole maps change, and who had asked there?                               [knz_lzs_compare_kernel, knz_lzs_qhit_kernel]
+//           new entry states: a sequential walk over the segments' (entry used, exit) pairs        [knz_lzs_relink_kernel]
 // The first segment is exact in round 1, so segment k is exact after round k + 1 at the latest; in practice a trace started from a
 // wrong state meets the true one after a match or two and a block settles in 3-5 rounds. A fixed point IS the sequential parse (by
 // induction over the segments: exact entry state, exact holes in front of it), and only a fixed point is ever emitted; a block
@@ -25,7 +26,7 @@
 #pragma once
 #include "bits.h"
 
-#define KNZ_LZS_SEG 16384u
+#define KNZ_LZS_SEG 8192u
 #define KNZ_LZS_MAX_ROUNDS 48
 #define KNZ_LZS_NEVER 0xFFFFFFFFu
 #define KNZ_LZS_COARSE 512u                          // words of the coarse hole map (one bit per 2^cs positions)
@@ -47,7 +48,12 @@ struct LzSegArgs {
     uint64_t map_stride;
     uint8_t* blk_state;            // [nblocks] 0 running, 1 settled, 2 left to the one-wave kernel, 3 not a block for this stage, 4 declined before any parse (answered by the one-wave kernel)
     uint32_t* blk_flags;           // [nblocks][4] round results: entries changed, maps changed, rounds taken, first map word that moved
-    uint32_t* rprof;               // diagnostics (KNZ_LZS_PROF) or null: [round][nblocks][2] first segment with a new entry state, first map word that moved
+    uint32_t* rprof;               // diagnostics (KNZ_LZS_PROF) or null: [round][nblocks][3] first segment with a new entry state, first map word that moved, segments that run next
+    uint32_t* qmap;                // [nblocks][segs][KNZ_LZS_COARSE] the coarse cells in front of its entry a segment's last parse asked about
+    uint32_t* cmap;                // [nblocks][KNZ_LZS_COARSE] the coarse cells whose map words differ between the previous round and this one
+    uint8_t* qhit;                 // [nblocks][segs] qmap & cmap != 0
+    unsigned long long* sprof;     // diagnostics (KNZ_LZS_PROF) or null: [nblocks][segs][4] ticks of all parses, steps / hole-chain steps / ticks of the last one
+    uint32_t all_again;            // (measurements) every live segment of a block with holes runs in every round
 };
 
 __device__ __forceinline__ void knz_lzs_geom(const LzArgs& a, uint32_t b, int count, int& srcEnd, int& maxDist, int& minMatch, uint32_t& flag, bool& decline) {
@@ -96,6 +102,7 @@ __global__ __launch_bounds__(64) void knz_lzs_init_kernel(LzSegArgs g) {
 
 __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
     __shared__ uint32_t s_coarse[KNZ_LZS_COARSE];                       // 2 KiB: the waves of a CU are limited by their wave slots, not by LDS
+    __shared__ uint32_t s_q[KNZ_LZS_COARSE];                            // the cells in front of the entry state this parse asks about
     const LzArgs& a = g.pa.a;
     const int lane = threadIdx.x;
     const bool writer = lane == 0;
@@ -119,17 +126,29 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
     uint32_t* Cn = g.Cn + (size_t)b * KNZ_LZS_COARSE;
     unsigned cs = 6;
     while (((uint32_t)count >> cs) >= 32u * KNZ_LZS_COARSE) cs++;
-    { const uint32_t* Cp = g.Cp + (size_t)b * KNZ_LZS_COARSE; for (int i = lane; i < (int)KNZ_LZS_COARSE; i += 64) s_coarse[i] = Cp[i]; }
+    { const uint32_t* Cp = g.Cp + (size_t)b * KNZ_LZS_COARSE; for (int i = lane; i < (int)KNZ_LZS_COARSE; i += 64) { s_coarse[i] = Cp[i]; s_q[i] = 0; } }
     wave_sync();
+    // What a parse takes from the previous round: whether the block had any jumped-over position (a change of that runs every segment
+    // again), and the hole bits of the cells it asks about (logged in s_q; relink runs it again when one of those cells moved).
+    // Nothing else: the largest hole only gates questions about positions this parse has passed itself.
     bool anyHoles = g.Sp[2 * b] != 0;
-    int maxHole = anyHoles ? (int)g.Sp[2 * b + 1] : -1;
+    int maxHole = -1;                                                         // the largest position this parse jumped over
     uint32_t ntok = 0;
     uint4* tokOut = g.tok + si * g.tok_cap;
     bool overflow = false;
+#if !defined(KNZ_HIP_EMU)
+#define KNZ_LZS_NOW() (unsigned long long)__builtin_readcyclecounter()
+#else
+#define KNZ_LZS_NOW() 0ull
+#endif
+    const unsigned long long t0 = g.sprof ? KNZ_LZS_NOW() : 0ull;
+    uint32_t nSteps = 0, nChain = 0;
 
 #define KNZ_LZS_CAND(P) ((int)wave_sload_u32(cand8 + 4 * (size_t)(P)))
 #define KNZ_LZS_CP(P) ((int)((wave_sload_u32((const uint8_t*)((uintptr_t)(cp8 + (P)) & ~(uintptr_t)3)) >> (8 * ((uintptr_t)(cp8 + (P)) & 3))) & 0xFFu))
     auto is_hole = [&](int q) -> bool {
+        if (q < eSrc) { if (writer) atomicOr(&s_q[(uint32_t)q >> (cs + 5)], 1u << (((uint32_t)q >> cs) & 31)); }
+        else if (q > maxHole) return false;
         if (!((s_coarse[(uint32_t)q >> (cs + 5)] >> (((uint32_t)q >> cs) & 31)) & 1u)) return false;
         const uint32_t w = (uint32_t)q >> 5, m = 1u << (q & 31);
         uint32_t bits;
@@ -141,13 +160,14 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
     };
     auto true_cand = [&](int raw) -> int {
         int q = raw;
-        if (anyHoles) while (q > 0 && q <= maxHole && is_hole(q)) q = KNZ_LZS_CAND(q);
+        if (anyHoles) while (q > 0 && is_hole(q)) { q = KNZ_LZS_CAND(q); nChain++; }
         return q;
     };
     auto len_from_cp = [&](int cp, int maxMatch) -> int { const int whole = maxMatch & ~7; return cp < whole ? cp : whole; };
 
     while (srcIdx < srcEnd) {
         if (srcIdx >= segEnd && srcInc < 64) break;                           // hand over only when not skipping
+        nSteps++;
         int bestLen = 0;
         const int srcIdx1 = srcIdx + 1;
         const int nextPos = srcIdx1 + (srcInc >> 6);
@@ -265,9 +285,9 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
         ntok++;
         anchor = srcIdx + bestLen;
         // the reference hashes every position of the match now (:517-553): jumped-over positions under it are holes no longer
-        if (anyHoles && srcIdx + 1 <= maxHole) {
-            const int hi = min(anchor, maxHole + 1);
-            for (int q0 = srcIdx + 1; q0 < hi; q0 += 64) { const int q = q0 + lane; if (q < hi) atomicOr(&Mn[q >> 5], 1u << (q & 31)); }
+        // (in a block with holes: all of them, so that the M bits of a trace do not depend on where other segments' holes were)
+        if (anyHoles) {
+            for (int q0 = srcIdx + 1; q0 < anchor; q0 += 64) { const int q = q0 + lane; if (q < anchor) atomicOr(&Mn[q >> 5], 1u << (q & 31)); }
             wave_order_lanes();
         }
         srcIdx = anchor;
@@ -277,14 +297,33 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
         X[0] = (uint32_t)srcIdx; X[1] = (uint32_t)anchor; X[2] = (uint32_t)repd0; X[3] = (uint32_t)repd1; X[4] = (uint32_t)srcInc | ((uint32_t)repdIdx << 31);
         g.ntok[si] = overflow ? KNZ_LZS_NEVER : ntok;
     }
+    if (g.sprof && writer) {
+        const unsigned long long dt = KNZ_LZS_NOW() - t0;
+        unsigned long long* P = g.sprof + 4 * si; P[0] += dt; P[1] = nSteps; P[2] = nChain; P[3] = dt;
+    }
+    wave_sync_lds();
+    { uint32_t* Q = g.qmap + si * KNZ_LZS_COARSE; for (int i = lane; i < (int)KNZ_LZS_COARSE; i += 64) Q[i] = s_q[i]; }
 #undef KNZ_LZS_CAND
+#undef KNZ_LZS_NOW
 #undef KNZ_LZS_CP
 }
 
-// one thread per block: the entry states of the next round. The exit of a segment is known for the entry state its last parse started
-// from; a segment whose entry state lies at or behind its end has nothing to parse and hands the state on unchanged. If any live
-// segment of the block needs a new parse (new entry state, or the hole maps moved), all of them run again, so that the next
-// generation of the maps is complete.
+__device__ __forceinline__ bool knz_lzs_live(const LzSegArgs& g, uint32_t b, uint32_t s, int srcEnd) {
+    const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
+    return (int)(s * (uint64_t)g.seg_size) < srcEnd && g.entry[5 * ((size_t)b * g.segs + s)] < segEnd;
+}
+
+// one thread per block: the entry states of the next round, and which segments run in it. The exit of a segment is known for the entry
+// state its last parse started from; a segment whose entry state lies at or behind its end has nothing to parse and hands the state on
+// unchanged.
+//   * A block that has never had a jumped-over position has empty maps whatever its segments do: the segments whose entry state is new run.
+//   * With holes, and an entry state that moved (or the block's first / last hole appearing): every live segment runs, so that the next
+//     generation of the maps is the union of what ONE set of traces wrote, each over its own stretch of the block.
+//   * With holes and no entry state moved, the traces are a chain (each starts where the one in front ended), the maps are exactly their
+//     union, J over [entry srcIdx, exit srcIdx) and M over [entry anchor, exit anchor) per segment. Then only the segments that asked
+//     about a cell whose words moved in this round run again (qhit); the others' stretches of the maps are copied into the next
+//     generation [knz_lzs_carry_kernel]. A trace that is not run again is, by induction over the rounds, what a parse against the
+//     latest maps would produce, so "nothing to run" is the same fixed point as before.
 __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_t round) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     const LzArgs& a = g.pa.a;
@@ -318,22 +357,26 @@ __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_
             const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
             if (E[0] < segEnd && !(U[0] == E[0] && U[1] == E[1] && U[2] == E[2] && U[3] == E[3] && U[4] == E[4])) { firstSeg = s; break; }
         }
-        uint32_t* R = g.rprof + ((size_t)round * a.nblocks + b) * 2;
+        uint32_t* R = g.rprof + ((size_t)round * a.nblocks + b) * 3;
         R[0] = firstSeg | (ns << 16); R[1] = g.blk_flags[4 * b + 3];
     }
     g.blk_flags[4 * b + 3] = 0xFFFFFFFFu;
-    const bool again = changed || mapsChanged;
-    // a block that has never had a jumped-over position has empty maps whatever its segments do: only the segments whose entry state is
-    // new run again. With holes, every live segment runs again, so that the next generation of the maps is complete.
     const bool holey = (g.Sp[2 * b] | g.Sn[2 * b]) != 0;
+    const bool everyone = holey && (changed || (g.Sp[2 * b] != 0) != (g.Sn[2 * b] != 0) || (g.all_again && mapsChanged));
+    bool again = false;
+    uint32_t nrun = 0;
     for (uint32_t s = 0; s < ns; s++) {
         const size_t si = (size_t)b * g.segs + s;
         const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
         const uint32_t* E = g.entry + 5 * si;
         const uint32_t* U = g.used + 5 * si;
         const bool same = U[0] == E[0] && U[1] == E[1] && U[2] == E[2] && U[3] == E[3] && U[4] == E[4];
-        g.need[si] = (again && E[0] < segEnd && (holey || !same)) ? 1 : 0;
+        const bool run = E[0] < segEnd && (everyone || !same || (holey && !g.all_again && g.qhit[si] != 0));
+        g.need[si] = run ? 1 : 0;
+        again |= run;
+        nrun += run ? 1u : 0u;
     }
+    if (g.rprof) g.rprof[((size_t)round * a.nblocks + b) * 3 + 2] = nrun;
     g.blk_flags[4 * b] = cur[1];                                              // anchor behind the last match (used when the block has settled)
     g.blk_flags[4 * b + 2] = round + 1;
     if (overflow) g.blk_state[b] = 2;
@@ -341,7 +384,7 @@ __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_
     else if (round + 1 >= KNZ_LZS_MAX_ROUNDS) g.blk_state[b] = 2;
 }
 
-// did the hole maps of this round differ from the previous round's? grid (ceil(words / 256), nblocks)
+// which map words differ from the previous round's, as coarse cells; grid (ceil(words / 256), nblocks)
 __global__ __launch_bounds__(256) void knz_lzs_compare_kernel(LzSegArgs g, uint32_t words) {
     const uint32_t b = blockIdx.y;
     if (g.blk_state[b] != 0) return;
@@ -351,11 +394,72 @@ __global__ __launch_bounds__(256) void knz_lzs_compare_kernel(LzSegArgs g, uint3
         const size_t i = (size_t)b * g.map_stride + w;
         diff = g.Jp[i] != g.Jn[i] || g.Mp[i] != g.Mn[i];
     }
+    if (diff) {
+        unsigned cs = 6;
+        while ((g.pa.a.in_len[b] >> cs) >= 32u * KNZ_LZS_COARSE) cs++;
+        const uint32_t cell = (w * 32u) >> cs;                               // a word of 32 positions lies inside one cell (cs >= 6)
+        atomicOr(&g.cmap[(size_t)b * KNZ_LZS_COARSE + (cell >> 5)], 1u << (cell & 31));
+    }
     const uint64_t dm = wave_ballot(diff);
     if (dm != 0 && (threadIdx.x & 63) == 0) {
         g.blk_flags[4 * b + 1] = 1;
         atomicMin(&g.blk_flags[4 * b + 3], w + (uint32_t)(__ffsll((unsigned long long)dm) - 1));   // (diagnostics: the first word that moved)
     }
+}
+
+// per segment: did its last parse ask about a cell that moved? grid (segs, nblocks), one wave
+__global__ __launch_bounds__(64) void knz_lzs_qhit_kernel(LzSegArgs g) {
+    const uint32_t b = blockIdx.y, s = blockIdx.x, lane = threadIdx.x;
+    if (g.blk_state[b] != 0) return;
+    const size_t si = (size_t)b * g.segs + s;
+    const uint32_t* Q = g.qmap + si * KNZ_LZS_COARSE;
+    const uint32_t* C = g.cmap + (size_t)b * KNZ_LZS_COARSE;
+    uint32_t hit = 0;
+    for (uint32_t i = lane; i < KNZ_LZS_COARSE; i += 64) hit |= Q[i] & C[i];
+    const uint64_t any = wave_ballot(hit != 0);
+    if (lane == 0) g.qhit[si] = any != 0 ? 1 : 0;
+}
+
+// the stretches of the maps that belong to live segments which did not run in this round, copied into this round's generation;
+// grid (segs, nblocks), one wave, after the parse kernel
+__global__ __launch_bounds__(64) void knz_lzs_carry_kernel(LzSegArgs g) {
+    const LzArgs& a = g.pa.a;
+    const uint32_t b = blockIdx.y, s = blockIdx.x, lane = threadIdx.x;
+    if (g.blk_state[b] != 0) return;
+    if ((g.Sp[2 * b]) == 0) return;                                           // nothing to copy
+    const size_t si = (size_t)b * g.segs + s;
+    const int count = (int)a.in_len[b];
+    const int srcEnd = count - 18;
+    if (g.need[si] || !knz_lzs_live(g, b, s, srcEnd)) return;
+    const uint32_t* U = g.used + 5 * si;
+    const uint32_t* X = g.exit_ + 5 * si;
+    if (U[0] == KNZ_LZS_NEVER) return;
+    unsigned cs = 6;
+    while (((uint32_t)count >> cs) >= 32u * KNZ_LZS_COARSE) cs++;
+    const uint32_t* Jp = g.Jp + (size_t)b * g.map_stride; const uint32_t* Mp = g.Mp + (size_t)b * g.map_stride;
+    uint32_t* Jn = g.Jn + (size_t)b * g.map_stride; uint32_t* Mn = g.Mn + (size_t)b * g.map_stride;
+    uint32_t* Cn = g.Cn + (size_t)b * KNZ_LZS_COARSE;
+    uint32_t top = 0; bool any = false;
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t lo = pass ? U[1] : U[0], hi = pass ? X[1] : X[0];      // M over [entry anchor, exit anchor), J over [entry srcIdx, exit srcIdx)
+        if (hi <= lo) continue;
+        const uint32_t w0 = lo >> 5, w1 = (hi - 1) >> 5;
+        for (uint32_t w = w0 + lane; w <= w1; w += 64) {
+            uint32_t mask = 0xFFFFFFFFu;
+            if (w == w0) mask &= 0xFFFFFFFFu << (lo & 31);
+            if (w == w1) mask &= 0xFFFFFFFFu >> (31 - ((hi - 1) & 31));
+            const uint32_t v = (pass ? Mp[w] : Jp[w]) & mask;
+            if (v == 0) continue;
+            atomicOr(pass ? &Mn[w] : &Jn[w], v);
+            if (!pass) {
+                const uint32_t cell = (w * 32u) >> cs;
+                atomicOr(&Cn[cell >> 5], 1u << (cell & 31));
+                any = true;
+                top = max(top, w * 32u + 31u - (uint32_t)__clz(v));
+            }
+        }
+    }
+    if (any) { atomicOr(&g.Sn[2 * b], 1u); atomicMax(&g.Sn[2 * b + 1], top); }
 }
 
 // ---- layout of a settled block (:425-591) ------------------------------------------------------------------------------------
@@ -370,10 +474,6 @@ __device__ __forceinline__ LzsSizes knz_lzs_sizes(const uint4& t, uint32_t minMa
     const uint32_t mLen = bestLen - minMatch, th = fl < 8 ? 3u : 7u;
     z.ml = mLen >= th ? knz_lzs_len_size(mLen - th) : 0u;
     return z;
-}
-__device__ __forceinline__ bool knz_lzs_live(const LzSegArgs& g, uint32_t b, uint32_t s, int srcEnd) {
-    const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
-    return (int)(s * (uint64_t)g.seg_size) < srcEnd && g.entry[5 * ((size_t)b * g.segs + s)] < segEnd;
 }
 
 // per segment: tokens, literal-stream bytes, distance bytes, length-extension bytes; grid (segs, nblocks)
