@@ -185,14 +185,26 @@ __device__ __forceinline__ void knz_rank_chain_block(const uint8_t* src, uint8_t
 // before the compare (off the loop-carried path: r is known early), the lane-1 copy of q keeps its +inf in lane 0 by being
 // shifted in place (DPP without bound_ctrl leaves lane 0 alone), and the decoded byte leaves through one v_writelane with a
 // compile-time lane (16 symbols per VGPR, stored by 16 lanes). ~17 instructions per symbol, no VALU -> SALU hand-over.
-template <int MODE, bool PACKED>
+// Round 3 (XP & 4, the default): the lane-1 copies of (q, e) are no longer kept in registers of their own. The three
+// instructions that consume them (is the key above greater? / take the new entry or the neighbour's / the smaller key) read lane-1
+// through a DPP wave_shr:1 source operand (wave.h: wave_rank_fused; lane 0 has no source lane, is left alone by the hardware
+// and so keeps the pre-set "new entry" / "new key"). gfx950 has no DPP form of v_cmp, so "q[lane-1] > qc" is v_max_i32_dpp +
+// a plain compare: one instruction less per step than two maintained copies, measured 672 -> 636 ms on the slowest block of
+// S-silesia, 316 -> 290 ms on a text block (A/B on the box: KNZ_RANK_VARIANT=4 is the kept-copies form). Measured on the
+// same data (variants 7 / 8): four more instructions per low step cost 7 ns beside the chain and 5 ns on it: a lone wave
+// pays per instruction issued, wherever it sits.
+template <int MODE, bool PACKED, bool WIDE = false, int XP = 0>
 struct RankChainV {
+    uint32_t xdummy = 0;                                                       // (XP: measurement variants, see step_low)
     uint32_t e[4], p[4];
     int q[4];
     uint32_t ep, pp, vff;
     int qp, lane;
 
+    // (XP & 4, packed form: the lane-1 copies are not kept, the step takes them inside its instructions: wave_rank_fused)
+    static constexpr bool FUSED = PACKED && (XP & 4) != 0;
     __device__ __forceinline__ void refresh() {
+        if (FUSED) return;
         ep = wave_shr1(e[0]);
         if (!PACKED) pp = wave_shr1(p[0]);
         qp = (int)wave_shr1_keep0((uint32_t)qp, (uint32_t)q[0]);              // lane 0 keeps INT_MAX
@@ -212,9 +224,21 @@ struct RankChainV {
         const uint32_t se = wave_readlane(e[0], r);
         int vqc;
         uint32_t vnew;
+#ifndef KNZ_HIP_EMU
+        if (XP & 1) asm volatile("v_add_u32 %0, %0, %1\n\tv_xor_b32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_xor_b32 %0, %0, %1" : "+v"(xdummy) : "v"(vi8));   // 4 instructions beside the chain
+        if (XP & 2) { uint32_t t; asm volatile("v_add_u32 %0, %1, %2\n\tv_sub_u32 %0, %0, %2\n\tv_add_u32 %0, %0, %2" : "=&v"(t) : "s"(se), "v"(vi8)); vi8 = t - se; }   // (X2: 4 instructions ON the chain)
+#endif
         if (PACKED) { vqc = MODE == 1 ? (int)(vi8 >> 8) : (int)((se + vi8) >> 9); vnew = (se & vff) | vi8; }   // (i<<8) + (p<<8|sym) < 2^32 for i, p < 2^23
         else { vqc = MODE == 1 ? (int)vi : (int)((wave_readlane(p[0], r) + vi) >> 1); vnew = se; }
         const int qx = (int)wave_in_vgpr((uint32_t)lane > r ? 0x7FFFFFFFu : (uint32_t)q[0]);   // lanes above r always keep (opaque: or-ing two lane masks would go through the SALU)
+        if (FUSED) {
+            const bool keepf = qx > vqc;
+            uint32_t t; int m;
+            wave_rank_fused(q[0], e[0], vnew, vqc, t, m);
+            e[0] = keepf ? e[0] : t;
+            q[0] = keepf ? q[0] : m;
+            return se;
+        }
         const bool keep = qx > vqc, ins = qp > vqc;
         e[0] = keep ? e[0] : (ins ? vnew : ep);
         if (!PACKED) p[0] = keep ? p[0] : (ins ? vi : pp);
@@ -245,7 +269,8 @@ struct RankChainV {
             es = wave_shr1_keep0(wave_ror1(e[K > 0 ? K - 1 : 0]), e[K]);
             if (!PACKED) ps = wave_shr1_keep0(wave_ror1(p[K > 0 ? K - 1 : 0]), p[K]);
             qs = (int)wave_shr1_keep0(wave_ror1((uint32_t)q[K > 0 ? K - 1 : 0]), (uint32_t)q[K]);
-        } else { es = ep; ps = pp; qs = qp; }                                      // register 0: the maintained copies (q: lane 0 = +inf)
+        } else if (FUSED) { es = wave_shr1(e[0]); qs = (int)wave_shr1_old((uint32_t)q[0], 0x7FFFFFFFu); }
+        else { es = ep; ps = pp; qs = qp; }                                      // register 0: the maintained copies (q: lane 0 = +inf)
         const int qx = (int)wave_in_vgpr(64u * K + (uint32_t)lane > r ? 0x7FFFFFFFu : (uint32_t)q[K]);
         const bool keep = qx > vqc, ins = qs > vqc;
         e[K] = keep ? e[K] : (ins ? vnew : es);
@@ -278,6 +303,37 @@ struct RankChainV {
         const uint32_t vi8 = wave_in_vgpr(i << 8), vi = wave_in_vgpr(i);
         return (r < 64 ? step_low(r, vi8, vi) : step_high(r, vi8, vi)) & (PACKED ? 0xFFu : 0xFFFFFFFFu);
     }
+    // any rank below 64 * NR as ONE straight-line body: registers NR-1 .. 0 all take the select step (the ones above r's keep
+    // everything: their lanes are "above r"), the accessed entry is read from the register that holds it through a select of the
+    // NR registers (r >> 6 is known long before the entries are). No branch per symbol and nothing to reconcile behind one; the
+    // steps of the extra registers run beside the critical path (a lone wave waits on latencies, not on issue slots).
+    template <int NR>
+    __device__ __forceinline__ uint32_t step_wide(uint32_t r, uint32_t vi8, uint32_t vi) {
+        const uint32_t kr = r >> 6, l = r & 63;
+        uint32_t esel = e[0], psel = p[0];
+        if (NR > 1) { esel = kr == 1 ? e[1] : esel; if (!PACKED) psel = kr == 1 ? p[1] : psel; }
+        if (NR > 2) { esel = kr == 2 ? e[2] : esel; if (!PACKED) psel = kr == 2 ? p[2] : psel; }
+        if (NR > 3) { esel = kr == 3 ? e[3] : esel; if (!PACKED) psel = kr == 3 ? p[3] : psel; }
+        const uint32_t se = wave_readlane(esel, l);
+        int vqc;
+        uint32_t vnew;
+        if (PACKED) { vqc = MODE == 1 ? (int)(vi8 >> 8) : (int)((se + vi8) >> 9); vnew = (se & vff) | vi8; }
+        else { vqc = MODE == 1 ? (int)vi : (int)((wave_readlane(psel, l) + vi) >> 1); vnew = se; }
+        if (NR > 3) high_reg<3>(r, vqc, vnew, vi);
+        if (NR > 2) high_reg<2>(r, vqc, vnew, vi);
+        if (NR > 1) high_reg<1>(r, vqc, vnew, vi);
+        high_reg<0>(r, vqc, vnew, vi);
+        refresh();
+        return se;
+    }
+    template <int W, int NR>
+    __device__ __forceinline__ void word_wide(uint32_t w, uint32_t i, uint32_t& ob) {
+        const uint32_t vi8 = wave_in_vgpr(i << 8), vi = wave_in_vgpr(i);
+        ob = wave_writelane_c<4 * W>(ob, step_wide<NR>(w & 0xFFu, vi8, vi));
+        ob = wave_writelane_c<4 * W + 1>(ob, step_wide<NR>((w >> 8) & 0xFFu, vi8 + 0x100u, vi + 1u));
+        ob = wave_writelane_c<4 * W + 2>(ob, step_wide<NR>((w >> 16) & 0xFFu, vi8 + 0x200u, vi + 2u));
+        ob = wave_writelane_c<4 * W + 3>(ob, step_wide<NR>(w >> 24, vi8 + 0x300u, vi + 3u));
+    }
     // word W (0..3) of a group that holds ranks >= 64, first symbol at time i: one dispatch per symbol; symbols go to lanes 4W .. 4W+3 of ob
     template <int W>
     __device__ __forceinline__ void word_any(uint32_t w, uint32_t i, uint32_t& ob) {
@@ -286,6 +342,10 @@ struct RankChainV {
             const uint32_t s = run_top(i + 3, 4);
             ob = wave_writelane_c<4 * W>(ob, s); ob = wave_writelane_c<4 * W + 1>(ob, s);
             ob = wave_writelane_c<4 * W + 2>(ob, s); ob = wave_writelane_c<4 * W + 3>(ob, s);
+            return;
+        }
+        if (WIDE) {                                                           // one branch per word: are all its ranks below 128?
+            if ((w & 0x80808080u) == 0) word_wide<W, 2>(w, i, ob); else word_wide<W, 4>(w, i, ob);
             return;
         }
         const uint32_t vi8 = wave_in_vgpr(i << 8), vi = wave_in_vgpr(i);
@@ -313,13 +373,11 @@ struct RankChainV {
     }
 };
 
-template <int MODE, bool PACKED>
-__device__ __forceinline__ void knz_rank_chain_block_v(const uint8_t* src, uint8_t* dst, uint32_t n, int lane) {
-    RankChainV<MODE, PACKED> c;
-    c.init_identity(lane);
-    uint32_t i0 = 0;
+// ranks [begin, end) of a block through the chain `c`; begin is a multiple of 64 (whole output rows)
+template <int MODE, bool PACKED, bool WIDE, int XP>
+__device__ __forceinline__ void knz_rank_chain_range_v(RankChainV<MODE, PACKED, WIDE, XP>& c, const uint8_t* src, uint8_t* dst, uint32_t begin, uint32_t end, int lane) {
+    uint32_t i0 = begin;
     if ((((uintptr_t)src) & 3) == 0) {                                          // (the pipeline's own regions are 16-byte aligned)
-        const uint32_t ng = n >> 4;                                             // whole groups of 16 ranks
         // decoded symbols leave 64 at a time as one 64-byte row (round 3; 16 single bytes per group cost 1.5x the traffic: every line was
         // written in four partial pieces). Four groups are collected in one register, group q in byte q of lanes 0..15; a 4 x 4 byte
         // transpose inside every quad of lanes (two DPP moves + two byte permutes) turns that into four consecutive symbols per lane:
@@ -328,12 +386,13 @@ __device__ __forceinline__ void knz_rank_chain_block_v(const uint8_t* src, uint8
         const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
         const uint32_t rowSlot = 4u * ((uint32_t)lane & 3u) + (((uint32_t)lane >> 2) & 3u);
         uint32_t racc = 0, rsh = 0;
-        const uint32_t ngRows = rows ? (ng & ~3u) : 0u;                         // groups that lie in whole rows: the loop takes these, the last < 64 ranks go byte by byte below
+        const uint32_t g0 = begin >> 4;
+        const uint32_t gEnd = rows ? g0 + (((end - begin) >> 4) & ~3u) : g0;     // groups that lie in whole rows: the loop takes these, the last < 64 ranks go byte by byte below
         knz_u32x4 nxt = {0, 0, 0, 0};
-        if (ngRows) nxt = wave_sload_u32x4(src);
-        for (uint32_t g = 0; g < ngRows; g++) {
+        if (gEnd > g0) nxt = wave_sload_u32x4(src + 16 * (size_t)g0);
+        for (uint32_t g = g0; g < gEnd; g++) {
             const knz_u32x4 cur = nxt;
-            if (g + 1 < ngRows) nxt = wave_sload_u32x4(src + 16 * (size_t)(g + 1));  // one group ahead of the chain
+            if (g + 1 < gEnd) nxt = wave_sload_u32x4(src + 16 * (size_t)(g + 1));  // one group ahead of the chain
             const uint32_t i = 16 * g;
             uint32_t ob = 0;
             const uint32_t any = cur.x | cur.y | cur.z | cur.w;
@@ -354,19 +413,56 @@ __device__ __forceinline__ void knz_rank_chain_block_v(const uint8_t* src, uint8
                 racc = 0; rsh = 0;
             }
         }
-        i0 = 16 * ngRows;
+        i0 = 16 * gEnd;
     }
-    for (uint32_t i = i0; i < n; i++) {                                         // the last < 16 ranks (or an unaligned source): byte by byte
+    for (uint32_t i = i0; i < end; i++) {                                       // the last < 64 ranks (or an unaligned source): byte by byte
         const uint32_t s = c.step_any(wave_uniform(src[i]), i);
         if (lane == 0) dst[i] = (uint8_t)s;
     }
 }
 
+// The packed form (symbol and last access time in one register) holds while (i << 8) + (p << 8 | sym) fits 32 bits, i.e. for
+// times below 2^23. An 8 MiB block behind a BWT is 2^23 + 25 ranks long (the primary indexes travel in front of the data,
+// BWTBlockCodec.go:126-171): the chain runs packed up to time 2^23 and is unpacked there for the ranks that are left, instead
+// of taking the three-register form for the whole block (what rounds 1-2 and the first half of round 3 did at BASELINE's block size).
+#define KNZ_RANK_PACKED_TIMES (1u << 23)
+template <int MODE, bool WIDE, int XP>
+__device__ __forceinline__ void knz_rank_chain_block_v(const uint8_t* src, uint8_t* dst, uint32_t n, int lane, bool allowPacked, uint32_t cutRows) {
+    if (!allowPacked) {
+        RankChainV<MODE, false, WIDE, XP> c;
+        c.init_identity(lane);
+        knz_rank_chain_range_v<MODE, false, WIDE, XP>(c, src, dst, 0, n, lane);
+        return;
+    }
+    RankChainV<MODE, true, WIDE, XP> c;
+    c.init_identity(lane);
+    const uint32_t cut = min(n, cutRows ? min(64u * cutRows, KNZ_RANK_PACKED_TIMES) : KNZ_RANK_PACKED_TIMES);   // (tests move the cut onto small inputs)
+    knz_rank_chain_range_v<MODE, true, WIDE, XP>(c, src, dst, 0, cut, lane);
+    if (cut == n) return;
+    RankChainV<MODE, false, WIDE, XP> u;
+    u.lane = lane;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { u.e[k] = c.e[k] & 0xFFu; u.p[k] = c.e[k] >> 8; u.q[k] = c.q[k]; }
+    u.qp = 0x7FFFFFFF;
+    u.vff = c.vff;
+    u.refresh();
+    knz_rank_chain_range_v<MODE, false, WIDE, XP>(u, src, dst, cut, n, lane);
+}
+
+#if !defined(KNZ_HIP_EMU)
+__device__ unsigned long long g_knz_rank_ticks[1024];                            // diagnostics (KNZ_RANK_PROF): 100 MHz ticks per block of the last launch
+#define KNZ_RANK_NOW() (unsigned long long)__builtin_amdgcn_s_memrealtime()
+#define KNZ_RANK_TICKS(b, t0) do { if (threadIdx.x == 0 && (b) < 1024u) g_knz_rank_ticks[b] = KNZ_RANK_NOW() - (t0); } while (0)
+#else
+#define KNZ_RANK_NOW() 0ull
+#define KNZ_RANK_TICKS(b, t0) do { } while (0)
+#endif
 template <int MODE, int FLAGS>
 __global__ __launch_bounds__(64) void knz_rank_inverse_chain_kernel(XfArgs a) {
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
-    if (!a.active[b]) return;
+    const unsigned long long t0 = KNZ_RANK_NOW();
+    if (!a.active[b]) { KNZ_RANK_TICKS(b, t0); return; }
     const uint32_t n = a.in_len[b];
     if (lane == 0) { a.out_len[b] = n; a.ok[b] = n <= a.out_cap ? 1 : -KNZ_ERR_PROCESS_BLOCK; }
     if (n > a.out_cap) return;
@@ -374,8 +470,8 @@ __global__ __launch_bounds__(64) void knz_rank_inverse_chain_kernel(XfArgs a) {
     uint8_t* dst = (uint8_t*)a.out_ptr[b];
     const bool packed = n <= (1u << 23) && !(a.mode & 0x100);                  // (bit 8 of mode: tests force the three-register form)
     if (FLAGS & 4) {
-        if (packed) knz_rank_chain_block_v<MODE, true>(src, dst, n, lane);
-        else knz_rank_chain_block_v<MODE, false>(src, dst, n, lane);
+        knz_rank_chain_block_v<MODE, (FLAGS & 8) != 0, (FLAGS >> 4) & 7>(src, dst, n, lane, !(a.mode & 0x100), a.mode >> 12);
+        KNZ_RANK_TICKS(b, t0);
     } else {
         if (packed) knz_rank_chain_block<MODE, true, FLAGS>(src, dst, n, lane);
         else knz_rank_chain_block<MODE, false, FLAGS>(src, dst, n, lane);

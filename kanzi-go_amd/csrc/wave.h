@@ -47,6 +47,18 @@ __device__ __forceinline__ uint32_t wave_shr1_keep0(uint32_t cur, uint32_t v) { 
 // hides a (wave-uniform) value in a VGPR: arithmetic on it is issued to the vector ALU, so that an SGPR written by a
 // v_readlane is consumed without the VALU -> SALU hand-over (~6 ns for a lone wave on gfx950, tools/gpu/lat_bench.hip)
 __device__ __forceinline__ uint32_t wave_in_vgpr(uint32_t x) { asm("" : "+v"(x)); return x; }
+// the three consumers of the lane-1 copies of (q, e) in one step of the inverse RANK chain, with the copies taken inside the instructions
+// (DPP wave_shr:1 as the first source, bound_ctrl off: lane 0 has no lane below it and keeps what the destination held):
+//   t = q[lane-1] > vqc ? vnew : e[lane-1]   (lane 0: vnew)       m = min(q[lane-1], vqc)   (lane 0: vqc)
+__device__ __forceinline__ void wave_rank_fused(int q, uint32_t e, uint32_t vnew, int vqc, uint32_t& t, int& m) {
+    t = vnew; m = vqc;
+    int mx;                                                                    // (gfx950 has no DPP form of the compares: max, then a plain compare; lane 0 of mx is never looked at)
+    asm volatile("v_max_i32_dpp %2, %3, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cmp_gt_i32_e32 vcc, %2, %5\n\t"
+                 "v_cndmask_b32_dpp %0, %4, %0, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_i32_dpp %1, %3, %1 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                 : "+v"(t), "+v"(m), "=&v"(mx) : "v"(q), "v"(e), "v"(vqc) : "vcc");
+}
 // scalar loads that are issued where they stand and waited for together: the compiler gives every scalar load it schedules itself a wait
 // of its own as soon as a branch separates it from its use, which turns five independent reads of one step into five round trips.
 // p must be 4-byte aligned. The values are valid behind WAVE_SLOAD_WAIT(...) naming them.
@@ -159,6 +171,11 @@ inline uint32_t wave_shl1(uint32_t v) { const uint32_t r = wave_shfl(v, hipemu::
 inline uint32_t wave_shr1_old(uint32_t v, uint32_t old) { const uint32_t r = wave_shfl(v, hipemu::lane() - 1); return hipemu::lane() == 0 ? old : r; }
 inline uint32_t wave_shr1_keep0(uint32_t cur, uint32_t v) { const uint32_t r = wave_shfl(v, hipemu::lane() - 1); return hipemu::lane() == 0 ? cur : r; }
 inline uint32_t wave_in_vgpr(uint32_t x) { return x; }
+inline void wave_rank_fused(int q, uint32_t e, uint32_t vnew, int vqc, uint32_t& t, int& m) {
+    const int qp = (int)wave_shfl((uint32_t)q, hipemu::lane() - 1);
+    const uint32_t ep = wave_shfl(e, hipemu::lane() - 1);
+    if (hipemu::lane() == 0) { t = vnew; m = vqc; } else { t = qp > vqc ? vnew : ep; m = qp < vqc ? qp : vqc; }
+}
 inline uint32_t wave_pin_sgpr(uint32_t x) { return x; }
 inline uint64_t wave_sload_u64_async(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 inline uint32_t wave_sload_u32_async(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }

@@ -462,19 +462,24 @@ def check_rank_chain_variants(be, monkeypatch, max_len=1 << 30, bwt_len=150000):
     extra.append(("bwtlike", O.transform_forward(_TID["BWT"], corpus(bwt_len))))
     cases = [(nm, d) for nm, d in list(transform_inputs(max_len=max_len)) + extra if len(d) > 0]
     fwd = [(nm, d, O.transform_forward(_TID["RANK"], d)) for nm, d in cases]
-    for variant in ("0", "3", "5"):
-        for unpacked in (False, True):
+    for variant in ("0", "3", "4", "5", "6"):
+        for unpacked in (False, True, "cut"):
             monkeypatch.setenv("KNZ_RANK_VARIANT", variant)
-            if unpacked:
+            monkeypatch.delenv("KNZ_RANK_UNPACKED", raising=False)
+            monkeypatch.delenv("KNZ_RANK_CUT", raising=False)
+            if unpacked is True:
                 monkeypatch.setenv("KNZ_RANK_UNPACKED", "1")
-            else:
-                monkeypatch.delenv("KNZ_RANK_UNPACKED", raising=False)
+            elif unpacked == "cut":                                  # packed up to rank 1024, the three-register form behind it (what an
+                if variant not in ("4", "5", "6"):                        # 8 MiB block behind a BWT does at rank 2^23)
+                    continue
+                monkeypatch.setenv("KNZ_RANK_CUT", "1024")
             for nm, d, f in fwd:
                 if f is None:
                     continue
                 assert t.inverse(f, len(d) + 512) == d, (variant, unpacked, nm)
     monkeypatch.delenv("KNZ_RANK_VARIANT", raising=False)
     monkeypatch.delenv("KNZ_RANK_UNPACKED", raising=False)
+    monkeypatch.delenv("KNZ_RANK_CUT", raising=False)
     c.close()
 
 

@@ -1,0 +1,8 @@
+#!/bin/bash
+mkdir -p gpurun_out; export TMPDIR=/tmp
+for v in 5 6; do
+  KNZ_RANK_VARIANT=$v KNZ_RANK_PROF=1 timeout 900 python bench.py --steps 1 --warmup 1 --no-pmc --no-cpu-baseline --no-host-hook > gpurun_out/t_bench_$v.json 2> gpurun_out/t_bench_$v.err; echo variant $v rc=$?
+  grep "inverse RANK chain" gpurun_out/t_bench_$v.err | tail -1
+  python -c "
+import json; d=json.loads(open('gpurun_out/t_bench_$v.json').read().strip().splitlines()[-1]); print(d['value'], d['decode_MBps'], d.get('roundtrip_ok'))"
+done
