@@ -350,6 +350,8 @@ struct RankChainV {
         }
         const uint32_t vi8 = wave_in_vgpr(i << 8), vi = wave_in_vgpr(i);
         const uint32_t r0 = w & 0xFFu, r1 = (w >> 8) & 0xFFu, r2 = (w >> 16) & 0xFFu, r3 = w >> 24;
+        // (measured: the hand-scheduled block of word<W>() in place of step_low() here is SLOWER, 617 -> 640 ms on the slowest block: the
+        // blocks pin the schedule around the four branches)
         ob = wave_writelane_c<4 * W>(ob, r0 < 64 ? step_low(r0, vi8, vi) : step_high(r0, vi8, vi));
         ob = wave_writelane_c<4 * W + 1>(ob, r1 < 64 ? step_low(r1, vi8 + 0x100u, vi + 1u) : step_high(r1, vi8 + 0x100u, vi + 1u));
         ob = wave_writelane_c<4 * W + 2>(ob, r2 < 64 ? step_low(r2, vi8 + 0x200u, vi + 2u) : step_high(r2, vi8 + 0x200u, vi + 2u));
@@ -366,6 +368,14 @@ struct RankChainV {
             return;
         }
         const uint32_t vi8 = wave_in_vgpr(i << 8), vi = PACKED && MODE != 1 ? 0u : wave_in_vgpr(i);
+        if (FUSED && MODE == 2) {                                                // the four steps as four hand-scheduled blocks
+            const uint32_t vmaxi = wave_in_vgpr(0x7FFFFFFFu);
+            wave_rank_step_packed<4 * W>(e[0], q[0], ob, w & 0xFFu, vi8, vff, (uint32_t)lane, vmaxi);
+            wave_rank_step_packed<4 * W + 1>(e[0], q[0], ob, (w >> 8) & 0xFFu, vi8 + 0x100u, vff, (uint32_t)lane, vmaxi);
+            wave_rank_step_packed<4 * W + 2>(e[0], q[0], ob, (w >> 16) & 0xFFu, vi8 + 0x200u, vff, (uint32_t)lane, vmaxi);
+            wave_rank_step_packed<4 * W + 3>(e[0], q[0], ob, w >> 24, vi8 + 0x300u, vff, (uint32_t)lane, vmaxi);
+            return;
+        }
         ob = wave_writelane_c<4 * W>(ob, step_low(w & 0xFFu, vi8, vi));
         ob = wave_writelane_c<4 * W + 1>(ob, step_low((w >> 8) & 0xFFu, vi8 + 0x100u, vi + 1u));
         ob = wave_writelane_c<4 * W + 2>(ob, step_low((w >> 16) & 0xFFu, vi8 + 0x200u, vi + 2u));

@@ -59,6 +59,33 @@ __device__ __forceinline__ void wave_rank_fused(int q, uint32_t e, uint32_t vnew
                  "v_min_i32_dpp %1, %3, %1 wave_shr:1 row_mask:0xf bank_mask:0xf"
                  : "+v"(t), "+v"(m), "=&v"(mx) : "v"(q), "v"(e), "v"(vqc) : "vcc");
 }
+// One whole step of the packed inverse RANK chain for a rank below 64 (rank_inv.hip: RankChainV::step_low) as ONE block of 14
+// instructions in an order that needs no wait state between them (the compiler's own schedule of the same step carries three s_nop,
+// and a lone wave pays for every instruction it issues): e = time << 8 | symbol, q = key, lane = lane id, vmax = INT_MAX, vff = 0xFF,
+// vi8 = time of this access << 8 (all wave-uniform where they are operands of a scalar). The decoded entry goes to lane L of ob.
+template <int L>
+__device__ __forceinline__ void wave_rank_step_packed(uint32_t& e, int& q, uint32_t& ob, uint32_t r, uint32_t vi8, uint32_t vff, uint32_t lane, uint32_t vmax) {
+    uint32_t se, vnew;
+    int qx, vqc;
+    uint64_t keep;
+    asm volatile("v_readlane_b32 %[se], %[e], %[r]\n\t"
+                 "v_cmp_ge_u32_e32 vcc, %[r], %[lane]\n\t"
+                 "v_cndmask_b32_e32 %[qx], %[vmax], %[q], vcc\n\t"                      // lanes above r always keep
+                 "v_add_u32_e32 %[vqc], %[se], %[vi8]\n\t"
+                 "v_lshrrev_b32_e32 %[vqc], 9, %[vqc]\n\t"                              // qc = (i + p) >> 1
+                 "v_and_or_b32 %[vnew], %[se], %[vff], %[vi8]\n\t"
+                 "v_cmp_gt_i32_e64 %[keep], %[qx], %[vqc]\n\t"
+                 "v_max_i32_dpp %[qx], %[q], %[vqc] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cmp_gt_i32_e32 vcc, %[qx], %[vqc]\n\t"                              // q[lane-1] > qc: the new entry lands here
+                 "v_cndmask_b32_dpp %[vnew], %[e], %[vnew], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_i32_dpp %[vqc], %[q], %[vqc] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cndmask_b32_e64 %[e], %[vnew], %[e], %[keep]\n\t"
+                 "v_cndmask_b32_e64 %[q], %[vqc], %[q], %[keep]\n\t"
+                 "v_writelane_b32 %[ob], %[se], %[L]"
+                 : [e] "+v"(e), [q] "+v"(q), [ob] "+v"(ob), [se] "=&s"(se), [vnew] "=&v"(vnew), [qx] "=&v"(qx), [vqc] "=&v"(vqc), [keep] "=&s"(keep)
+                 : [r] "s"(r), [vi8] "v"(vi8), [vff] "v"(vff), [lane] "v"(lane), [vmax] "v"(vmax), [L] "n"(L)
+                 : "vcc");
+}
 // scalar loads that are issued where they stand and waited for together: the compiler gives every scalar load it schedules itself a wait
 // of its own as soon as a branch separates it from its use, which turns five independent reads of one step into five round trips.
 // p must be 4-byte aligned. The values are valid behind WAVE_SLOAD_WAIT(...) naming them.
@@ -175,6 +202,19 @@ inline void wave_rank_fused(int q, uint32_t e, uint32_t vnew, int vqc, uint32_t&
     const int qp = (int)wave_shfl((uint32_t)q, hipemu::lane() - 1);
     const uint32_t ep = wave_shfl(e, hipemu::lane() - 1);
     if (hipemu::lane() == 0) { t = vnew; m = vqc; } else { t = qp > vqc ? vnew : ep; m = qp < vqc ? qp : vqc; }
+}
+template <int L>
+inline void wave_rank_step_packed(uint32_t& e, int& q, uint32_t& ob, uint32_t r, uint32_t vi8, uint32_t vff, uint32_t lane, uint32_t vmax) {
+    const uint32_t se = wave_shfl(e, (int)r);
+    const int vqc = (int)((se + vi8) >> 9);
+    const uint32_t vnew = (se & vff) | vi8;
+    const int qx = lane > r ? (int)vmax : q;
+    const bool keep = qx > vqc;
+    uint32_t t; int m;
+    wave_rank_fused(q, e, vnew, vqc, t, m);
+    e = keep ? e : t;
+    q = keep ? q : m;
+    if ((int)lane == L) ob = se;
 }
 inline uint32_t wave_pin_sgpr(uint32_t x) { return x; }
 inline uint64_t wave_sload_u64_async(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
