@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void knz_ans1_expand_kernel(Ans1Args a, uint4*
             o.x = e.y;
             o.y = freq << 20;                                   // xMax = ((ANS_TOP >> 11) << 16) * freq
             o.z = bias;
-            o.w = (((uint32_t)KNZ_ANS1_SCALE - freq) << 8) | sh;
+            o.w = (((uint32_t)KNZ_ANS1_SCALE - freq) << 16) | sh;     // (the factor in the high half: the multiply selects it as an operand half, no shift in the chain)
         }
         out[i] = o;
     }
@@ -301,12 +301,12 @@ __global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a, const u
 #pragma unroll
         for (int j = 0; j < KNZ_ANS1_GROUP; j++) {
             const bool x = st >= e[j].y;
-            mask |= (wave_ballot(x) & 0xFull) << (4 * j);
+            mask |= wave_ballot(x) & (0xFull << (4 * j));                    // lanes 4j..4j+3 speak for step j (every lane mirrors lanes 0..3): no shift
             wslot[4 * j + (lane & 3)] = (uint16_t)st;
             st = x ? (st >> 16) : st;
             // q = st / freq < 2^20 after the renormalisation (st < freq << 20): the product with 2048 - freq fits mul24
             const uint32_t qq = (uint32_t)(((uint64_t)st * e[j].x) >> 32) >> (e[j].w & 31u);
-            st = st + e[j].z + knz_mul24(qq, e[j].w >> 8);
+            st = st + e[j].z + knz_mul24(qq, e[j].w >> 16);
         }
     };
     auto flush = [&](uint64_t m0, uint64_t m1, uint64_t m2) {
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
         // one step of the four states; SHIFT = where the symbol goes in the collected word
         auto step = [&](uint32_t shift) {
             const uint32_t slot = st & (KNZ_ANS1_SCALE - 1);
-            const uint16_t* cq = s_cum + ctx * KNZ_ANS1_CUM_STRIDE;
+            const uint16_t* cq = s_cum + knz_mul24(ctx, KNZ_ANS1_CUM_STRIDE);
             // 16 x 16 search: largest s with cum[s] <= slot (an absent symbol shares its cum with the next present one)
             const uint32_t mA = (uint32_t)(wave_ballot(cq[16 * l] <= slot) >> sh) & 0xFFFFu;
             const uint32_t gi = (uint32_t)__popc(mA) - 1;
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
             const uint32_t r = cnt + (uint32_t)__popc(nlo & hLo) + (uint32_t)__popc(nhi & hHi);   // refill order st3, st2, st1, st0 (:918-949)
             const uint32_t w = wave_in_vgpr(s_pay[r & (KNZ_ANS1_PAYRING2 - 1)]);                    // read whether needed or not: no branch around it
             st = need ? ((st << 16) | w) : st;
-            cnt += (uint32_t)__popc(nlo & aLo) + (uint32_t)__popc(nhi & aHi);
+            cnt += (uint32_t)__popcll(nb) >> 4;                                 // all 16 lanes of a state speak: one scalar popcount instead of two masked ones
         };
         const uint32_t t4 = tn >> 2;
         for (uint32_t tq = 0; tq < t4; tq++) {
