@@ -350,8 +350,15 @@ struct RankChainV {
         }
         const uint32_t vi8 = wave_in_vgpr(i << 8), vi = wave_in_vgpr(i);
         const uint32_t r0 = w & 0xFFu, r1 = (w >> 8) & 0xFFu, r2 = (w >> 16) & 0xFFu, r3 = w >> 24;
-        // (measured: the hand-scheduled block of word<W>() in place of step_low() here is SLOWER, 617 -> 640 ms on the slowest block: the
-        // blocks pin the schedule around the four branches)
+#ifndef KNZ_HIP_EMU
+        if (FUSED && MODE == 2) {                                                // the four dispatches and steps of the word as one hand-written block, the list updated in place
+            const uint32_t vmaxi = wave_in_vgpr(0x7FFFFFFFu);
+            wave_rank_word_any_packed<4 * W>(e[0], e[1], e[2], e[3], q[0], q[1], q[2], q[3], ob, r0, r1, r2, r3, vi8, vff, (uint32_t)lane, vmaxi);
+            return;
+        }
+#endif
+        // (the emulator and the other variants: the compiler's dispatch. Measured: only the low step as a hand-scheduled block between the
+        // compiler's branches is SLOWER, 617 -> 640 ms on the slowest block)
         ob = wave_writelane_c<4 * W>(ob, r0 < 64 ? step_low(r0, vi8, vi) : step_high(r0, vi8, vi));
         ob = wave_writelane_c<4 * W + 1>(ob, r1 < 64 ? step_low(r1, vi8 + 0x100u, vi + 1u) : step_high(r1, vi8 + 0x100u, vi + 1u));
         ob = wave_writelane_c<4 * W + 2>(ob, r2 < 64 ? step_low(r2, vi8 + 0x200u, vi + 2u) : step_high(r2, vi8 + 0x200u, vi + 2u));
