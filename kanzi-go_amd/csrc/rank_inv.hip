@@ -193,6 +193,9 @@ __device__ __forceinline__ void knz_rank_chain_block(const uint8_t* src, uint8_t
 // S-silesia, 316 -> 290 ms on a text block (A/B on the box: KNZ_RANK_VARIANT=4 is the kept-copies form). Measured on the
 // same data (variants 7 / 8): four more instructions per low step cost 7 ns beside the chain and 5 ns on it: a lone wave
 // pays per instruction issued, wherever it sits.
+#ifndef KNZ_HIP_EMU
+#include "rank_inv_asm.h"
+#endif
 template <int MODE, bool PACKED, bool WIDE = false, int XP = 0>
 struct RankChainV {
     uint32_t xdummy = 0;                                                       // (XP: measurement variants, see step_low)
@@ -350,15 +353,8 @@ struct RankChainV {
         }
         const uint32_t vi8 = wave_in_vgpr(i << 8), vi = wave_in_vgpr(i);
         const uint32_t r0 = w & 0xFFu, r1 = (w >> 8) & 0xFFu, r2 = (w >> 16) & 0xFFu, r3 = w >> 24;
-#ifndef KNZ_HIP_EMU
-        if (FUSED && MODE == 2) {                                                // the four dispatches and steps of the word as one hand-written block, the list updated in place
-            const uint32_t vmaxi = wave_in_vgpr(0x7FFFFFFFu);
-            wave_rank_word_any_packed<4 * W>(e[0], e[1], e[2], e[3], q[0], q[1], q[2], q[3], ob, r0, r1, r2, r3, vi8, vff, (uint32_t)lane, vmaxi);
-            return;
-        }
-#endif
-        // (the emulator and the other variants: the compiler's dispatch. Measured: only the low step as a hand-scheduled block between the
-        // compiler's branches is SLOWER, 617 -> 640 ms on the slowest block)
+        // (the emulator and the measurement variants; the default device build takes groups with high ranks through rank_inv_asm.h. Measured: only
+        // the low step as a hand-scheduled block between the compiler's branches is SLOWER, 617 -> 640 ms on the slowest block)
         ob = wave_writelane_c<4 * W>(ob, r0 < 64 ? step_low(r0, vi8, vi) : step_high(r0, vi8, vi));
         ob = wave_writelane_c<4 * W + 1>(ob, r1 < 64 ? step_low(r1, vi8 + 0x100u, vi + 1u) : step_high(r1, vi8 + 0x100u, vi + 1u));
         ob = wave_writelane_c<4 * W + 2>(ob, r2 < 64 ? step_low(r2, vi8 + 0x200u, vi + 2u) : step_high(r2, vi8 + 0x200u, vi + 2u));
@@ -415,8 +411,16 @@ __device__ __forceinline__ void knz_rank_chain_range_v(RankChainV<MODE, PACKED, 
             const uint32_t any = cur.x | cur.y | cur.z | cur.w;
             if (any == 0) ob = c.run_top(i + 15, 16);
             else if (any & 0xC0C0C0C0u) {                                        // ranks >= 64 in the group: words without one take the clean body
+#ifndef KNZ_HIP_EMU
+                if (PACKED && MODE == 2 && (XP & 4) != 0 && !WIDE) {               // the whole group as one hand-written block (rank_inv_asm.h)
+                    knz_rank_group_any_packed(c.e[0], c.e[1], c.e[2], c.e[3], c.q[0], c.q[1], c.q[2], c.q[3], ob, cur.x, cur.y, cur.z, cur.w, i << 8, c.vff,
+                                              (uint32_t)lane, wave_in_vgpr(0x7FFFFFFFu));
+                } else
+#endif
+                {
                 c.template word_any<0>(cur.x, i, ob); c.template word_any<1>(cur.y, i + 4, ob);
                 c.template word_any<2>(cur.z, i + 8, ob); c.template word_any<3>(cur.w, i + 12, ob);
+                }
             } else {
                 c.template word<0>(cur.x, i, ob); c.template word<1>(cur.y, i + 4, ob);
                 c.template word<2>(cur.z, i + 8, ob); c.template word<3>(cur.w, i + 12, ob);

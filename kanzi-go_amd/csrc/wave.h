@@ -86,124 +86,6 @@ __device__ __forceinline__ void wave_rank_step_packed(uint32_t& e, int& q, uint3
                  : [r] "s"(r), [vi8] "v"(vi8), [vff] "v"(vff), [lane] "v"(lane), [vmax] "v"(vmax), [L] "n"(L)
                  : "vcc");
 }
-// One access of ANY rank of the packed inverse RANK chain (rank_inv.hip), the dispatch on the rank included, as one block with its own
-// branches: the list (e0..e3, q0..q3: ranks 64k + lane in register k) is updated IN PLACE. Written by hand because the compiler's
-// version of the same dispatch, unrolled sixteen times per group, reconciles the twelve live registers behind every branch with
-// v_mov_b32 (12 of the 27 instructions of a low step inside a word that holds a high rank). Register k of an access at rank r:
-//   k above r's register: untouched;  r's register: lanes above r & 63 keep (the "protected" form);  registers below: every lane
-//   is at or below r, no protection; register 0: the lane-1 copies are DPP operands (lane 0 always takes the new entry).
-// The lane-1 copy of register k > 0 takes its lane 0 from lane 63 of register k - 1 (wave_ror:1 of k - 1, then wave_shr:1 of k
-// over it, which leaves lane 0 alone). Registers are walked from r's down, so that k - 1 is still the old one.
-#define KNZ_RK_DPP " row_mask:0xf bank_mask:0xf\n\t"
-#define KNZ_RK_COMMON /* qc, new entry from the accessed entry %[se]; %[t8] = time of this access << 8 */ \
-    "v_add_u32_e32 %[vqc], %[se], %[t8]\n\t" \
-    "v_lshrrev_b32_e32 %[vqc], 9, %[vqc]\n\t" \
-    "v_and_or_b32 %[vnew], %[se], %[vff], %[t8]\n\t"
-#define KNZ_RK_COPIES(EK, QK, EL, QL) /* lane-1 copies of register K (EL / QL = the register below) */ \
-    "v_mov_b32_dpp %[es], %[" EL "] wave_ror:1" KNZ_RK_DPP \
-    "v_mov_b32_dpp %[qs], %[" QL "] wave_ror:1" KNZ_RK_DPP \
-    "v_mov_b32_dpp %[es], %[" EK "] wave_shr:1" KNZ_RK_DPP \
-    "v_mov_b32_dpp %[qs], %[" QK "] wave_shr:1" KNZ_RK_DPP
-#define KNZ_RK_SELECT_PROT(EK, QK) /* r's own register: lanes above %[l] keep */ \
-    "v_cmp_ge_u32_e32 vcc, %[l], %[lane]\n\t" \
-    "v_cndmask_b32_e32 %[qx], %[vmax], %[" QK "], vcc\n\t" \
-    "v_cmp_gt_i32_e64 %[keep], %[qx], %[vqc]\n\t" \
-    "v_cmp_gt_i32_e32 vcc, %[qs], %[vqc]\n\t" \
-    "v_cndmask_b32_e32 %[es], %[es], %[vnew], vcc\n\t" \
-    "v_min_i32_e32 %[qs], %[vqc], %[qs]\n\t" \
-    "v_cndmask_b32_e64 %[" EK "], %[es], %[" EK "], %[keep]\n\t" \
-    "v_cndmask_b32_e64 %[" QK "], %[qs], %[" QK "], %[keep]\n\t"
-#define KNZ_RK_SELECT(EK, QK) /* a register wholly below r */ \
-    "v_cmp_gt_i32_e64 %[keep], %[" QK "], %[vqc]\n\t" \
-    "v_cmp_gt_i32_e32 vcc, %[qs], %[vqc]\n\t" \
-    "v_cndmask_b32_e32 %[es], %[es], %[vnew], vcc\n\t" \
-    "v_min_i32_e32 %[qs], %[vqc], %[qs]\n\t" \
-    "v_cndmask_b32_e64 %[" EK "], %[es], %[" EK "], %[keep]\n\t" \
-    "v_cndmask_b32_e64 %[" QK "], %[qs], %[" QK "], %[keep]\n\t"
-#define KNZ_RK_REG0 /* register 0 below r: DPP operands, no protection */ \
-    "v_cmp_gt_i32_e64 %[keep], %[q0], %[vqc]\n\t" \
-    "v_max_i32_dpp %[qx], %[q0], %[vqc] wave_shr:1" KNZ_RK_DPP \
-    "v_cmp_gt_i32_e32 vcc, %[qx], %[vqc]\n\t" \
-    "v_cndmask_b32_dpp %[vnew], %[e0], %[vnew], vcc wave_shr:1" KNZ_RK_DPP \
-    "v_min_i32_dpp %[vqc], %[q0], %[vqc] wave_shr:1" KNZ_RK_DPP \
-    "v_cndmask_b32_e64 %[e0], %[vnew], %[e0], %[keep]\n\t" \
-    "v_cndmask_b32_e64 %[q0], %[vqc], %[q0], %[keep]\n\t"
-// symbol N of a word on the straight path (rank below 64 falls through: no taken branch), its time << 8 in %[t8]
-#define KNZ_RK_SYMBOL(N, R, TIME, LN) \
-    TIME \
-    "s_cmp_gt_u32 %[" R "], 63\n\t" \
-    "s_cbranch_scc1 .Lknz_rk_high" N "_%=\n\t" \
-    "v_readlane_b32 %[se], %[e0], %[" R "]\n\t" \
-    "v_cmp_ge_u32_e32 vcc, %[" R "], %[lane]\n\t" \
-    "v_cndmask_b32_e32 %[qx], %[vmax], %[q0], vcc\n\t" \
-    KNZ_RK_COMMON \
-    "v_cmp_gt_i32_e64 %[keep], %[qx], %[vqc]\n\t" \
-    "v_max_i32_dpp %[qx], %[q0], %[vqc] wave_shr:1" KNZ_RK_DPP \
-    "v_cmp_gt_i32_e32 vcc, %[qx], %[vqc]\n\t" \
-    "v_cndmask_b32_dpp %[vnew], %[e0], %[vnew], vcc wave_shr:1" KNZ_RK_DPP \
-    "v_min_i32_dpp %[vqc], %[q0], %[vqc] wave_shr:1" KNZ_RK_DPP \
-    "v_cndmask_b32_e64 %[e0], %[vnew], %[e0], %[keep]\n\t" \
-    "v_cndmask_b32_e64 %[q0], %[vqc], %[q0], %[keep]\n" \
-    ".Lknz_rk_ret" N "_%=:\n\t" \
-    "v_writelane_b32 %[ob], %[se], %[" LN "]\n\t"
-// the same symbol with a rank of 64 or more, out of line behind the word
-#define KNZ_RK_HIGH(N, R) \
-    ".Lknz_rk_high" N "_%=:\n\t" \
-    "s_and_b32 %[l], %[" R "], 63\n\t" \
-    "s_cmp_lt_u32 %[" R "], 128\n\t" \
-    "s_cbranch_scc1 .Lknz_rk_k1_" N "_%=\n\t" \
-    "s_cmp_lt_u32 %[" R "], 192\n\t" \
-    "s_cbranch_scc1 .Lknz_rk_k2_" N "_%=\n\t" \
-    "v_readlane_b32 %[se], %[e3], %[l]\n\t" \
-    KNZ_RK_COPIES("e3", "q3", "e2", "q2") \
-    KNZ_RK_COMMON \
-    KNZ_RK_SELECT_PROT("e3", "q3") \
-    KNZ_RK_COPIES("e2", "q2", "e1", "q1") \
-    KNZ_RK_SELECT("e2", "q2") \
-    KNZ_RK_COPIES("e1", "q1", "e0", "q0") \
-    KNZ_RK_SELECT("e1", "q1") \
-    KNZ_RK_REG0 \
-    "s_branch .Lknz_rk_ret" N "_%=\n" \
-    ".Lknz_rk_k2_" N "_%=:\n\t" \
-    "v_readlane_b32 %[se], %[e2], %[l]\n\t" \
-    KNZ_RK_COPIES("e2", "q2", "e1", "q1") \
-    KNZ_RK_COMMON \
-    KNZ_RK_SELECT_PROT("e2", "q2") \
-    KNZ_RK_COPIES("e1", "q1", "e0", "q0") \
-    KNZ_RK_SELECT("e1", "q1") \
-    KNZ_RK_REG0 \
-    "s_branch .Lknz_rk_ret" N "_%=\n" \
-    ".Lknz_rk_k1_" N "_%=:\n\t" \
-    "v_readlane_b32 %[se], %[e1], %[l]\n\t" \
-    KNZ_RK_COPIES("e1", "q1", "e0", "q0") \
-    KNZ_RK_COMMON \
-    KNZ_RK_SELECT_PROT("e1", "q1") \
-    KNZ_RK_REG0 \
-    "s_branch .Lknz_rk_ret" N "_%=\n"
-// four accesses (ranks r0..r3 at times i .. i+3, vi8 = i << 8); the decoded entries go to lanes L0 .. L0+3 of ob
-template <int L0>
-__device__ __forceinline__ void wave_rank_word_any_packed(uint32_t& e0, uint32_t& e1, uint32_t& e2, uint32_t& e3, int& q0, int& q1, int& q2, int& q3, uint32_t& ob,
-                                                          uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t vi8, uint32_t vff, uint32_t lane, uint32_t vmax) {
-    uint32_t se, l, vnew, es, t8;
-    int qx, vqc, qs;
-    uint64_t keep;
-    asm volatile(
-        KNZ_RK_SYMBOL("0", "r0", "v_mov_b32_e32 %[t8], %[vi8]\n\t", "L0")
-        KNZ_RK_SYMBOL("1", "r1", "v_add_u32_e32 %[t8], 0x100, %[vi8]\n\t", "L1")
-        KNZ_RK_SYMBOL("2", "r2", "v_add_u32_e32 %[t8], 0x200, %[vi8]\n\t", "L2")
-        KNZ_RK_SYMBOL("3", "r3", "v_add_u32_e32 %[t8], 0x300, %[vi8]\n\t", "L3")
-        "s_branch .Lknz_rk_done_%=\n"
-        KNZ_RK_HIGH("0", "r0")
-        KNZ_RK_HIGH("1", "r1")
-        KNZ_RK_HIGH("2", "r2")
-        KNZ_RK_HIGH("3", "r3")
-        ".Lknz_rk_done_%=:"
-        : [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [e3] "+v"(e3), [q0] "+v"(q0), [q1] "+v"(q1), [q2] "+v"(q2), [q3] "+v"(q3), [ob] "+v"(ob),
-          [se] "=&s"(se), [l] "=&s"(l), [vnew] "=&v"(vnew), [es] "=&v"(es), [qx] "=&v"(qx), [vqc] "=&v"(vqc), [qs] "=&v"(qs), [t8] "=&v"(t8), [keep] "=&s"(keep)
-        : [r0] "s"(r0), [r1] "s"(r1), [r2] "s"(r2), [r3] "s"(r3), [vi8] "v"(vi8), [vff] "v"(vff), [lane] "v"(lane), [vmax] "v"(vmax),
-          [L0] "n"(L0), [L1] "n"(L0 + 1), [L2] "n"(L0 + 2), [L3] "n"(L0 + 3)
-        : "vcc", "scc");
-}
 // scalar loads that are issued where they stand and waited for together: the compiler gives every scalar load it schedules itself a wait
 // of its own as soon as a branch separates it from its use, which turns five independent reads of one step into five round trips.
 // p must be 4-byte aligned. The values are valid behind WAVE_SLOAD_WAIT(...) naming them.
