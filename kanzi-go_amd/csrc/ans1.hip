@@ -667,8 +667,9 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds_kernel(Ans1DecArgs a, 
 #define KNZ_ANS1_PAYRING2 4096                        // words: a tile of 256 steps consumes at most 1024
 __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a, const uint16_t* cum16) {
     __shared__ uint16_t s_cum[256 * KNZ_ANS1_CUM_STRIDE];
-    __shared__ uint16_t s_pay[KNZ_ANS1_PAYRING2];
+    __shared__ uint16_t s_pay[KNZ_ANS1_PAYRING2 + 4];                    // + the first four words again behind the end: a window of four never wraps
     __shared__ uint32_t s_ob[4][64];
+    __shared__ uint16_t s_l1[256 * 16];                                  // first level of the search, cum[ctx][16 l] side by side: the 16 lanes of a state read 32 consecutive bytes (in s_cum they are 32 bytes apart: four lanes to a bank)
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
     const uint32_t slotId = blockIdx.x;
@@ -682,6 +683,8 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
     {
         const uint32_t* src = (const uint32_t*)(cum16 + (size_t)slotId * 256 * KNZ_ANS1_CUM_STRIDE);   // 131,584 B, 4-byte aligned
         for (uint32_t i = lane; i < 256 * KNZ_ANS1_CUM_STRIDE / 2; i += 64) ((uint32_t*)s_cum)[i] = src[i];
+        wave_sync();
+        for (uint32_t i = lane; i < 256 * 16; i += 64) s_l1[i] = s_cum[(i >> 4) * KNZ_ANS1_CUM_STRIDE + 16 * (i & 15)];
     }
     uint32_t st = a.info[(size_t)slotId * 8 + 1 + g];
     const uint32_t end4 = n & ~3u;
@@ -701,22 +704,37 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
             wave_sync();
             for (uint32_t j = lane; j < KNZ_ANS1_PAYRING2 / 4; j += 64) {
                 const uint32_t wi = payHi + j;
-                s_pay[wi & (KNZ_ANS1_PAYRING2 - 1)] = (uint16_t)(knz_fetch32(a.stream, (int64_t)(paybit + 16ull * wi), (int64_t)limit) >> 16);
+                const uint16_t wv = (uint16_t)(knz_fetch32(a.stream, (int64_t)(paybit + 16ull * wi), (int64_t)limit) >> 16);
+                const uint32_t at = wi & (KNZ_ANS1_PAYRING2 - 1);
+                s_pay[at] = wv;
+                if (at < 4) s_pay[KNZ_ANS1_PAYRING2 + at] = wv;
             }
             payHi += KNZ_ANS1_PAYRING2 / 4;
             wave_sync();
         }
+        // the (at most four) renormalisation words of a step are taken from a 64-bit window that is read from the ring as soon as the
+        // step before has counted its words: the LDS round trip of the word is off the path from one state to the next
+        auto load_win = [&](uint32_t c2) -> uint64_t {                       // c2 = 2 x the number of words consumed
+            const uint16_t* wp = (const uint16_t*)((const uint8_t*)s_pay + (c2 & (2 * KNZ_ANS1_PAYRING2 - 2)));
+            return (uint64_t)wp[0] | ((uint64_t)wp[1] << 16) | ((uint64_t)wp[2] << 32) | ((uint64_t)wp[3] << 48);
+        };
+        uint32_t cnt2 = 2 * cnt;
+        uint64_t win = load_win(cnt2);
+        uint32_t c1 = s_l1[16 * ctx + l];                                  // first level of the search for the context of the coming step
         uint32_t acc = 0;
-        // one step of the four states; SHIFT = where the symbol goes in the collected word
+        // one step of the four states; SHIFT = where the symbol goes in the collected word. The true lanes of a compare are a PREFIX of the
+        // state's 16 lanes (cum is sorted), so "how many" is 32 - (leading zeros of the 16-bit group mask): v_ffbh on a word operand, one
+        // instruction instead of mask + popcount.
         auto step = [&](uint32_t shift) {
             const uint32_t slot = st & (KNZ_ANS1_SCALE - 1);
             const uint16_t* cq = s_cum + knz_mul24(ctx, KNZ_ANS1_CUM_STRIDE);
             // 16 x 16 search: largest s with cum[s] <= slot (an absent symbol shares its cum with the next present one)
-            const uint32_t mA = (uint32_t)(wave_ballot(cq[16 * l] <= slot) >> sh) & 0xFFFFu;
-            const uint32_t gi = (uint32_t)__popc(mA) - 1;
-            const uint32_t mB = (uint32_t)(wave_ballot(cq[16 * gi + l] <= slot) >> sh) & 0xFFFFu;
-            const uint32_t sym = 16 * gi + (uint32_t)__popc(mB) - 1;
+            const uint32_t mA = (uint32_t)(wave_ballot(c1 <= slot) >> sh) & 0xFFFFu;
+            const uint32_t gi31 = 527u - 16u * (uint32_t)__builtin_clz(mA);                       // 16 (popc - 1) + 31
+            const uint32_t mB = (uint32_t)(wave_ballot(cq[gi31 - 31u + l] <= slot) >> sh) & 0xFFFFu;
+            const uint32_t sym = gi31 - (uint32_t)__builtin_clz(mB);                              // 16 gi + popc - 1
             const uint32_t lo = cq[sym], hi = cq[sym + 1];
+            c1 = s_l1[16 * sym + l];
             const uint32_t fr = min(hi - lo, (uint32_t)KNZ_ANS1_SCALE - 1);     // decSymbol.reset :972-977
             st = fr * (st >> KNZ_ANS1_LR) + slot - lo;                          // (:846-858)
             ctx = sym;
@@ -724,10 +742,11 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
             const bool need = st < (1u << 15);
             const uint64_t nb = wave_ballot(need);
             const uint32_t nlo = (uint32_t)nb, nhi = (uint32_t)(nb >> 32);
-            const uint32_t r = cnt + (uint32_t)__popc(nlo & hLo) + (uint32_t)__popc(nhi & hHi);   // refill order st3, st2, st1, st0 (:918-949)
-            const uint32_t w = wave_in_vgpr(s_pay[r & (KNZ_ANS1_PAYRING2 - 1)]);                    // read whether needed or not: no branch around it
-            st = need ? ((st << 16) | w) : st;
-            cnt += (uint32_t)__popcll(nb) >> 4;                                 // all 16 lanes of a state speak: one scalar popcount instead of two masked ones
+            const uint32_t rk = (uint32_t)__popc(nlo & hLo) + (uint32_t)__popc(nhi & hHi);        // refill order st3, st2, st1, st0 (:918-949): 0..3
+            const uint32_t w = wave_in_vgpr((uint32_t)(win >> (16u * rk)));                         // (low half) taken whether needed or not: no branch around it
+            st = need ? knz_byte_perm(st, w, 0x05040100u) : st;                 // (st << 16) | (w & 0xFFFF)
+            cnt2 += (uint32_t)__popcll(nb) >> 3;                                // all 16 lanes of a state speak: one scalar popcount
+            win = load_win(cnt2);
         };
         const uint32_t t4 = tn >> 2;
         for (uint32_t tq = 0; tq < t4; tq++) {
@@ -737,6 +756,7 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
         }
         for (uint32_t t = 4 * t4; t < tn; t++) step(8 * (t & 3));
         if (tn & 3) s_ob[g][tn >> 2] = acc;
+        cnt = cnt2 >> 1;
         wave_sync();
         {
             const uint8_t* ob = (const uint8_t*)s_ob[g];
