@@ -376,6 +376,7 @@ struct Ans1DecArgs {
     uint32_t* info;                // [nslots * 8] {mode, st0..st3, lr}
     uint64_t* paybit;              // [nslots]
     int32_t* blk_status;
+    uint32_t plain_loop;           // (KNZ_ANS1_PLAIN: the compiler's schedule of the LDS decoder's loop instead of the hand-written block; A/B and cross-check)
 };
 
 // One context of a chunk header (decodeHeader :605-710: alphabet, then the frequencies in groups of 6 / 8 behind their bit width).
@@ -671,7 +672,8 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
     __shared__ uint32_t s_ob[4][64];
     __shared__ uint16_t s_l1[256 * 16];                                  // first level of the search, cum[ctx][16 l] side by side: the 16 lanes of a state read 32 consecutive bytes (in s_cum they are 32 bytes apart: four lanes to a bank)
     const int lane = threadIdx.x;
-    const int g = lane >> 4, l = lane & 15;
+    const int grp = lane >> 4, l = lane & 15;
+    const int g = 3 - grp;                                               // state 3 in lanes 0..15: the states that refill BEFORE a state (the higher ones, :918-949) sit in the lanes below it
     const uint32_t slotId = blockIdx.x;
     const uint64_t limit = a.nbytes << 3;
     const uint32_t b = slotId / a.chunks_per_block, k = slotId % a.chunks_per_block;
@@ -694,9 +696,9 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
     uint32_t payHi = 0;                                                  // words [payHi - ring, payHi) are staged
     // ballot bits of the states that refill BEFORE this one in a step (the higher ones), and of all four states (lane 16 g' speaks for state g')
     const uint64_t allm = 0x0001000100010001ull;
-    const uint64_t higher = g == 3 ? 0ull : (allm & ~(((uint64_t)1 << (16 * (g + 1))) - 1));
-    const uint32_t hLo = (uint32_t)higher, hHi = (uint32_t)(higher >> 32), aLo = (uint32_t)allm, aHi = (uint32_t)(allm >> 32);
-    const uint32_t sh = 16u * (uint32_t)g;
+    const uint64_t higher = allm & (((uint64_t)1 << (16 * grp)) - 1);   // lane 16 k speaks for the state in lanes 16 k .. 16 k + 15
+    const uint32_t hLo = (uint32_t)higher, hHi = (uint32_t)(higher >> 32);
+    const uint32_t sh = 16u * (uint32_t)grp;
     wave_sync();
     for (uint32_t t0 = 0; t0 < q; t0 += 256) {
         const uint32_t tn = min(256u, q - t0);
@@ -749,6 +751,87 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
             win = load_win(cnt2);
         };
         const uint32_t t4 = tn >> 2;
+#ifndef KNZ_HIP_EMU
+        if (t4 != 0 && !a.plain_loop) {
+            // The same four steps per output word as ONE hand-written block with its own loop (a lone wave pays for every instruction it
+            // issues: no s_nop - the two slots behind each compare whose mask is read as data hold the next things the step needs - and
+            // three instructions less address arithmetic per step than the compiler's schedule of the lambda above). LDS reads in flight
+            // never cross the block's boundary: it starts with the two reads the first step waits for and ends with a wait.
+            // v254:v255 = the 64-bit scratch of the two mask shifts and of the window shift (named, so that its halves can be addressed).
+#define KNZ_A1_STEP(SHIFT, EXTRA) \
+            "v_and_b32_e32 %[slot], 0x7ff, %[st]\n\t" \
+            "v_mad_u32_u24 %[basel], %[ctx], %[k514], %[cumL]\n\t"      /* &cum[ctx][16 * 31 + l] */ \
+            "s_waitcnt lgkmcnt(1)\n\t"                     /* the first-level value; the window (issued after it) may still be on its way */ \
+            "v_cmp_ge_u32_e32 vcc, %[slot], %[c1]\n\t" \
+            "v_lshrrev_b32_e32 %[hi11], 11, %[st]\n\t" \
+            "v_mad_u32_u24 %[base], %[ctx], %[k514], %[cumA]\n\t"       /* &cum[ctx][0] */ \
+            "v_lshrrev_b64 v[254:255], %[sh], vcc\n\t" \
+            "v_ffbh_u32_sdwa v254, v254 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t" \
+            "v_mad_i32_i24 %[adr], v254, %[m32], %[basel]\n\t"          /* group 31 - clz: 32 bytes per group */ \
+            "ds_read_u16 %[c2], %[adr]\n\t" \
+            "v_mad_i32_i24 %[g16], v254, -16, %[c527]\n\t"              /* 16 (31 - clz) + 31 */ \
+            "s_waitcnt lgkmcnt(0)\n\t" \
+            "v_cmp_ge_u32_e32 vcc, %[slot], %[c2]\n\t" \
+            "s_nop 1\n\t" \
+            "v_lshrrev_b64 v[254:255], %[sh], vcc\n\t" \
+            "v_ffbh_u32_sdwa v254, v254 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t" \
+            "v_sub_u32_e32 %[ctx], %[g16], v254\n\t"                    /* the symbol = the next context */ \
+            "v_lshl_add_u32 %[adr], %[ctx], 1, %[base]\n\t" \
+            "ds_read_b32 %[lohi], %[adr]\n\t" \
+            "v_lshl_add_u32 %[adr], %[ctx], 5, %[l1L]\n\t" \
+            "ds_read_u16 %[c1], %[adr]\n\t" \
+            "v_lshl_or_b32 %[acc], %[ctx], " SHIFT ", %[acc]\n\t" \
+            EXTRA \
+            "s_waitcnt lgkmcnt(1)\n\t" \
+            "v_sub_u32_sdwa %[g16], %[lohi], %[lohi] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t" \
+            "v_sub_u32_sdwa %[slot], %[slot], %[lohi] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t" \
+            "v_min_u32_e32 %[g16], 0x7ff, %[g16]\n\t" \
+            "v_mad_u32_u24 %[st], %[g16], %[hi11], %[slot]\n\t" \
+            "v_cmp_gt_u32_e32 vcc, %[thr], %[st]\n\t"                   /* which states renormalise */ \
+            "s_and_b64 s[100:101], vcc, %[m15]\n\t"                     /* one bit per state, in the top lane of its sixteen (s100:s101 named: its halves are operands) */ \
+            "s_bcnt1_i32_b64 %[s0], s[100:101]\n\t" \
+            "v_mbcnt_lo_u32_b32 v254, s100, 0\n\t"                      /* states in the lanes below that renormalise = words in front of this state's */ \
+            "v_mbcnt_hi_u32_b32 v254, s101, v254\n\t" \
+            "v_lshlrev_b32_e32 v254, 4, v254\n\t" \
+            "v_lshrrev_b64 v[254:255], v254, %[win]\n\t" \
+            "s_add_u32 %[cnt], %[cnt], %[s0]\n\t" \
+            "v_perm_b32 v254, %[st], v254, %[sel]\n\t" \
+            "v_cndmask_b32_e32 %[st], %[st], v254, vcc\n\t" \
+            "s_and_b32 %[s0], %[cnt], 0xfff\n\t" \
+            "v_lshl_add_u32 %[adr], %[s0], 1, %[payA]\n\t" \
+            "ds_read_b64 %[win], %[adr]\n\t"
+            uint32_t slot, base, basel, hi11, g16, adr, c2, lohi, accv, c1v, s0, n4 = t4, cntw = cnt2 >> 1;
+            uint64_t winv;
+            uint32_t obp = knz_lds_addr(&s_ob[g][0]);
+            const uint32_t cumA = knz_lds_addr(s_cum), cumL = cumA + 2u * (uint32_t)l + 992u, l1L = knz_lds_addr(s_l1) + 2u * (uint32_t)l, payA = knz_lds_addr(s_pay);
+            asm volatile(
+                "v_lshl_add_u32 %[adr], %[ctx], 5, %[l1L]\n\t"
+                "ds_read_u16 %[c1], %[adr]\n\t"
+                "s_and_b32 %[s0], %[cnt], 0xfff\n\t"
+                "v_lshl_add_u32 %[adr], %[s0], 1, %[payA]\n\t"
+                "ds_read_b64 %[win], %[adr]\n"
+                ".Lknz_a1_loop_%=:\n\t"
+                "v_mov_b32_e32 %[acc], 0\n\t"
+                KNZ_A1_STEP("0", "") KNZ_A1_STEP("8", "") KNZ_A1_STEP("16", "")
+                KNZ_A1_STEP("24", "ds_write_b32 %[obp], %[acc]\n\t")              /* the collected word leaves in front of the step's last two reads' waits */
+                "v_add_u32_e32 %[obp], 4, %[obp]\n\t"
+                "s_sub_u32 %[n4], %[n4], 1\n\t"
+                "s_cmp_lg_u32 %[n4], 0\n\t"
+                "s_cbranch_scc1 .Lknz_a1_loop_%=\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : [st] "+v"(st), [ctx] "+v"(ctx), [cnt] "+s"(cntw), [obp] "+v"(obp), [n4] "+s"(n4),
+                  [slot] "=&v"(slot), [base] "=&v"(base), [basel] "=&v"(basel), [hi11] "=&v"(hi11), [g16] "=&v"(g16), [adr] "=&v"(adr), [c2] "=&v"(c2), [lohi] "=&v"(lohi),
+                  [acc] "=&v"(accv), [c1] "=&v"(c1v), [win] "=&v"(winv), [s0] "=&s"(s0)
+                : [sh] "v"(sh), [cumL] "v"(cumL), [cumA] "v"(cumA), [l1L] "v"(l1L), [payA] "v"(payA), [thr] "s"(1u << 15), [sel] "s"(0x05040100u),
+                  [k514] "s"(2u * KNZ_ANS1_CUM_STRIDE), [m32] "s"(-32), [c527] "s"(527u), [m15] "s"(0x8000800080008000ull)
+                : "vcc", "scc", "v254", "v255", "s100", "s101", "memory");
+            cnt2 = 2 * cntw;
+#undef KNZ_A1_STEP
+            c1 = s_l1[16 * ctx + l];
+            win = load_win(cnt2);
+            acc = 0;
+        } else
+#endif
         for (uint32_t tq = 0; tq < t4; tq++) {
             step(0); step(8); step(16); step(24);
             s_ob[g][tq] = acc;                                                  // (all 16 lanes of the state hold the same word)

@@ -86,6 +86,8 @@ __device__ __forceinline__ void wave_rank_step_packed(uint32_t& e, int& q, uint3
                  : [r] "s"(r), [vi8] "v"(vi8), [vff] "v"(vff), [lane] "v"(lane), [vmax] "v"(vmax), [L] "n"(L)
                  : "vcc");
 }
+// byte address inside the workgroup's LDS of an object in __shared__ memory (for hand-written ds_* instructions)
+__device__ __forceinline__ uint32_t knz_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 // scalar loads that are issued where they stand and waited for together: the compiler gives every scalar load it schedules itself a wait
 // of its own as soon as a branch separates it from its use, which turns five independent reads of one step into five round trips.
 // p must be 4-byte aligned. The values are valid behind WAVE_SLOAD_WAIT(...) naming them.
