@@ -1,3 +1,6 @@
+// (Round 3: the default device build runs the groups of sixteen accesses of the packed RANK chain through the hand-written blocks of
+// rank_inv_asm.h; what follows is the C++ form of the same steps: the emulator's, the measurement variants', MTFT's and the
+// three-register form's.)
 // Inverse RANK / MTFT as ONE chain per block (SBRT.Inverse, v2/transform/SBRT.go:180-226), rebuilt around the two things that
 // bound a lone wave on gfx950: the number of instructions per symbol and the number of VALU <-> SALU hand-overs on the
 // loop-carried path (each one costs a pipeline drain: ~15 cycles per instruction were measured on the round-1 form, whose
