@@ -483,6 +483,45 @@ def check_rank_chain_variants(be, monkeypatch, max_len=1 << 30, bwt_len=150000):
     c.close()
 
 
+def rank_patterns(scale=1):
+    """Rank sequences (any byte sequence is a valid input of SBRT.Inverse, SBRT.go:180-226) aimed at the paths of the device's hand-written
+    blocks (rank_inv_asm.h): ranks on both sides of every register boundary of the list (63/64, 127/128, 191/192), the last rank, words of
+    four zeros between high ranks, whole groups of zeros, groups with exactly one high rank at each of the 16 positions, and lengths that end
+    inside a word, a group and a row of 64."""
+    rng = np.random.default_rng(4242)
+    n0 = 4096 * scale
+    yield "uniform", rng.integers(0, 256, n0 + 37).astype(np.uint8).tobytes()
+    for lo, hi in ((63, 64), (127, 128), (191, 192), (254, 255), (0, 255), (0, 64), (1, 192)):
+        yield "pair%d_%d" % (lo, hi), rng.choice(np.array([lo, hi], dtype=np.uint8), n0 + 5).tobytes()
+    yield "all255", bytes([255]) * (n0 + 1)
+    yield "all64", bytes([64]) * (n0 + 2)
+    v = np.zeros(n0 + 3, dtype=np.uint8)
+    v[rng.integers(0, len(v), len(v) // 23)] = rng.integers(64, 256, len(v) // 23).astype(np.uint8)
+    yield "zeros_with_high", v.tobytes()
+    v = np.minimum(rng.geometric(0.25, n0 + 61), 63).astype(np.uint8) - 1
+    for k in range(16):
+        v[16 * (3 * k + 1) + k] = 64 + 12 * k          # one high rank per group, at every position of a group
+    yield "one_high_per_group", v.tobytes()
+    v = rng.integers(0, 256, n0 + 19).astype(np.uint8)
+    v[64:64 + 640] = 0                                   # whole groups / rows of zeros inside random ranks
+    v[1000:1004] = 0
+    yield "uniform_with_zero_rows", v.tobytes()
+    for n in (1, 3, 4, 5, 15, 16, 17, 63, 64, 65, 127, 129):
+        yield "len%d" % n, rng.integers(0, 256, n).astype(np.uint8).tobytes()
+
+
+def check_rank_inverse_patterns(be, scale=1):
+    """Device SBRT RANK inverse == oracle inverse on rank_patterns(), and forward of the result gives the ranks back."""
+    c = K.Codec("NONE", "NONE", 1 << 20, lib=be.lib)
+    t = K.ByteTransform(c, "RANK")
+    for nm, ranks in rank_patterns(scale):
+        want = O.transform_inverse(_TID["RANK"], ranks, len(ranks) + 64)
+        got = t.inverse(ranks, len(ranks) + 512)
+        assert got == want, nm
+        assert t.forward(got) == ranks, nm
+    c.close()
+
+
 def check_bwt_list_ranking(be, monkeypatch, max_len=70000):
     """Inverse BWT by list ranking (bwt.hip: splitter walks, Wyllie ranking, emit) forced onto small blocks (by default blocks
     below 64 KiB take the 8-chain kernel): streams with ragged last blocks, the BWT_test.go inputs, and damaged streams, which the

@@ -107,6 +107,10 @@ def test_rank_chain_variants(be, monkeypatch):
     P.check_rank_chain_variants(be, monkeypatch, max_len=4100, bwt_len=12000)
 
 
+def test_rank_inverse_patterns(be):
+    P.check_rank_inverse_patterns(be, scale=1)
+
+
 def test_srt_chain_form(be):
     P.check_srt_chain_form(be)
 

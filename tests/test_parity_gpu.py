@@ -262,6 +262,10 @@ def test_rank_chain_variants(be, monkeypatch):
     P.check_rank_chain_variants(be, monkeypatch)
 
 
+def test_rank_inverse_patterns(be):
+    P.check_rank_inverse_patterns(be, scale=8)
+
+
 def test_srt_chain_form(be):
     P.check_srt_chain_form(be)
 
