@@ -121,6 +121,8 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
     const int eSrc = srcIdx, eAnchor = anchor;                                // where this segment's own knowledge of the holes begins
     const uint8_t* cand8 = (const uint8_t*)(g.pa.cand + g.pa.gstart[b]);
     const uint8_t* cp8 = g.pa.cp8 + g.pa.gstart[b];
+    const uint8_t* cpA = (const uint8_t*)((uintptr_t)cp8 & ~(uintptr_t)3);   // (4-byte aligned base + offset of the common-prefix bytes for the step's scalar read)
+    const uint32_t cpo = (uint32_t)((uintptr_t)cp8 & 3);
     const uint32_t* Jp = g.Jp + (size_t)b * g.map_stride; const uint32_t* Mp = g.Mp + (size_t)b * g.map_stride;
     uint32_t* Jn = g.Jn + (size_t)b * g.map_stride; uint32_t* Mn = g.Mn + (size_t)b * g.map_stride;
     uint32_t* Cn = g.Cn + (size_t)b * KNZ_LZS_COARSE;
@@ -174,27 +176,15 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
         const int maxMatch = min(srcEnd - srcIdx1, KNZ_LZ_MAX_MATCH);
         const int minRef = max(srcIdx - maxDist, 0);
         const int refA = srcIdx1 - (repdIdx ? repd1 : repd0), refB = srcIdx1 - (repdIdx ? repd0 : repd1);
-        const uint8_t* pp = src + srcIdx;
-        const uint8_t* pa_ = src + max(refA, 0);
-        const uint8_t* pb_ = src + max(refB, 0);
-        const uint8_t* pc_ = cp8 + srcIdx;
-        const uint8_t* y0 = (const uint8_t*)((uintptr_t)pp & ~(uintptr_t)3);
-        const uint8_t* y2 = cand8 + 4 * (size_t)srcIdx;
-        const uint8_t* y3 = (const uint8_t*)((uintptr_t)pc_ & ~(uintptr_t)3);
-        const uint8_t* y4 = (const uint8_t*)((uintptr_t)pa_ & ~(uintptr_t)3);
-        const uint8_t* y5 = (const uint8_t*)((uintptr_t)pb_ & ~(uintptr_t)3);
-        uint64_t l0 = wave_sload_u64_async(y0);
-        uint32_t l1 = wave_sload_u32_async(y0 + 8);
-        uint32_t l2 = wave_sload_u32_async(y2);
-        uint32_t l3 = wave_sload_u32_async(y3);
-        uint64_t l4 = wave_sload_u64_async(y4);
-        uint64_t l5 = wave_sload_u64_async(y5);
-        WAVE_SLOAD_WAIT5A(l0, l2, l3, l4, l5, y0, y2, y3, y4, y5);
-        l1 = wave_pin_sgpr(l1);
-        const uint32_t shp = ((uint32_t)(uintptr_t)pp & 3u) * 8u;
+        // the step's five reads as base + offset scalar loads (wave.h: wave_lz_step_loads)
+        const uint32_t sIdx = (uint32_t)srcIdx, tcp = cpo + sIdx, ra = (uint32_t)max(refA, 0), rb = (uint32_t)max(refB, 0);
+        const WaveLzLoads L = wave_lz_step_loads(src, cand8, cpA, sIdx & ~3u, sIdx << 2, tcp & ~3u, ra & ~3u, rb & ~3u);
+        const uint64_t l0 = (uint64_t)L.a.x | ((uint64_t)L.a.y << 32);
+        const uint32_t l1 = L.a.z;
+        const uint32_t shp = (sIdx & 3u) * 8u;
         const uint64_t p = shp ? ((l0 >> shp) | ((uint64_t)l1 << (64 - shp))) : l0;
-        const int raw0 = (int)l2, cp0 = (int)((l3 >> (8 * ((uint32_t)(uintptr_t)pc_ & 3u))) & 0xFFu);
-        const uint32_t vA = (uint32_t)(l4 >> (((uint32_t)(uintptr_t)pa_ & 3u) * 8u)), vB = (uint32_t)(l5 >> (((uint32_t)(uintptr_t)pb_ & 3u) * 8u));
+        const int raw0 = (int)L.c, cp0 = (int)((L.d >> (8 * (tcp & 3u))) & 0xFFu);
+        const uint32_t vA = (uint32_t)(L.e >> ((ra & 3u) * 8u)), vB = (uint32_t)(L.f >> ((rb & 3u) * 8u));
         const int ref0 = true_cand(raw0);
         int ref = refA;
         if (ref > minRef && (uint32_t)(p >> 8) == vA) {

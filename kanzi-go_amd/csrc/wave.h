@@ -112,6 +112,24 @@ template <int L> __device__ __forceinline__ uint32_t wave_writelane_c(uint32_t v
 typedef uint32_t knz_u32x4 __attribute__((ext_vector_type(4)));
 typedef knz_u32x4 knz_u32x4_a4 __attribute__((aligned(4)));
 __device__ __forceinline__ uint32_t wave_sload_u32(const uint8_t* p) { return *(const __attribute__((address_space(4))) uint32_t*)(uintptr_t)p; }
+// the five scalar reads of one LZ parse step (lz_fwd_seg.hip) as base + 32-bit offset loads in ONE statement, waited for inside it: 16 bytes
+// of the source at o0, the table entry at o2, the common-prefix word at o3, 8 source bytes at o4 and at o5. The offsets cost one scalar
+// instruction each; a 64-bit pointer per read costs three to four (the rounds of the parse are bound by the scalar unit of the CU: one
+// instruction per cycle for its 32 waves).
+struct WaveLzLoads { knz_u32x4 a; uint32_t c, d; uint64_t e, f; };
+__device__ __forceinline__ WaveLzLoads wave_lz_step_loads(const uint8_t* src, const uint8_t* cand, const uint8_t* cp, uint32_t o0, uint32_t o2, uint32_t o3, uint32_t o4, uint32_t o5) {
+    WaveLzLoads r;
+    asm volatile("s_load_dwordx4 %0, %5, %8\n\t"
+                 "s_load_dword %1, %6, %9\n\t"
+                 "s_load_dword %2, %7, %10\n\t"
+                 "s_load_dwordx2 %3, %5, %11\n\t"
+                 "s_load_dwordx2 %4, %5, %12\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(r.a), "=&s"(r.c), "=&s"(r.d), "=&s"(r.e), "=&s"(r.f)
+                 : "s"(src), "s"(cand), "s"(cp), "s"(o0), "s"(o2), "s"(o3), "s"(o4), "s"(o5)
+                 : "memory");
+    return r;
+}
 __device__ __forceinline__ knz_u32x4 wave_sload_u32x4(const uint8_t* p) { return *(const __attribute__((address_space(4))) knz_u32x4_a4*)(uintptr_t)p; }
 // tells the compiler that v is the same in every lane (moves it to an SGPR)
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -227,6 +245,13 @@ template <int L> inline uint32_t wave_writelane_c(uint32_t v, uint32_t val) { re
 struct knz_u32x4 { uint32_t x, y, z, w; };
 inline uint32_t wave_sload_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 inline knz_u32x4 wave_sload_u32x4(const uint8_t* p) { knz_u32x4 v; __builtin_memcpy(&v, p, 16); return v; }
+struct WaveLzLoads { knz_u32x4 a; uint32_t c, d; uint64_t e, f; };
+inline WaveLzLoads wave_lz_step_loads(const uint8_t* src, const uint8_t* cand, const uint8_t* cp, uint32_t o0, uint32_t o2, uint32_t o3, uint32_t o4, uint32_t o5) {
+    WaveLzLoads r;
+    __builtin_memcpy(&r.a, src + o0, 16); __builtin_memcpy(&r.c, cand + o2, 4); __builtin_memcpy(&r.d, cp + o3, 4);
+    __builtin_memcpy(&r.e, src + o4, 8); __builtin_memcpy(&r.f, src + o5, 8);
+    return r;
+}
 #endif
 
 // inclusive prefix sum across the wave
