@@ -167,8 +167,12 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
     };
     auto len_from_cp = [&](int cp, int maxMatch) -> int { const int whole = maxMatch & ~7; return cp < whole ? cp : whole; };
 
-    while (srcIdx < srcEnd) {
-        if (srcIdx >= segEnd && srcInc < 64) break;                           // hand over only when not skipping
+    // (Conditions of the hot path are written as nested single compares and integer flags: a combined or carried `bool` of wave-uniform values is
+    // kept by the compiler as a 64-bit lane mask, four scalar instructions where a compare and a branch do, and the rounds are bound by the
+    // scalar unit.)
+    for (;;) {
+        if (srcIdx >= srcEnd) break;
+        if (srcIdx >= segEnd) { if (srcInc < 64) break; }                     // hand over only when not skipping
         nSteps++;
         int bestLen = 0;
         const int srcIdx1 = srcIdx + 1;
@@ -186,22 +190,26 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
         const int raw0 = (int)L.c, cp0 = (int)((L.d >> (8 * (tcp & 3u))) & 0xFFu);
         const uint32_t vA = (uint32_t)(L.e >> ((ra & 3u) * 8u)), vB = (uint32_t)(L.f >> ((rb & 3u) * 8u));
         const int ref0 = true_cand(raw0);
-        int ref = refA;
-        if (ref > minRef && (uint32_t)(p >> 8) == vA) {
+        int ref = refB;                                                       // (what the reference leaves in `ref` when neither repeat distance matches)
+        const uint32_t p1 = (uint32_t)(p >> 8);
+        int rep = 0;                                                          // 1: the first repeat distance matches, 2: the second
+        if (refA > minRef) { if (p1 == vA) rep = 1; }
+        if (rep == 0) { if (refB > minRef) { if (p1 == vB) rep = 2; } }
+        if (rep != 0) {
+            ref = rep == 1 ? refA : refB;
             bestLen = knz_lz_match_wave(src, srcIdx1, ref, maxMatch, lane);
-        } else {
-            ref = refB;
-            if (ref > minRef && (uint32_t)(p >> 8) == vB) bestLen = knz_lz_match_wave(src, srcIdx1, ref, maxMatch, lane);
         }
         if (bestLen < minMatch) {
             ref = ref0;
-            bool found = false;
+            int found = 0;
             if (ref > minRef) {
                 const int mm = min(srcEnd - srcIdx, KNZ_LZ_MAX_MATCH);
-                if (ref == raw0 && cp0 < 255) { if (cp0 >= 4) { bestLen = len_from_cp(cp0, mm); found = bestLen >= minMatch; } }
-                else if ((uint32_t)p == knz_sle32(src + ref)) { bestLen = knz_lz_match_wave(src, srcIdx, ref, mm, lane); found = bestLen >= minMatch; }
+                int viaCp = 0;
+                if (ref == raw0) { if (cp0 < 255) viaCp = 1; }
+                if (viaCp) { if (cp0 >= 4) { bestLen = len_from_cp(cp0, mm); if (bestLen >= minMatch) found = 1; } }
+                else if ((uint32_t)p == knz_sle32(src + ref)) { bestLen = knz_lz_match_wave(src, srcIdx, ref, mm, lane); if (bestLen >= minMatch) found = 1; }
             }
-            if (!found) {
+            if (found == 0) {
                 if (nextPos > srcIdx1) {                                      // positions jumped over: not hashed until a match covers them
                     for (int q0 = srcIdx1; q0 < nextPos; q0 += 64) {
                         const int q = q0 + lane;
