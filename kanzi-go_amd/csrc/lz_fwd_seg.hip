@@ -146,8 +146,8 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
     const unsigned long long t0 = g.sprof ? KNZ_LZS_NOW() : 0ull;
     uint32_t nSteps = 0, nChain = 0;
 
-#define KNZ_LZS_CAND(P) ((int)wave_sload_u32(cand8 + 4 * (size_t)(P)))
-#define KNZ_LZS_CP(P) ((int)((wave_sload_u32((const uint8_t*)((uintptr_t)(cp8 + (P)) & ~(uintptr_t)3)) >> (8 * ((uintptr_t)(cp8 + (P)) & 3))) & 0xFFu))
+#define KNZ_LZS_CAND(P) ((int)wave_sload_u32(cand8 + (size_t)(uint32_t)(4u * (uint32_t)(P))))                       // (32-bit offsets: the scalar load takes base + offset, no 64-bit address arithmetic)
+#define KNZ_LZS_CP(P) ((int)((wave_sload_u32(cpA + (size_t)((cpo + (uint32_t)(P)) & ~3u)) >> (8 * ((cpo + (uint32_t)(P)) & 3u))) & 0xFFu))
     auto is_hole = [&](int q) -> bool {
         if (q < eSrc) { if (writer) atomicOr(&s_q[(uint32_t)q >> (cs + 5)], 1u << (((uint32_t)q >> cs) & 31)); }
         else if (q > maxHole) return false;
