@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
 #define KNZ_LZS_CAND(P) ((int)wave_sload_u32(cand8 + (size_t)(uint32_t)(4u * (uint32_t)(P))))                       // (32-bit offsets: the scalar load takes base + offset, no 64-bit address arithmetic)
 #define KNZ_LZS_CP(P) ((int)((wave_sload_u32(cpA + (size_t)((cpo + (uint32_t)(P)) & ~3u)) >> (8 * ((cpo + (uint32_t)(P)) & 3u))) & 0xFFu))
     auto is_hole = [&](int q) -> bool {
-        if (q < eSrc) { if (writer) atomicOr(&s_q[(uint32_t)q >> (cs + 5)], 1u << (((uint32_t)q >> cs) & 31)); }
+        if (q < eSrc) s_q[(uint32_t)q >> (cs + 5)] |= 1u << (((uint32_t)q >> cs) & 31);       // (every lane writes the same word: the wave is the only writer of its log, no atomic needed)
         else if (q > maxHole) return false;
         if (!((s_coarse[(uint32_t)q >> (cs + 5)] >> (((uint32_t)q >> cs) & 31)) & 1u)) return false;
         const uint32_t w = (uint32_t)q >> 5, m = 1u << (q & 31);
