@@ -413,22 +413,15 @@ __device__ __forceinline__ void knz_rank_chain_range_v(RankChainV<MODE, PACKED, 
             uint32_t ob = 0;
             const uint32_t any = cur.x | cur.y | cur.z | cur.w;
 #ifndef KNZ_HIP_EMU
-            if (PACKED && MODE == 2 && (XP & 4) != 0 && !WIDE && (any & 0xC0C0C0C0u) == 0) {   // no rank of 64 or more in the group: one hand-written block (rank_inv_asm.h)
-                knz_rank_group_low_packed(c.e[0], c.q[0], ob, cur.x, cur.y, cur.z, cur.w, i << 8, c.vff, (uint32_t)lane, wave_in_vgpr(0x7FFFFFFFu));
+            if (PACKED && MODE == 2 && (XP & 4) != 0 && !WIDE) {                       // the group of sixteen accesses as one hand-written block (rank_inv_asm.h)
+                knz_rank_group_packed(c.e[0], c.e[1], c.e[2], c.e[3], c.q[0], c.q[1], c.q[2], c.q[3], ob, cur.x, cur.y, cur.z, cur.w, i << 8, c.vff,
+                                      (uint32_t)lane, wave_in_vgpr(0x7FFFFFFFu));
             } else
 #endif
             if (any == 0) ob = c.run_top(i + 15, 16);
             else if (any & 0xC0C0C0C0u) {                                        // ranks >= 64 in the group: words without one take the clean body
-#ifndef KNZ_HIP_EMU
-                if (PACKED && MODE == 2 && (XP & 4) != 0 && !WIDE) {               // the whole group as one hand-written block (rank_inv_asm.h)
-                    knz_rank_group_any_packed(c.e[0], c.e[1], c.e[2], c.e[3], c.q[0], c.q[1], c.q[2], c.q[3], ob, cur.x, cur.y, cur.z, cur.w, i << 8, c.vff,
-                                              (uint32_t)lane, wave_in_vgpr(0x7FFFFFFFu));
-                } else
-#endif
-                {
                 c.template word_any<0>(cur.x, i, ob); c.template word_any<1>(cur.y, i + 4, ob);
                 c.template word_any<2>(cur.z, i + 8, ob); c.template word_any<3>(cur.w, i + 12, ob);
-                }
             } else {
                 c.template word<0>(cur.x, i, ob); c.template word<1>(cur.y, i + 4, ob);
                 c.template word<2>(cur.z, i + 8, ob); c.template word<3>(cur.w, i + 12, ob);
