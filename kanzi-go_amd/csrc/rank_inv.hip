@@ -401,6 +401,7 @@ __device__ __forceinline__ void knz_rank_chain_range_v(RankChainV<MODE, PACKED, 
         const bool rows = (((uintptr_t)dst) & 3) == 0;
         const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
         const uint32_t rowSlot = 4u * ((uint32_t)lane & 3u) + (((uint32_t)lane >> 2) & 3u);
+        const uint32_t vmaxAll = wave_in_vgpr(0x7FFFFFFFu);                     // (loop invariant operand of the hand-written block)
         uint32_t racc = 0, rsh = 0;
         const uint32_t g0 = begin >> 4;
         const uint32_t gEnd = rows ? g0 + (((end - begin) >> 4) & ~3u) : g0;     // groups that lie in whole rows: the loop takes these, the last < 64 ranks go byte by byte below
@@ -415,7 +416,7 @@ __device__ __forceinline__ void knz_rank_chain_range_v(RankChainV<MODE, PACKED, 
 #ifndef KNZ_HIP_EMU
             if (PACKED && MODE == 2 && (XP & 4) != 0 && !WIDE) {                       // the group of sixteen accesses as one hand-written block (rank_inv_asm.h)
                 knz_rank_group_packed(c.e[0], c.e[1], c.e[2], c.e[3], c.q[0], c.q[1], c.q[2], c.q[3], ob, cur.x, cur.y, cur.z, cur.w, i << 8, c.vff,
-                                      (uint32_t)lane, wave_in_vgpr(0x7FFFFFFFu));
+                                      (uint32_t)lane, vmaxAll);
             } else
 #endif
             if (any == 0) ob = c.run_top(i + 15, 16);

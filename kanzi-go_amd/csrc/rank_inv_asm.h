@@ -145,35 +145,6 @@
     "v_writelane_b32 %[ob], %[se], " L2 "\n\t" \
     "v_writelane_b32 %[ob], %[se], " L3 "\n\t" \
     "s_branch .Lknz_rk_wend" W "_%=\n"
-// sixteen accesses (the ranks in w0..w3, first one at time i; i8 = i << 8 as a scalar); decoded entries to lanes 0..15 of ob
-__device__ __forceinline__ void knz_rank_group_any_packed(uint32_t& e0, uint32_t& e1, uint32_t& e2, uint32_t& e3, int& q0, int& q1, int& q2, int& q3, uint32_t& ob,
-                                                          uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t i8, uint32_t vff, uint32_t lane, uint32_t vmax) {
-    uint32_t se, l, r, vnew, es, t8, vbase;
-    int qx, vqc, qs;
-    uint64_t keep;
-    asm volatile(
-        "v_mov_b32_e32 %[vbase], %[i8]\n\t"
-        KNZ_RK_WORD("0", "w0", "0", "0x100", "0x200", "0x300", "0", "1", "2", "3")
-        KNZ_RK_WORD("1", "w1", "0x400", "0x500", "0x600", "0x700", "4", "5", "6", "7")
-        KNZ_RK_WORD("2", "w2", "0x800", "0x900", "0xa00", "0xb00", "8", "9", "10", "11")
-        KNZ_RK_WORD("3", "w3", "0xc00", "0xd00", "0xe00", "0xf00", "12", "13", "14", "15")
-        "s_branch .Lknz_rk_done_%=\n"
-        KNZ_RK_WORD_REST("0", "w0", "0", "0x100", "0x200", "0x300", "2", "0", "1", "2", "3")
-        KNZ_RK_WORD_REST("1", "w1", "0x400", "0x500", "0x600", "0x700", "6", "4", "5", "6", "7")
-        KNZ_RK_WORD_REST("2", "w2", "0x800", "0x900", "0xa00", "0xb00", "10", "8", "9", "10", "11")
-        KNZ_RK_WORD_REST("3", "w3", "0xc00", "0xd00", "0xe00", "0xf00", "14", "12", "13", "14", "15")
-        KNZ_RK_HIGH("00") KNZ_RK_HIGH("01") KNZ_RK_HIGH("02") KNZ_RK_HIGH("03")
-        KNZ_RK_HIGH("10") KNZ_RK_HIGH("11") KNZ_RK_HIGH("12") KNZ_RK_HIGH("13")
-        KNZ_RK_HIGH("20") KNZ_RK_HIGH("21") KNZ_RK_HIGH("22") KNZ_RK_HIGH("23")
-        KNZ_RK_HIGH("30") KNZ_RK_HIGH("31") KNZ_RK_HIGH("32") KNZ_RK_HIGH("33")
-        ".Lknz_rk_done_%=:"
-        : [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [e3] "+v"(e3), [q0] "+v"(q0), [q1] "+v"(q1), [q2] "+v"(q2), [q3] "+v"(q3), [ob] "+v"(ob),
-          [se] "=&s"(se), [l] "=&s"(l), [r] "=&s"(r), [vnew] "=&v"(vnew), [es] "=&v"(es), [qx] "=&v"(qx), [vqc] "=&v"(vqc), [qs] "=&v"(qs), [t8] "=&v"(t8),
-          [vbase] "=&v"(vbase), [keep] "=&s"(keep)
-        : [w0] "s"(w0), [w1] "s"(w1), [w2] "s"(w2), [w3] "s"(w3), [i8] "s"(i8), [vff] "v"(vff), [lane] "v"(lane), [vmax] "v"(vmax)
-        : "vcc", "scc");
-}
-
 // ---- a group WITHOUT a rank of 64 or more (every group of a text-like block): words of four ranks 0 go out of line, the others are
 // four low steps in a row; sixteen ranks 0 are one step
 #define KNZ_RK_ZERO4(W, T3, Q3, L0, L1, L2, L3) \
@@ -199,46 +170,10 @@ __device__ __forceinline__ void knz_rank_group_any_packed(uint32_t& e0, uint32_t
     KNZ_RK_X2(WR) KNZ_RK_T(T2) KNZ_RK_LOW(L2) "\tv_writelane_b32 %[ob], %[se], " L2 "\n\t" \
     KNZ_RK_X3(WR) KNZ_RK_T(T3) KNZ_RK_LOW(L3) "\tv_writelane_b32 %[ob], %[se], " L3 "\n" \
     ".Lknz_rk_bwend" W "_%=:\n\t"
-__device__ __forceinline__ void knz_rank_group_low_packed(uint32_t& e0, int& q0, uint32_t& ob, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t i8,
-                                                          uint32_t vff, uint32_t lane, uint32_t vmax) {
-    uint32_t se, l, r, vnew, t8, vbase;
-    int qx, vqc;
-    uint64_t keep;
-    asm volatile(
-        "s_or_b32 %[r], %[w0], %[w1]\n\t"
-        "s_or_b32 %[l], %[w2], %[w3]\n\t"
-        "s_or_b32 %[r], %[r], %[l]\n\t"
-        "s_cmp_eq_u32 %[r], 0\n\t"
-        "s_cbranch_scc1 .Lknz_rk_zero16_%=\n\t"
-        "v_mov_b32_e32 %[vbase], %[i8]\n\t"
-        KNZ_RK_CWORD("0", "w0", "0", "0x100", "0x200", "0x300", "0", "1", "2", "3")
-        KNZ_RK_CWORD("1", "w1", "0x400", "0x500", "0x600", "0x700", "4", "5", "6", "7")
-        KNZ_RK_CWORD("2", "w2", "0x800", "0x900", "0xa00", "0xb00", "8", "9", "10", "11")
-        KNZ_RK_CWORD("3", "w3", "0xc00", "0xd00", "0xe00", "0xf00", "12", "13", "14", "15")
-        "s_branch .Lknz_rk_done_%=\n"
-        KNZ_RK_ZERO4("0", "0x300", "2", "0", "1", "2", "3")
-        KNZ_RK_ZERO4("1", "0x700", "6", "4", "5", "6", "7")
-        KNZ_RK_ZERO4("2", "0xb00", "10", "8", "9", "10", "11")
-        KNZ_RK_ZERO4("3", "0xf00", "14", "12", "13", "14", "15")
-        ".Lknz_rk_zero16_%=:\n\t"                                 /* sixteen ranks 0: times i .. i+15 */
-        "v_readlane_b32 %[se], %[e0], 0\n\t"
-        "s_and_b32 %[se], %[se], 0xff\n\t"
-        "s_add_i32 %[l], %[i8], 0xf00\n\t"
-        "s_or_b32 %[l], %[l], %[se]\n\t"
-        "v_writelane_b32 %[e0], %[l], 0\n\t"
-        "s_lshr_b32 %[l], %[i8], 8\n\t"
-        "s_add_i32 %[l], %[l], 14\n\t"
-        "v_writelane_b32 %[q0], %[l], 0\n\t"
-        "v_mov_b32_e32 %[ob], %[se]\n"
-        ".Lknz_rk_done_%=:"
-        : [e0] "+v"(e0), [q0] "+v"(q0), [ob] "+v"(ob),
-          [se] "=&s"(se), [l] "=&s"(l), [r] "=&s"(r), [vnew] "=&v"(vnew), [qx] "=&v"(qx), [vqc] "=&v"(vqc), [t8] "=&v"(t8), [vbase] "=&v"(vbase), [keep] "=&s"(keep)
-        : [w0] "s"(w0), [w1] "s"(w1), [w2] "s"(w2), [w3] "s"(w3), [i8] "s"(i8), [vff] "v"(vff), [lane] "v"(lane), [vmax] "v"(vmax)
-        : "vcc", "scc");
-}
 
-// ---- both kinds of group behind ONE statement (what the chain's loop calls): with two statements the compiler reconciles the list's
-// registers where their paths meet and again on the loop's back edge (30-40 v_mov_b32 per group of sixteen accesses)
+// ---- sixteen accesses (the ranks in w0..w3, first one at time i; i8 = i << 8 as a scalar); decoded entries to lanes 0..15 of ob.
+// Both kinds of group behind ONE statement: with a statement per kind the compiler reconciles the list's registers where their paths
+// meet and again on the loop's back edge (30-40 v_mov_b32 per group: measured 460 -> 418 ms on the slowest block)
 __device__ __forceinline__ void knz_rank_group_packed(uint32_t& e0, uint32_t& e1, uint32_t& e2, uint32_t& e3, int& q0, int& q1, int& q2, int& q3, uint32_t& ob,
                                                       uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t i8, uint32_t vff, uint32_t lane, uint32_t vmax) {
     uint32_t se, l, r, vnew, es, t8, vbase;
