@@ -1,0 +1,3 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
