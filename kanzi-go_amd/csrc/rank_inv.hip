@@ -405,6 +405,14 @@ __device__ __forceinline__ void knz_rank_chain_range_v(RankChainV<MODE, PACKED, 
         uint32_t racc = 0, rsh = 0;
         const uint32_t g0 = begin >> 4;
         const uint32_t gEnd = rows ? g0 + (((end - begin) >> 4) & ~3u) : g0;     // groups that lie in whole rows: the loop takes these, the last < 64 ranks go byte by byte below
+#ifndef KNZ_HIP_EMU
+        if (PACKED && MODE == 2 && (XP & 4) != 0 && !WIDE && !(XP & 3)) {           // default device form: the loop over the groups and the groups themselves hand-written (rank_inv_asm.h)
+            if (gEnd > g0)
+                knz_rank_rows_packed(c.e[0], c.e[1], c.e[2], c.e[3], c.q[0], c.q[1], c.q[2], c.q[3], src + 16 * (size_t)g0, 16u * (gEnd - g0), dst + 16 * (size_t)g0,
+                                     4u * rowSlot, (16u * g0) << 8, c.vff, (uint32_t)lane, vmaxAll, sel1, sel2);
+        } else
+#endif
+        {
         knz_u32x4 nxt = {0, 0, 0, 0};
         if (gEnd > g0) nxt = wave_sload_u32x4(src + 16 * (size_t)g0);
         for (uint32_t g = g0; g < gEnd; g++) {
@@ -435,6 +443,7 @@ __device__ __forceinline__ void knz_rank_chain_range_v(RankChainV<MODE, PACKED, 
                 if (lane < 16) ((uint32_t*)(dst + (i - 48)))[rowSlot] = o;
                 racc = 0; rsh = 0;
             }
+        }
         }
         i0 = 16 * gEnd;
     }

@@ -231,3 +231,106 @@ __device__ __forceinline__ void knz_rank_group_packed(uint32_t& e0, uint32_t& e1
         : [w0] "s"(w0), [w1] "s"(w1), [w2] "s"(w2), [w3] "s"(w3), [i8] "s"(i8), [vff] "v"(vff), [lane] "v"(lane), [vmax] "v"(vmax)
         : "vcc", "scc");
 }
+
+// ---- the loop around the block as well: `nbytes` / 16 groups of sixteen ranks starting at src (nbytes a multiple of 64), the decoded bytes
+// to dbase in rows of 64 (lane l < 16 stores the dword at doff = 4 * rowSlot(l), see rank_inv.hip, + 64 per row). The ranks of a group arrive
+// through one s_load_dwordx4 issued a group ahead (into s92..s95, moved to s88..s91 = w0..w3 when the group starts: the registers are named
+// because the halves of a loaded quad are operands); four groups are collected in `racc` (byte k of lane j = symbol j of group k) and leave
+// through the 4 x 4 byte transpose inside every quad of lanes. Per group the loop costs ~16 instructions; the compiler's loop around the
+// one-group statement cost ~30 (measured: slowest block 418 -> see profiles/r03_rank_inverse_per_block.txt).
+__device__ __forceinline__ void knz_rank_rows_packed(uint32_t& e0, uint32_t& e1, uint32_t& e2, uint32_t& e3, int& q0, int& q1, int& q2, int& q3,
+                                                     const uint8_t* src, uint32_t nbytes, uint8_t* dbase, uint32_t doff, uint32_t i8,
+                                                     uint32_t vff, uint32_t lane, uint32_t vmax, uint32_t sel1, uint32_t sel2) {
+    uint32_t se, l, lo, r, vnew, es, t8, vbase, ob, racc, tt, soff, rsh, w0, w1, w2, w3;
+    int qx, vqc, qs;
+    uint64_t keep;
+    const uint32_t lastoff = nbytes - 16;
+    asm volatile(
+        "s_load_dwordx4 s[88:91], %[src], 0x0\n\t"
+        "s_mov_b32 %[soff], 16\n\t"
+        "s_mov_b32 %[rsh], 0\n\t"
+        "v_mov_b32_e32 %[vbase], %[i8]\n\t"
+        "v_mov_b32_e32 %[racc], 0\n\t"
+        "s_waitcnt lgkmcnt(0)\n"
+        ".Lknz_rk_loop_%=:\n\t"
+        "s_min_u32 %[lo], %[soff], %[lastoff]\n\t"               /* the group after this one (the last group is read twice rather than reading past the end) */
+        "s_load_dwordx4 s[92:95], %[src], %[lo]\n\t"             /* (%[lo] stays untouched until the wait at the bottom of the loop) */
+        "s_or_b32 %[r], %[w0], %[w1]\n\t"
+        "s_or_b32 %[l], %[w2], %[w3]\n\t"
+        "s_or_b32 %[r], %[r], %[l]\n\t"
+        "s_and_b32 %[l], %[r], 0xc0c0c0c0\n\t"
+        "s_cmp_eq_u32 %[l], 0\n\t"
+        "s_cbranch_scc1 .Lknz_rk_lowgroup_%=\n\t"
+        KNZ_RK_WORD("0", "w0", "0", "0x100", "0x200", "0x300", "0", "1", "2", "3")
+        KNZ_RK_WORD("1", "w1", "0x400", "0x500", "0x600", "0x700", "4", "5", "6", "7")
+        KNZ_RK_WORD("2", "w2", "0x800", "0x900", "0xa00", "0xb00", "8", "9", "10", "11")
+        KNZ_RK_WORD("3", "w3", "0xc00", "0xd00", "0xe00", "0xf00", "12", "13", "14", "15")
+        ".Lknz_rk_done_%=:\n\t"
+        "v_and_b32_e32 %[tt], 0xff, %[ob]\n\t"
+        "v_lshl_or_b32 %[racc], %[tt], %[rsh], %[racc]\n\t"
+        "v_add_u32_e32 %[vbase], 0x1000, %[vbase]\n\t"
+        "s_addk_i32 %[i8], 0x1000\n\t"
+        "s_add_u32 %[soff], %[soff], 16\n\t"
+        "s_add_u32 %[rsh], %[rsh], 8\n\t"
+        "s_cmp_lg_u32 %[rsh], 32\n\t"
+        "s_cbranch_scc1 .Lknz_rk_norow_%=\n\t"
+        "v_mov_b32_dpp %[tt], %[racc] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_perm_b32 %[tt], %[tt], %[racc], %[sel1]\n\t"
+        "s_mov_b32 %[rsh], 0\n\t"
+        "s_nop 0\n\t"
+        "v_mov_b32_dpp %[racc], %[tt] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_perm_b32 %[tt], %[racc], %[tt], %[sel2]\n\t"
+        "s_mov_b64 exec, 0xffff\n\t"
+        "global_store_dword %[doff], %[tt], %[dbase]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "v_add_u32_e32 %[doff], 64, %[doff]\n\t"
+        "v_mov_b32_e32 %[racc], 0\n"
+        ".Lknz_rk_norow_%=:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b64 s[88:89], s[92:93]\n\t"
+        "s_mov_b64 s[90:91], s[94:95]\n\t"
+        "s_cmp_le_u32 %[soff], %[nbytes]\n\t"                   /* soff = 16 x (groups done + 1) */
+        "s_cbranch_scc1 .Lknz_rk_loop_%=\n\t"
+        "s_branch .Lknz_rk_end_%=\n"
+        KNZ_RK_WORD_REST("0", "w0", "0", "0x100", "0x200", "0x300", "2", "0", "1", "2", "3")
+        KNZ_RK_WORD_REST("1", "w1", "0x400", "0x500", "0x600", "0x700", "6", "4", "5", "6", "7")
+        KNZ_RK_WORD_REST("2", "w2", "0x800", "0x900", "0xa00", "0xb00", "10", "8", "9", "10", "11")
+        KNZ_RK_WORD_REST("3", "w3", "0xc00", "0xd00", "0xe00", "0xf00", "14", "12", "13", "14", "15")
+        KNZ_RK_HIGH("00") KNZ_RK_HIGH("01") KNZ_RK_HIGH("02") KNZ_RK_HIGH("03")
+        KNZ_RK_HIGH("10") KNZ_RK_HIGH("11") KNZ_RK_HIGH("12") KNZ_RK_HIGH("13")
+        KNZ_RK_HIGH("20") KNZ_RK_HIGH("21") KNZ_RK_HIGH("22") KNZ_RK_HIGH("23")
+        KNZ_RK_HIGH("30") KNZ_RK_HIGH("31") KNZ_RK_HIGH("32") KNZ_RK_HIGH("33")
+        ".Lknz_rk_lowgroup_%=:\n\t"
+        "s_cmp_eq_u32 %[r], 0\n\t"
+        "s_cbranch_scc1 .Lknz_rk_zero16_%=\n\t"
+        KNZ_RK_CWORD("0", "w0", "0", "0x100", "0x200", "0x300", "0", "1", "2", "3")
+        KNZ_RK_CWORD("1", "w1", "0x400", "0x500", "0x600", "0x700", "4", "5", "6", "7")
+        KNZ_RK_CWORD("2", "w2", "0x800", "0x900", "0xa00", "0xb00", "8", "9", "10", "11")
+        KNZ_RK_CWORD("3", "w3", "0xc00", "0xd00", "0xe00", "0xf00", "12", "13", "14", "15")
+        "s_branch .Lknz_rk_done_%=\n"
+        KNZ_RK_ZERO4("0", "0x300", "2", "0", "1", "2", "3")
+        KNZ_RK_ZERO4("1", "0x700", "6", "4", "5", "6", "7")
+        KNZ_RK_ZERO4("2", "0xb00", "10", "8", "9", "10", "11")
+        KNZ_RK_ZERO4("3", "0xf00", "14", "12", "13", "14", "15")
+        ".Lknz_rk_zero16_%=:\n\t"
+        "v_readlane_b32 %[se], %[e0], 0\n\t"
+        "s_and_b32 %[se], %[se], 0xff\n\t"
+        "s_add_i32 %[l], %[i8], 0xf00\n\t"
+        "s_or_b32 %[l], %[l], %[se]\n\t"
+        "v_writelane_b32 %[e0], %[l], 0\n\t"
+        "s_lshr_b32 %[l], %[i8], 8\n\t"
+        "s_add_i32 %[l], %[l], 14\n\t"
+        "v_writelane_b32 %[q0], %[l], 0\n\t"
+        "v_mov_b32_e32 %[ob], %[se]\n\t"
+        "s_branch .Lknz_rk_done_%=\n"
+        ".Lknz_rk_end_%=:"
+        : [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [e3] "+v"(e3), [q0] "+v"(q0), [q1] "+v"(q1), [q2] "+v"(q2), [q3] "+v"(q3),
+          [doff] "+v"(doff), [i8] "+s"(i8),
+          [se] "=&s"(se), [l] "=&s"(l), [r] "=&s"(r), [lo] "=&s"(lo), [soff] "=&s"(soff), [rsh] "=&s"(rsh), [keep] "=&s"(keep),
+          [w0] "=&{s88}"(w0), [w1] "=&{s89}"(w1), [w2] "=&{s90}"(w2), [w3] "=&{s91}"(w3),
+          [vnew] "=&v"(vnew), [es] "=&v"(es), [qx] "=&v"(qx), [vqc] "=&v"(vqc), [qs] "=&v"(qs), [t8] "=&v"(t8), [vbase] "=&v"(vbase),
+          [ob] "=&v"(ob), [racc] "=&v"(racc), [tt] "=&v"(tt)
+        : [src] "s"(src), [dbase] "s"(dbase), [nbytes] "s"(nbytes), [lastoff] "s"(lastoff), [vff] "v"(vff), [lane] "v"(lane), [vmax] "v"(vmax),
+          [sel1] "v"(sel1), [sel2] "v"(sel2)
+        : "vcc", "scc", "s92", "s93", "s94", "s95", "memory");
+}
