@@ -237,7 +237,7 @@ __device__ __forceinline__ void knz_rank_group_packed(uint32_t& e0, uint32_t& e1
 // through one s_load_dwordx4 issued a group ahead (into s92..s95, moved to s88..s91 = w0..w3 when the group starts: the registers are named
 // because the halves of a loaded quad are operands); four groups are collected in `racc` (byte k of lane j = symbol j of group k) and leave
 // through the 4 x 4 byte transpose inside every quad of lanes. Per group the loop costs ~16 instructions; the compiler's loop around the
-// one-group statement cost ~30 (measured: slowest block 418 -> see profiles/r03_rank_inverse_per_block.txt).
+// one-group statement cost ~30 (measured: slowest block 418 -> 408 ms, profiles/r03_rank_inverse_per_block.txt).
 __device__ __forceinline__ void knz_rank_rows_packed(uint32_t& e0, uint32_t& e1, uint32_t& e2, uint32_t& e3, int& q0, int& q1, int& q2, int& q3,
                                                      const uint8_t* src, uint32_t nbytes, uint8_t* dbase, uint32_t doff, uint32_t i8,
                                                      uint32_t vff, uint32_t lane, uint32_t vmax, uint32_t sel1, uint32_t sel2) {
