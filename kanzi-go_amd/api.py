@@ -186,9 +186,9 @@ class Codec:
 
     def last_kernel_times(self):
         """[(kernel name, ms)] of the probed launches of the last device batch (HIP events on the launch stream)."""
-        names = C.create_string_buffer(8192)
-        ms = (C.c_float * 64)()
-        n = self.L.knz_last_kernel_times(self.h, names, 8192, ms, 64)
+        names = C.create_string_buffer(16384)
+        ms = (C.c_float * 128)()
+        n = self.L.knz_last_kernel_times(self.h, names, 16384, ms, 128)
         nm = names.value.decode().split("\n")
         return [(nm[i], float(ms[i])) for i in range(n)]
 

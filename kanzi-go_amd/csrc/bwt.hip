@@ -2,10 +2,8 @@
 // Forward replaces BWTBlockCodec.Forward / BWT.Forward / DivSufSort.ComputeBWT (v2/transform/BWTBlockCodec.go:78-137,
 // v2/transform/BWT.go:132-175, v2/transform/DivSufSort.go:179-311). The BWT is a function of the input alone (sorted
 // suffixes, a suffix that ends first is smaller), so DivSufSort's induced sorting is replaced by a GPU suffix sort:
-// prefix doubling over the concatenation of ALL blocks in HBM (block id in the top key bits keeps blocks apart):
-//   round 0: radix sort of (block id, first 6 symbols) keys            [radix sort of prims.hip]
-//   round k: only suffixes whose group is not yet a singleton are re-sorted by (group start, rank of suffix i+h);
-//            group starts double as ranks, h doubles every round (Manber-Myers / Larsson-Sadakane refinement).
+// prefix doubling over ALL blocks of the batch at once (bwt_sort.hip: per-block radix sort of the first symbols, then rounds that
+// refine only the groups that are not singletons yet, by a segmented sort in LDS; Manber-Myers / Larsson-Sadakane refinement).
 // Output rule (DivSufSort.go:187-197): dst[0] = src[n-1], then src[SA[r]-1] for every rank r except the rank of
 // suffix 0; primaryIndex(k) = rank(suffix k*ceil(n/8)) + 1 (:202-206,:227-229,:283-285,:298-300,:309).
 // Inverse replaces BWTBlockCodec.Inverse / BWT.inverseMergeTPSI / inverseBiPSIv2 (BWTBlockCodec.go:141-225,
@@ -24,78 +22,6 @@ __device__ __forceinline__ uint32_t knz_bwt_block_of(const uint32_t* gstart, uin
     uint32_t lo = 0, hi = nblocks;            // largest b with gstart[b] <= g
     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (gstart[mid] <= g) lo = mid; else hi = mid; }
     return lo;
-}
-
-// round 0 keys: (block | 6 symbols x 8 bits, zero behind the end of the block): 48 + log2(blocks) bits to sort. A suffix shorter than 6
-// symbols shares its key with the suffixes that go on with zeros there; inside that group it is the smallest, and the doubling rounds put it
-// there (knz_bwt_subkeys_kernel). (Rounds 1-2 of this project used 9-bit symbols to tell the two apart at once: a whole radix pass more over
-// every suffix for the sake of five suffixes per block.)
-__global__ __launch_bounds__(256) void knz_bwt_init_kernel(BwtGeom g, uint32_t total, uint64_t* keys, uint32_t* vals) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const uint32_t b = knz_bwt_block_of(g.gstart, g.nblocks, i);
-    const uint32_t loc = i - g.gstart[b];
-    const uint32_t n = g.in_len[b];
-    const uint8_t* src = (const uint8_t*)g.in_ptr[b];
-    uint64_t k = (uint64_t)b;
-#pragma unroll
-    for (int j = 0; j < 6; j++) k = (k << 8) | (loc + j < n ? (uint64_t)src[loc + j] : 0);
-    keys[i] = k;
-    vals[i] = i;
-}
-
-// group boundaries after a sort: head[j] = j if keys differ from the predecessor else 0 (max-scanned later)
-__global__ __launch_bounds__(256) void knz_bwt_heads_kernel(const uint64_t* keys, uint32_t total, uint32_t* head) {
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= total) return;
-    head[j] = (j == 0 || keys[j] != keys[j - 1]) ? j : 0;
-}
-
-// rank[SA[j]] = group start + 1 ; unresolved[j] = group has more than one member
-__global__ __launch_bounds__(256) void knz_bwt_ranks_kernel(const uint32_t* sa, const uint32_t* gs, uint32_t total, uint32_t* rank, uint8_t* unresolved) {
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= total) return;
-    const uint32_t s = gs[j];
-    rank[sa[j]] = s + 1;
-    const bool single = (s == j) && (j + 1 == total || gs[j + 1] == j + 1);
-    unresolved[j] = single ? 0 : 1;
-}
-
-// subset keys for a doubling round: (group start, rank of suffix i+h inside the same block, 0 past the end)
-__global__ __launch_bounds__(256) void knz_bwt_subkeys_kernel(BwtGeom g, const uint32_t* pos, uint32_t m, const uint32_t* sa, const uint32_t* gs,
-                                                              const uint32_t* rank, uint32_t h, uint32_t bits, uint64_t* keys, uint32_t* vals) {
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= m) return;
-    const uint32_t j = pos[k];
-    const uint32_t i = sa[j];
-    const uint32_t b = knz_bwt_block_of(g.gstart, g.nblocks, i);
-    const uint32_t end = g.gstart[b + 1];
-    // second key: the rank of the suffix h symbols on, lifted over h; a suffix that ends within those h symbols is smaller than every member of
-    // its group that goes on, and among such suffixes the shorter one is the smaller (they can only share a group when they end in zeros:
-    // round 0 pads with zeros): its length - 1, which is < h
-    const uint64_t r2 = (uint64_t)i + h < end ? (uint64_t)rank[i + h] + h : (uint64_t)(end - 1 - i);
-    keys[k] = ((uint64_t)gs[j] << bits) | r2;                       // r2 <= total + h < 2^bits (the caller sizes `bits` for that)
-    vals[k] = i;
-}
-
-__global__ __launch_bounds__(256) void knz_bwt_subheads_kernel(const uint64_t* keys, const uint32_t* pos, uint32_t m, uint32_t* head) {
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= m) return;
-    head[k] = (k == 0 || keys[k] != keys[k - 1]) ? pos[k] : 0;
-}
-
-// write the refined order back, new group starts / ranks / unresolved flags for the subset
-__global__ __launch_bounds__(256) void knz_bwt_subupdate_kernel(const uint32_t* pos, uint32_t m, const uint32_t* vals, const uint32_t* gs2,
-                                                                uint32_t* sa, uint32_t* gs, uint32_t* rank, uint8_t* unresolved) {
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= m) return;
-    const uint32_t j = pos[k];
-    const uint32_t s = gs2[k];
-    sa[j] = vals[k];
-    gs[j] = s;
-    rank[vals[k]] = s + 1;
-    const bool single = (s == j) && (k + 1 == m || gs2[k + 1] != s);
-    unresolved[j] = single ? 0 : 1;
 }
 
 struct BwtOutArgs {
@@ -125,7 +51,7 @@ __global__ __launch_bounds__(256) void knz_bwt_output_kernel(BwtOutArgs a, uint3
     uint32_t pIndexSize, chunks, headerSize;
     knz_bwt_header_geom(n, pIndexSize, chunks, headerSize);
     const uint32_t r = j - gs0;
-    const uint32_t p0 = a.rank[gs0] - 1 - gs0;        // local 0-based rank of suffix 0
+    const uint32_t p0 = a.rank[gs0] - 1;              // 0-based rank of suffix 0 (ranks are block-local, bwt_sort.hip)
     const uint32_t s = a.sa[j] - gs0;
     if (s != 0) dst[headerSize + (r < p0 ? r + 1 : r)] = src[s - 1];
     if (r == 0) {
@@ -136,7 +62,7 @@ __global__ __launch_bounds__(256) void knz_bwt_output_kernel(BwtOutArgs a, uint3
         if (step * chunks != n) step++;
         uint32_t idx = 1;
         for (uint32_t c = 0; c < chunks; c++) {
-            const uint32_t pi = a.rank[gs0 + c * step] - 1 - gs0;     // primaryIndex(c) - 1
+            const uint32_t pi = a.rank[gs0 + c * step] - 1;           // primaryIndex(c) - 1
             for (int sh = (int)(pIndexSize - 1) * 8; sh >= 0; sh -= 8) dst[idx++] = (uint8_t)(pi >> sh);
         }
         a.out_len[b] = n + headerSize;

@@ -21,6 +21,7 @@
 #include "xxhash.hip"
 #include "skip.hip"
 #include "prims.h"
+#include "bwt_sort.hip"
 #include "layout.hip"
 #include <algorithm>
 #include <cstdio>

@@ -19,7 +19,7 @@ struct DevBuf {
 };
 
 // HIP-event pair around one launch of a kernel that can dominate a batch (bench.py's roofline line reads these)
-#define KNZ_MAX_PROBES 48
+#define KNZ_MAX_PROBES 128
 struct KernelProbe { const char* name = nullptr; hipEvent_t a = nullptr, b = nullptr; };
 
 struct Handle {
@@ -56,6 +56,7 @@ struct Handle {
     size_t lzi_serial_n = 0;          // blocks covered by lzi_serial in the last LZ inverse stage (1 = went to the one-wave kernel)
     DevBuf a1_freqs, a1_tab, a1_ctxhdr, a1_ctxbits, a1_dtab, a1_info, a1_paybit, a1_f16, a1_ent, a1_cum, a1_ctxpos;
     DevBuf sa_keys0, sa_keys1, sa_vals0, sa_vals1, sa_rank, sa_gs, sa_head, sa_unres, sa_pos, sa_tmp, sa_links, sa_sp;
+    DevBuf sa_hb, sa_tiles, sa_posl0, sa_posl1, sa_gid0, sa_gid1;   // suffix sort (bwt_sort.hip): head bits, per-tile tables, the large list
     void* pinned = nullptr;           // small pinned host area for results
     int32_t* pinned_status = nullptr; // pinned per-block tables of the last encode batch (grow-only)
     uint32_t* pinned_len = nullptr;

@@ -162,6 +162,8 @@ __device__ __forceinline__ void knz_wg_max_i32(int32_t* p, int32_t v) { (void)__
 __device__ __forceinline__ void wave_raise_priority() { __builtin_amdgcn_s_setprio(3); }
 // value of lane ^ 1 / lane ^ 2 (DPP quad_perm [1,0,3,2] / [2,3,0,1]) and the byte permute of two registers (v_perm_b32: selector byte 0..3 =
 // byte of lo, 4..7 = byte of hi)
+// number of bits of m below this lane's position (v_mbcnt_lo / _hi)
+__device__ __forceinline__ uint32_t wave_mbcnt64(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 __device__ __forceinline__ uint32_t wave_quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t wave_quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t knz_byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
@@ -206,6 +208,7 @@ inline uint64_t wave_ballot(bool p) {
     return r;
 }
 inline uint32_t wave_bcast(uint32_t v, int src) { return wave_shfl(v, src); }
+inline uint32_t wave_mbcnt64(uint64_t m) { return (uint32_t)__builtin_popcountll(m & ((1ull << hipemu::lane()) - 1)); }
 inline uint32_t wave_quad_xor1(uint32_t v) { return wave_shfl(v, hipemu::lane() ^ 1); }
 inline uint32_t wave_quad_xor2(uint32_t v) { return wave_shfl(v, hipemu::lane() ^ 2); }
 inline uint32_t wave_readlane(uint32_t v, uint32_t src) { return wave_shfl(v, (int)src); }

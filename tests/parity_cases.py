@@ -1170,6 +1170,50 @@ def check_fuzz(be, cases, seed, max_n, heavy_max_n=None):
     assert done >= cases * 3 // 4
 
 
+def bwt_sort_inputs(scale=1):
+    """Inputs that reach every part of the forward suffix sort (bwt_sort.hip): groups that stay on the segmented-sort list, groups larger than a
+    segment (device-wide sort), groups that move from the large list to the normal one in several blocks of one batch (the list is then no longer in
+    slot order), long runs, periodic data, blocks that end inside a repeat."""
+    r = np.random.default_rng(4242)
+    n = 9000 * scale
+    z = np.zeros(n, dtype=np.uint8)
+    idx = r.integers(0, n, n // 13)
+    z[idx] = r.choice(np.array([0xFC, 0xFE, 0xFF, 1, 2, 0x80], dtype=np.uint8), len(idx))
+    yield "sparse", z.tobytes()
+    yield "zeros", bytes(n)
+    yield "two", np.where(r.random(n) < 0.02, 7, 9).astype(np.uint8).tobytes()
+    rec = r.integers(0, 256, 37, dtype=np.uint8)
+    per = np.tile(rec, n // 37 + 1)[:n].copy()
+    per[r.integers(0, n, n // 97)] = 3
+    yield "periodic", per.tobytes()
+    yield "text", corpus(n, 11)
+    yield "runs", b"".join(bytes([int(r.integers(0, 4))]) * int(r.integers(1, 400)) for _ in range(n // 100))[:n]
+    yield "abab", (b"ab" * n)[:n - 1]
+    yield "small", np.minimum(r.geometric(0.5, n), 255).astype(np.uint8).tobytes()
+
+
+def check_bwt_sort_forms(be, monkeypatch, scale=1, block_sizes=(1024, 4096), segs=("128", "256", None), check=True):
+    """The forward suffix sort with small segments (emulator build: KNZ_EMU_SG_T, so that short inputs use the large list and the hand-over between
+    the lists) and with the product's; the emulator build also checks the sort's invariants between rounds (KNZ_EMU_SS_CHECK)."""
+    if check:
+        monkeypatch.setenv("KNZ_EMU_SS_CHECK", "1")
+    for seg in segs:
+        if seg is None:
+            monkeypatch.delenv("KNZ_EMU_SG_T", raising=False)
+        else:
+            monkeypatch.setenv("KNZ_EMU_SG_T", seg)
+        for bs in block_sizes:
+            c = K.Codec("BWT", "NONE", bs, lib=be.lib)
+            for name, data in bwt_sort_inputs(scale):
+                n = len(data)
+                src, ks = be.to_dev(data)
+                cap = 2 * n + 65536 + 64 * (n // bs + 2)
+                dst, kd = be.empty(cap)
+                nb = c.dev_compress(src, n, dst, cap)
+                assert be.to_host(kd, nb) == O.compress(data, "BWT", "NONE", bs), (name, seg, bs)
+            c.close()
+
+
 class pytest_raises_knz:
     def __init__(self, code):
         self.code = code

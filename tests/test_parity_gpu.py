@@ -258,6 +258,11 @@ def test_bwt_inverse_list_ranking(be, monkeypatch):
     P.check_corrupt_streams(be)
 
 
+def test_bwt_suffix_sort_forms(be, monkeypatch):
+    # (the segment size is the product's on the device; 64 KiB and 1 MiB blocks: many blocks per batch, groups larger than a segment in every one)
+    P.check_bwt_sort_forms(be, monkeypatch, scale=60, block_sizes=(1 << 16, 1 << 20), segs=(None,), check=False)
+
+
 def test_rank_chain_variants(be, monkeypatch):
     P.check_rank_chain_variants(be, monkeypatch)
 
