@@ -362,6 +362,121 @@ __global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a, const u
     }
 }
 
+#ifndef KNZ_HIP_EMU
+// The same kernel with the dependent loop written by hand (device build; the emulator runs the C++ form above, which stays the A/B form on the
+// device: KNZ_ANS1_ENC_PLAIN). A lone wave pays ~2.5 ns for every instruction it issues (profiles/r02_lone_wave_latencies.md); the compiler's loop
+// has 11.5-12 per step: the renormalisation shift and its select are two instructions, every step folds its four ballot bits into a scalar mask
+// (s_and + s_or / s_mov), and every step has its own s_waitcnt. Here a step is 7 instructions + its entry load:
+//   ds_write_b32   the state BEFORE the renormalisation goes to the fixed LDS slot of (step, state): its low half is the candidate word, and
+//                  whether it is a real word is decided once per 48 steps by all 64 lanes (lane = 4 * step + state compares its slot with the
+//                  xMax of its (step, state), which it loaded together with the group's entries): no mask bookkeeping on the chain;
+//   v_cmp_ge_u32 / v_cndmask_b32_sdwa (src1_sel:WORD_1)   st = st >= xMax ? st >> 16 : st  in one select;
+//   v_mul_hi_u32, v_lshrrev_b32, v_mul_u32_u24_sdwa, v_add3_u32   st += bias + (st / freq) * (2^11 - freq)  as before.
+// Four steps per statement (an asm statement takes at most 30 operands); the compiler places the loads between the statements and one
+// s_waitcnt in front of each (the loads of a group return in order).
+#define KNZ_A1E_SDWA " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+#define KNZ_A1E_STEP(J) \
+    "ds_write_b32 %[ad], %[st] offset:%[o" J "]\n\t" \
+    "v_cmp_ge_u32_e32 vcc, %[st], %[y" J "]\n\t" \
+    "v_cndmask_b32_sdwa %[st], %[st], %[st], vcc" KNZ_A1E_SDWA \
+    "v_mul_hi_u32 %[q], %[st], %[x" J "]\n\t" \
+    "v_lshrrev_b32_e32 %[q], %[w" J "], %[q]\n\t" \
+    "v_mul_u32_u24_sdwa %[q], %[q], %[w" J "]" KNZ_A1E_SDWA \
+    "v_add3_u32 %[st], %[st], %[z" J "], %[q]\n\t"
+template <int OFF>
+__device__ __forceinline__ void knz_a1e_run4(uint32_t& st, const uint4& e0, const uint4& e1, const uint4& e2, const uint4& e3, uint32_t ad) {
+    uint32_t q;
+    asm volatile(KNZ_A1E_STEP("0") KNZ_A1E_STEP("1") KNZ_A1E_STEP("2") KNZ_A1E_STEP("3")
+                 : [st] "+v"(st), [q] "=&v"(q)
+                 : [x0] "v"(e0.x), [y0] "v"(e0.y), [z0] "v"(e0.z), [w0] "v"(e0.w), [x1] "v"(e1.x), [y1] "v"(e1.y), [z1] "v"(e1.z), [w1] "v"(e1.w),
+                   [x2] "v"(e2.x), [y2] "v"(e2.y), [z2] "v"(e2.z), [w2] "v"(e2.w), [x3] "v"(e3.x), [y3] "v"(e3.y), [z3] "v"(e3.z), [w3] "v"(e3.w),
+                   [ad] "v"(ad), [o0] "n"(OFF), [o1] "n"(OFF + 16), [o2] "n"(OFF + 32), [o3] "n"(OFF + 48)
+                 : "vcc");
+}
+template <int R>
+__device__ __forceinline__ void knz_a1e_run_group(uint32_t& st, const uint4* e, uint32_t ad) {
+    knz_a1e_run4<R * 256>(st, e[0], e[1], e[2], e[3], ad);
+    knz_a1e_run4<R * 256 + 64>(st, e[4], e[5], e[6], e[7], ad);
+    knz_a1e_run4<R * 256 + 128>(st, e[8], e[9], e[10], e[11], ad);
+    knz_a1e_run4<R * 256 + 192>(st, e[12], e[13], e[14], e[15], ad);
+}
+
+__global__ __launch_bounds__(64) void knz_ans1_encode_asm_kernel(Ans1Args a, const uint4* ent) {
+    __shared__ uint32_t s_w[3 * KNZ_ANS1_GROUP * 4];                    // state in front of the renormalisation of (step, state) of the current 48 steps
+    const int lane = threadIdx.x;
+    const uint32_t slotId = blockIdx.x;
+    uint32_t b, n; const uint8_t* src; bool bad;
+    const uint32_t steps = knz_ans1_steps(a, slotId, b, n, src, bad);
+    const bool live = n != 0;
+    uint8_t* slot = a.scratch + (size_t)slotId * KNZ_ANS1_SLOT;
+    uint8_t* payEnd = slot + KNZ_ANS1_PAY_OFF + KNZ_ANS1_PAY_CAP;
+    const uint4* __restrict__ base = ent + (size_t)slotId * KNZ_ANS1_ENT_STRIDE;
+    const uint4* __restrict__ my = base + (size_t)(lane & 3);           // lanes 4..63 mirror lanes 0..3 (same entries, same state, same LDS words)
+    const uint32_t ad = knz_lds_addr(s_w) + 4u * (uint32_t)(lane & 3);
+    uint32_t st = 1u << 15;
+    uint32_t flushed = 0;
+    uint4 buf0[KNZ_ANS1_GROUP], buf1[KNZ_ANS1_GROUP], buf2[KNZ_ANS1_GROUP];
+    uint32_t xm0 = 0xFFFFFFFFu, xm1 = 0xFFFFFFFFu, xm2;               // xMax of (step = lane >> 2, state = lane & 3) of the group a buffer holds
+    auto load_group = [&](uint32_t t0, uint4* e, uint32_t& xm) {
+#pragma unroll
+        for (int j = 0; j < KNZ_ANS1_GROUP; j++) e[j] = my[(size_t)(t0 + j) * 4];
+        xm = base[(size_t)t0 * 4 + (uint32_t)lane].y;
+    };
+    auto flush = [&](uint32_t x0, uint32_t x1, uint32_t x2) {
+        wave_sync_lds();
+        const uint64_t below = ((uint64_t)1 << lane) - 1;
+        const uint32_t v0 = s_w[lane], v1 = s_w[64 + lane], v2 = s_w[128 + lane];
+        const uint64_t m0 = wave_ballot(v0 >= x0), m1 = wave_ballot(v1 >= x1), m2 = wave_ballot(v2 >= x2);
+        const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2);
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const uint64_t m = r == 0 ? m0 : (r == 1 ? m1 : m2);
+            const uint32_t before = r == 0 ? 0u : (r == 1 ? c0 : c0 + c1);
+            if ((m >> lane) & 1) {
+                const uint32_t pos = flushed + before + (uint32_t)__popcll(m & below);
+                const uint32_t wv = r == 0 ? v0 : (r == 1 ? v1 : v2);
+                uint8_t* p = payEnd - 2 * ((size_t)pos + 1);
+                p[0] = (uint8_t)(wv >> 8);
+                p[1] = (uint8_t)wv;
+            }
+        }
+        flushed += c0 + c1 + c2;
+        wave_sync_lds();
+    };
+#pragma unroll
+    for (int j = 0; j < KNZ_ANS1_GROUP; j++) { buf0[j].x = 0; buf0[j].y = 0xFFFFFFFFu; buf0[j].z = 0; buf0[j].w = 0; buf1[j] = buf0[j]; }
+    for (uint32_t t0 = 0; t0 < steps + 2 * KNZ_ANS1_GROUP && steps; t0 += 3 * KNZ_ANS1_GROUP) {
+        load_group(t0, buf2, xm2); knz_a1e_run_group<0>(st, buf0, ad);
+        const uint32_t f0 = xm0;
+        load_group(t0 + KNZ_ANS1_GROUP, buf0, xm0); knz_a1e_run_group<1>(st, buf1, ad);
+        const uint32_t f1 = xm1;
+        load_group(t0 + 2 * KNZ_ANS1_GROUP, buf1, xm1); knz_a1e_run_group<2>(st, buf2, ad);
+        flush(f0, f1, xm2);
+    }
+    const uint32_t s1 = wave_shfl(st, 1), s2 = wave_shfl(st, 2), s3 = wave_shfl(st, 3);
+    if (bad && lane == 0) a.blk_status[b] = KNZ_ERR_PROCESS_BLOCK;
+    if (live && lane == 0) {
+        const uint32_t end4 = n & ~3u;
+        const uint32_t tail = n & 3;
+        for (uint32_t i = 0; i < tail; i++) payEnd[i] = src[end4 + i];
+        const uint32_t nbytes = 2 * flushed + tail;
+        uint32_t w[8];
+        for (int i = 0; i < 8; i++) w[i] = 0;
+        KnzBitWriter bw;
+        bw.init(w);
+        knz_put_varint(bw, nbytes);
+        bw.put(st, 32); bw.put(s1, 32); bw.put(s2, 32); bw.put(s3, 32);
+        uint32_t* u1 = (uint32_t*)(slot + KNZ_ANS1_U1_OFF);
+        for (int i = 0; i < 8; i++) u1[i] = knz_bswap32(w[i]);
+        uint32_t* ubits = a.unit_bits + (size_t)slotId * KNZ_UNITS_PER_CHUNK;
+        uint32_t* usrc = a.unit_src + (size_t)slotId * KNZ_UNITS_PER_CHUNK;
+        ubits[1] = bw.pos;
+        ubits[2] = 8 * nbytes;
+        usrc[2] = (uint32_t)(KNZ_ANS1_PAY_OFF + KNZ_ANS1_PAY_CAP - 2 * flushed);
+    }
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Decoder
 struct Ans1DecArgs {

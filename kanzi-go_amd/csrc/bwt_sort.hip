@@ -27,7 +27,7 @@
 #define KNZ_SG_T 2048                     // largest group of the normal list = list entries per workgroup stretch
 #endif
 #ifndef KNZ_SG_THREADS
-#define KNZ_SG_THREADS 256
+#define KNZ_SG_THREADS 512
 #endif
 
 struct SsGeom {

@@ -418,6 +418,7 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             uint32_t GB = std::max<uint32_t>(1, slotsPerGroup / cpb);                   // whole blocks per group
             if (const char* e = getenv("KNZ_ANS1_GROUP_BLOCKS")) GB = std::max(1, atoi(e));   // (tests: several groups on small inputs)
             const uint32_t gs = GB * cpb;
+            const bool ans1EncPlain = getenv("KNZ_ANS1_ENC_PLAIN") != nullptr;   // (A/B and cross-check: the compiler's loop instead of the hand-written one)
             if (h->a1_freqs.reserve((size_t)gs * 65536 * 4) || h->a1_tab.reserve((size_t)gs * 65536 * 8) ||
                 h->a1_ctxhdr.reserve((size_t)gs * 256 * KNZ_ANS1_CTXHDR_BYTES + 64) || h->a1_ctxbits.reserve((size_t)gs * 256 * 4) ||
                 h->a1_ent.reserve((size_t)gs * KNZ_ANS1_ENT_STRIDE * 16))
@@ -435,6 +436,10 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
                 hipLaunchKernelGGL(knz_ans1_stats_kernel, dim3(ns * 256), dim3(64), 0, st, a);
                 hipLaunchKernelGGL(knz_ans1_merge_kernel, dim3(ns), dim3(256), 0, st, a);
                 KNZ_LAUNCH_PROBED(knz_ans1_expand_kernel, dim3(ns, 128), dim3(256), 0, st, a, h->a1_ent.as<uint4>());
+#ifndef KNZ_HIP_EMU
+                if (!ans1EncPlain) KNZ_LAUNCH_PROBED(knz_ans1_encode_asm_kernel, dim3(ns), dim3(64), 0, st, a, (const uint4*)h->a1_ent.as<uint4>());
+                else
+#endif
                 KNZ_LAUNCH_PROBED(knz_ans1_encode_kernel, dim3(ns), dim3(64), 0, st, a, (const uint4*)h->a1_ent.as<uint4>());
             }
         } else if (cfg.entropy == KNZ_E_ANS0) {

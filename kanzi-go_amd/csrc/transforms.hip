@@ -259,12 +259,16 @@ __global__ __launch_bounds__(256) void knz_sbrt_carry_kernel(XfArgs a) {
 }
 
 // 3) replay of the list update inside each segment from the reconstructed state (SBRT.go:155-172)
+#define KNZ_SBRT_TILE 2048
 template <int MODE>
 __global__ __launch_bounds__(64) void knz_sbrt_apply_kernel(XfArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[KNZ_SEG];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[KNZ_SEG];
+    // 4.5 KB of LDS per wave: the segment is walked in tiles of 2 KiB and the tables that rebuild the list alias the tile buffers (round 4: the
+    // whole 8 KiB segment + its output + the tables were 20 KB = 2 waves per SIMD; the replay is instruction issue of one wave per segment, so
+    // the waves a SIMD can interleave set its rate)
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[2 * KNZ_SBRT_TILE];
     __shared__ uint8_t s_s2r[256], s_r2s[256];
-    __shared__ int s_p[256], s_q[256], s_t[256];
+    uint8_t* s_in = s_buf; uint8_t* s_out = s_buf + KNZ_SBRT_TILE;
+    int* s_p = (int*)s_buf; int* s_q = s_p + 256; int* s_t = s_q + 256;
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x / a.segs_per_block, s = blockIdx.x % a.segs_per_block;
     if (!a.active[b]) return;
@@ -277,7 +281,6 @@ __global__ __launch_bounds__(64) void knz_sbrt_apply_kernel(XfArgs a) {
     uint8_t* dst = (uint8_t*)a.out_ptr[b];
     const int32_t* ca = a.seg_a + (size_t)blockIdx.x * 256;
     const int32_t* cb = a.seg_b + (size_t)blockIdx.x * 256;
-    for (uint32_t i = lane; i < cnt; i += 64) s_in[i] = src[lo + i];
     for (int d = lane; d < 256; d += 64) {
         const int last = ca[d], prev = cb[d];
         s_t[d] = last;                                            // -1 = never accessed
@@ -300,9 +303,15 @@ __global__ __launch_bounds__(64) void knz_sbrt_apply_kernel(XfArgs a) {
     wave_sync();
     SbrtWave<MODE> w;
     w.load(s_r2s, s_q, s_p, lane);
-    w.template run_tile<true>(s_in, s_out, cnt, (int)lo, lane);
-    wave_sync();
-    for (uint32_t i = lane; i < cnt; i += 64) dst[lo + i] = s_out[i];
+    for (uint32_t base = 0; base < cnt; base += KNZ_SBRT_TILE) {
+        const uint32_t tc = min((uint32_t)KNZ_SBRT_TILE, cnt - base);
+        wave_sync();                                              // (the tables, then the tile before, have been read)
+        for (uint32_t i = lane; i < tc; i += 64) s_in[i] = src[lo + base + i];
+        wave_sync();
+        w.template run_tile<true>(s_in, s_out, tc, (int)(lo + base), lane);
+        wave_sync();
+        for (uint32_t i = lane; i < tc; i += 64) dst[lo + base + i] = s_out[i];
+    }
 }
 
 // SBRT inverse: one chain per block (SBRT.go:204-223), tiles staged through LDS

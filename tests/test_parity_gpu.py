@@ -279,6 +279,15 @@ def test_utf_streams(be):
     P.check_utf_streams(be)
 
 
+def test_ans1_encode_forms(be, monkeypatch):
+    # the hand-written encode loop (default on the device) is what every other ANS1 test runs; here the compiler's loop (the emulator's only form)
+    monkeypatch.setenv("KNZ_ANS1_ENC_PLAIN", "1")
+    P.check_entropy_encode(be, "ANS1")
+    P.check_stream(be, "BWT+RANK+ZRLT", "ANS1", 1 << 20, 3 * (1 << 20) + 12345)
+    monkeypatch.delenv("KNZ_ANS1_ENC_PLAIN")
+    P.check_stream(be, "NONE", "ANS1", 1 << 22, (1 << 23) + 777)
+
+
 def test_ans1_encode_in_groups(be, monkeypatch):
     monkeypatch.setenv("KNZ_ANS1_GROUP_BLOCKS", "3")
     P.check_stream(be, "NONE", "ANS1", 1 << 16, 10 * (1 << 16) - 100)
