@@ -88,6 +88,10 @@ KERNEL_BYTES = {
     "knz_ans0_walk_decode_kernel": lambda n, m, c: c + m, "knz_ans0_decode_kernel": lambda n, m, c: c + m,
     "knz_gather_kernel": lambda n, m, c: 2 * c, "knz_utf_forward_kernel": lambda n, m, c: 2 * n, "knz_utf_inverse_kernel": lambda n, m, c: 2 * n,
     "knz_text_forward_chain_kernel": lambda n, m, c: 2 * n, "knz_text_inverse_chain_kernel": lambda n, m, c: 2 * n,
+    "knz_ans1_encode_asm_kernel": lambda n, m, c: m + c, "knz_ans1_decode_lds2_kernel": lambda n, m, c: c + m,
+    "knz_bwt_output_kernel": lambda n, m, c: 2 * n, "knz_zrlt_seg_kernel": lambda n, m, c: n, "knz_zrlti_seg_kernel": lambda n, m, c: n,
+    "knz_lzs_parse_kernel": lambda n, m, c: n + m, "knz_huf_decode_kernel": lambda n, m, c: c + m,
+    # the suffix sort's working kernels move (key, value) pairs, not stream bytes: their rows carry the counter bytes only
 }
 
 
@@ -192,6 +196,7 @@ def pmc_traffic(argv_child, timeout_s=900):
     import pmc_traffic as P
     tmp = tempfile.mkdtemp(prefix="knz_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     res = {}
+    times = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
@@ -202,6 +207,11 @@ def pmc_traffic(argv_child, timeout_s=900):
             if p.returncode != 0 or not dbs:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): {p.stderr[-300:]}"
             res[counter] = P.per_kernel(dbs[0], counter)
+            if counter == "FETCH_SIZE":
+                try:
+                    times = {kernel_key(k): v for k, v in P.per_kernel_time(dbs[0]).items()}
+                except Exception:   # noqa: BLE001
+                    times = {}
         out = {}
         for k in set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"]):
             f, w = res["FETCH_SIZE"].get(k, 0.0), res["WRITE_SIZE"].get(k, 0.0)
@@ -209,6 +219,9 @@ def pmc_traffic(argv_child, timeout_s=900):
             fac = FETCH_FACTOR.get(key, 2.0)
             o = out.setdefault(key, {"bytes": 0, "fetch_KB_raw": 0.0, "write_KB_raw": 0.0, "fetch_factor": fac})
             o["bytes"] += int(fac * f * 1024 + w * 1024); o["fetch_KB_raw"] += round(f, 1); o["write_KB_raw"] += round(w, 1)
+        for key, (avg_us, calls) in times.items():
+            if key in out:
+                out[key]["avg_us_under_counters"] = round(avg_us, 1); out[key]["launches"] = calls
         return out, ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per-launch averages; bytes = fetch_factor x "
                      "FETCH_SIZE + WRITE_SIZE (factor 2 = the guide's gfx950 correction for wide vector loads, 1 = calibrated scalar-cache reads)")
     except Exception as e:   # noqa: BLE001 (a profiler problem must not cost the bench line)
@@ -228,6 +241,7 @@ def main():
     ap.add_argument("--block-size", type=int, default=0, help="override the block size (debug)")
     ap.add_argument("--transform", default="", help="override the transform sequence of the config, e.g. LZP or BWT+SRT+ZRLT (debug)")
     ap.add_argument("--entropy", default="", help="override the entropy codec of the config (debug)")
+    ap.add_argument("--copies", type=int, default=1, help="corpus copies in the one stream (single-GPU saturation curve: MB/s against blocks in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes (roofline.traffic = null)")
@@ -276,7 +290,7 @@ def main():
         base = bench_corpus.s_silesia(base_size)
         corpus_name = "S-silesia"
     strong = args.scaling == "strong" or world == 1
-    size = base_size if strong else base_size * world       # strong: ONE job whatever N; weak: one corpus copy per GPU, one stream
+    size = (base_size if strong else base_size * world) * max(1, args.copies)   # strong: ONE job whatever N; weak: one corpus copy per GPU, one stream
     nblocks = (size + bs - 1) // bs
     lo_b, hi_b = kd.block_range(nblocks, rank, world)
     per = kd.max_blocks_per_rank(nblocks, world)
@@ -408,7 +422,7 @@ def main():
             "data": "synthetic" if not emu else "synthetic (EMULATOR TEST HARNESS on CPU: not a measurement)",
             "config": {"workload": (f"BASELINE.json configs[{cfg_idx}]" if args.config != "l5" else "kanzi-go preset -l 5 (README.md:79; not a BASELINE.json config)") +
                                    f": -t {transform} -e {entropy} -b {bs >> 20}m on {corpus_name} "
-                                   f"(one .knz stream of {size} B" + ("" if strong else f" = {world} copies of {base_size} B") + ", bench_corpus.py)",
+                                   f"(one .knz stream of {size} B" + ("" if size == base_size else f" = {size // base_size} copies of {base_size} B") + ", bench_corpus.py)",
                        "blocks": nblocks, "block_size": bs,
                        "parallelism": f"contiguous block ranges over {world} GPU(s) ({','.join(str(x) for x in counts)} blocks), segments gathered to rank 0"},
             "encode_MBps": round(size / 1e6 / (t_enc / K_), 2), "decode_MBps": round(size / 1e6 / (t_dec / K_), 2),
@@ -433,11 +447,35 @@ def main():
                 del kern_ms[k]
         if phase_ms:
             roof["phase_ms_per_step"] = {k: round(v / K_, 3) for k, v in sorted(phase_ms.items(), key=lambda kv: -kv[1])}
+        # bytes that entered each transform stage of the last encode batch (knz_last_counter 8 + i): a kernel is priced on what ITS stage saw
+        stage_in = {}
+        if not emu and transform != "NONE":
+            for i, tok in enumerate(transform.split("+")):
+                try:
+                    stage_in[tok] = int(codec.last_counter(8 + i)) or n_local
+                except Exception:   # noqa: BLE001
+                    stage_in[tok] = n_local
+
+        def n_for(kernel):
+            for prefixes, toks in ((("knz_bwt_", "knz_ss_", "knz_sg_", "knz_sl_"), ("BWT",)), (("knz_rank_", "knz_sbrt_", "knz_mtft_"), ("RANK", "MTFT", "SRT")),
+                                   (("knz_zrlt",), ("ZRLT",)), (("knz_lzp_",), ("LZP",)), (("knz_lz",), ("LZ", "LZX")), (("knz_text_",), ("TEXT",)),
+                                   (("knz_utf_",), ("UTF",)), (("knz_srt_",), ("SRT",))):
+                if kernel.startswith(prefixes):
+                    for t in toks:
+                        if t in stage_in:
+                            return stage_in[t]
+            return n_local
+
+        def alg_bytes(kernel):
+            f = KERNEL_BYTES.get(kernel)
+            return None if f is None else f(n_for(kernel), m_local, c_local)
+        if stage_in:
+            roof["stage_input_bytes"] = stage_in
         if kern_ms:
             dom = max(kern_ms, key=lambda k: kern_ms[k])
             avg_ms = kern_ms[dom] / max(kern_launches[dom], 1)
             launches_per_step = kern_launches[dom] / K_
-            alg = KERNEL_BYTES.get(dom, lambda n, m, c: n + c)(n_local, m_local, c_local) / max(launches_per_step, 1)
+            alg = (alg_bytes(dom) if alg_bytes(dom) is not None else n_local + c_local) / max(launches_per_step, 1)
             ach = alg / 1e9 / (avg_ms / 1e3) if avg_ms > 0 else 0.0
             roof.update({"kernel": dom, "achieved": round(ach, 3), "frac": round(ach / HBM_PEAK_GBS, 6),
                          "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
@@ -448,7 +486,7 @@ def main():
                 # (fpaq: one 10^9-byte step is ~35 s of two serial chains per block; its counter passes run a single step)
                 child = ["--config", args.config, "--steps", "1" if args.config == "fpaq" else "2", "--warmup", "0" if args.config == "fpaq" else "1",
                          "--no-cpu-baseline", "--no-verify", "--no-pmc", "--no-host-hook"]
-                for flag, val in (("--size", args.size), ("--block-size", args.block_size)):
+                for flag, val in (("--size", args.size), ("--block-size", args.block_size), ("--copies", args.copies if args.copies > 1 else 0)):
                     if val:
                         child += [flag, str(val)]
                 for flag, val in (("--transform", args.transform), ("--entropy", args.entropy)):
@@ -460,6 +498,31 @@ def main():
                     roof["traffic"] = int(tr[dom]["bytes"])
                     roof["traffic_over_algorithmic"] = round(tr[dom]["bytes"] / max(alg, 1), 3)
                     roof["traffic_counters"] = {k: tr[dom][k] for k in ("fetch_KB_raw", "write_KB_raw", "fetch_factor")}
+                if tr is not None:
+                    # every kernel of the step that moves at least 1 MB per launch or runs for 50 us: time (HIP events of this run where the launch is
+                    # probed, else the trace of the counter pass), algorithmic bytes of ONE launch (the stage's bytes / launches per step),
+                    # counter bytes per launch, and what the counters say about the HBM rate while the kernel runs
+                    table = []
+                    steps_child = 1 if args.config == "fpaq" else 3           # (the child runs warm-up + steps launches of everything)
+                    for k, t in tr.items():
+                        if not k.startswith("knz_"):
+                            continue
+                        lps = kern_launches[k] / K_ if k in kern_launches else t.get("launches", 0) / steps_child
+                        ms = kern_ms[k] / max(kern_launches[k], 1) if k in kern_ms else t.get("avg_us_under_counters", 0.0) / 1e3
+                        if ms <= 0 or (t["bytes"] < 1e6 and ms < 0.05):
+                            continue
+                        ab = alg_bytes(k)
+                        row = {"kernel": k, "avg_launch_ms": round(ms, 4), "launches_per_step": round(lps, 2), "ms_per_step": round(ms * lps, 3),
+                               "timing": "events" if k in kern_ms else "trace of the counter pass",
+                               "counter_bytes_per_launch": int(t["bytes"]), "counter_GBps": round(t["bytes"] / 1e9 / (ms / 1e3), 1),
+                               "counter_frac_of_peak": round(t["bytes"] / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4)}
+                        if ab is not None and lps > 0:
+                            row["algorithmic_bytes_per_launch"] = int(ab / lps)
+                            row["algorithmic_GBps"] = round(ab / lps / 1e9 / (ms / 1e3), 1)
+                            row["frac"] = round(ab / lps / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 6)
+                            row["traffic_over_algorithmic"] = round(t["bytes"] / max(ab / lps, 1), 3)
+                        table.append(row)
+                    roof["per_kernel"] = sorted(table, key=lambda r: -r["ms_per_step"])[:40]
         out["roofline"] = roof
         if rank_kernel_max:
             out["kernel_ms_per_step_max_over_ranks"] = {k: round(v / K_, 3) for k, v in sorted(rank_kernel_max.items(), key=lambda kv: -kv[1])[:10]}

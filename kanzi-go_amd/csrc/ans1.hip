@@ -699,6 +699,7 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_kernel(Ans1DecArgs a) {
     }
 }
 
+#ifdef KNZ_MEASURE                       // the round-2 loop of the LDS decoder: kept for A/B measurements only (-DKNZ_MEASURE, KNZ_ANS1_LDS1)
 // LDS-resident decoder: one wave per chunk. The 2 MiB slot table of the decoder above costs one trip to the MALL per step
 // (~0.85 us: 64 K of them do not fit any cache level that is close); here the chunk keeps only the cumulated frequencies of its
 // 256 contexts in LDS (257 x u16 each, 129 KiB of the CU's 160 KiB) and finds the symbol of a slot with two 16-way searches:
@@ -772,6 +773,7 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds_kernel(Ans1DecArgs a, 
             dst[i] = (uint8_t)(knz_fetch32(a.stream, (int64_t)(paybit + 16ull * cnt + 8ull * (i - end4)), (int64_t)limit) >> 24);
     }
 }
+#endif
 
 // The same decoder with the per-step bookkeeping taken off the chain (round 3). The loop above spends 75 instructions per step of
 // 4 symbols, of which the two 16-way searches and the state update are ~40: the rest was (a) ten scalar instructions that pull the

@@ -238,10 +238,11 @@ extern "C" int knz_last_kernel_times(void* handle, char* names, int names_cap, f
 
 extern "C" int knz_last_counter(void* handle, int id, uint64_t* value) {
     Handle* h = (Handle*)handle;
-    if (!h || !value || id < KNZ_COUNTER_HUF_SERIAL_CHUNKS || id > KNZ_COUNTER_LZ_FWD_ROUNDS) return KNZ_ERR_INVALID_PARAM;
+    if (!h || !value || id < KNZ_COUNTER_HUF_SERIAL_CHUNKS || id > KNZ_COUNTER_STAGE_BYTES0 + 7 || (id > KNZ_COUNTER_LZ_FWD_ROUNDS && id < KNZ_COUNTER_STAGE_BYTES0)) return KNZ_ERR_INVALID_PARAM;
     DeviceGuard dg(h);
     *value = 0;
     if (id == KNZ_COUNTER_POST_TRANSFORM_BYTES) { *value = h->post_bytes; return KNZ_OK; }
+    if (id >= KNZ_COUNTER_STAGE_BYTES0) { *value = h->stage_bytes[id - KNZ_COUNTER_STAGE_BYTES0]; return KNZ_OK; }
     if (id == KNZ_COUNTER_TEXT_CHAIN_BLOCKS) {
         uint32_t v = 0;
         if (h->text_cnt.p && hipMemcpy(&v, h->text_cnt.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return KNZ_ERR_UNKNOWN;
@@ -416,9 +417,9 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             const size_t perSlot = (size_t)65536 * 12 + (size_t)256 * KNZ_ANS1_CTXHDR_BYTES + 1024 + KNZ_ANS1_ENT_STRIDE * 16;
             const uint32_t slotsPerGroup = (uint32_t)std::max<size_t>(cpb, std::min<size_t>((size_t)nblocks * cpb, ((size_t)8 << 30) / perSlot));
             uint32_t GB = std::max<uint32_t>(1, slotsPerGroup / cpb);                   // whole blocks per group
-            if (const char* e = getenv("KNZ_ANS1_GROUP_BLOCKS")) GB = std::max(1, atoi(e));   // (tests: several groups on small inputs)
+            if (const char* e = knz_test_switch("KNZ_ANS1_GROUP_BLOCKS")) GB = std::max(1, atoi(e));   // (tests: several groups on small inputs)
             const uint32_t gs = GB * cpb;
-            const bool ans1EncPlain = getenv("KNZ_ANS1_ENC_PLAIN") != nullptr;   // (A/B and cross-check: the compiler's loop instead of the hand-written one)
+            const bool ans1EncPlain = knz_test_switch("KNZ_ANS1_ENC_PLAIN") != nullptr;   // (A/B and cross-check: the compiler's loop instead of the hand-written one)
             if (h->a1_freqs.reserve((size_t)gs * 65536 * 4) || h->a1_tab.reserve((size_t)gs * 65536 * 8) ||
                 h->a1_ctxhdr.reserve((size_t)gs * 256 * KNZ_ANS1_CTXHDR_BYTES + 64) || h->a1_ctxbits.reserve((size_t)gs * 256 * 4) ||
                 h->a1_ent.reserve((size_t)gs * KNZ_ANS1_ENT_STRIDE * 16))
@@ -511,6 +512,7 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     eb.total_bits = res[0];
     h->post_bytes = 0;
     for (uint32_t b = 0; b < nblocks; b++) h->post_bytes += lenv[b];
+    for (int i = 0; i < 8; i++) h->stage_bytes[i] = (nblocks && cfg.transform != 0) ? ((const uint64_t*)((const uint8_t*)h->pinned + 3072))[i] : 0;
     return KNZ_OK;
 }
 

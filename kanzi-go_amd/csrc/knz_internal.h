@@ -6,6 +6,17 @@
 #include <string>
 #include <vector>
 
+// The library reads the environment in exactly two places. knz_test_switch: forms the test suites select (exact fall-backs, A/B of the
+// hand-written loops, small geometry on small inputs). knz_measure_switch: measurement variants and diagnostics, compiled in only with
+// -DKNZ_MEASURE (the shipped library carries the default form of every kernel plus the fall-backs the tests need, nothing else).
+#include <cstdlib>
+static inline const char* knz_test_switch(const char* name) { return getenv(name); }
+#ifdef KNZ_MEASURE
+static inline const char* knz_measure_switch(const char* name) { return getenv(name); }
+#else
+static inline const char* knz_measure_switch(const char*) { return nullptr; }
+#endif
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -26,6 +37,8 @@ struct Handle {
     knz_cfg cfg;
     KernelProbe probes[KNZ_MAX_PROBES];
     int nprobes = 0;
+    uint64_t stage_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // bytes that entered transform stage i of the last encode batch (knz_last_counter 8 + i)
+    DevBuf stage_sum;                 // their device-side sums
     uint64_t post_bytes = 0;          // bytes behind the transform sequence of the last encode batch (entropy coder input)
     int device = 0;
     hipStream_t stream = nullptr;

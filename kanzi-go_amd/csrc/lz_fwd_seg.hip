@@ -340,7 +340,13 @@ __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_
         const uint32_t* X = g.exit_ + 5 * si;
         for (int k = 0; k < 5; k++) E[k] = cur[k];
         const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
-        if (cur[0] >= segEnd) continue;                                       // nothing to parse here: the state passes through
+        if (cur[0] >= segEnd) {                                               // nothing to parse here: the state passes through
+            // A trace this segment recorded while it still had something to parse is dead now, but its bits may sit in the maps (its stretch was
+            // carried while it was live, and the stretch of the predecessor that now runs over it is carried from then on): forget the trace and
+            // have every live segment run, so that the next generation of the maps is written by live traces only.
+            if (g.used[5 * si] != KNZ_LZS_NEVER) { g.used[5 * si] = KNZ_LZS_NEVER; changed = true; }
+            continue;
+        }
         const bool same = U[0] == cur[0] && U[1] == cur[1] && U[2] == cur[2] && U[3] == cur[3] && U[4] == cur[4];
         if (!same) changed = true;
         else if (g.ntok[si] == KNZ_LZS_NEVER) overflow = true;

@@ -150,7 +150,7 @@ def test_text_stream_through_foreign_handle(be):
 
 def test_lz_forward_forms(be, monkeypatch):
     """Segment-parallel LZ parse (fixed point over segment entry states and hole maps, lz_fwd_seg.hip) against the two one-wave forms."""
-    P.check_lz_forward_forms(be, monkeypatch, segs=(256,))
+    P.check_lz_forward_forms(be, monkeypatch, segs=(256, 512))
 
 
 def test_lz_streams_small_segments(be, monkeypatch):

@@ -15,6 +15,12 @@ def per_kernel(path, counter):
     return {name.split("(")[0]: total / max(n, 1) for name, total, n in rows}
 
 
+def per_kernel_time(path):
+    """{kernel: (average launch duration in us, launches)} from the kernel trace of the same database (view top_kernels)."""
+    cur = sqlite3.connect(path).cursor()
+    return {name.split("(")[0]: (avg / 1e3 if avg > 1e5 else avg, calls) for name, calls, avg in cur.execute("select name,total_calls,average from top_kernels")}
+
+
 def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) -- python bench.py --steps 2 "
