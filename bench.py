@@ -83,7 +83,8 @@ KERNEL_BYTES = {
     "knz_lzp_forward_kernel": lambda n, m, c: n + m, "knz_lzp_inverse_kernel": lambda n, m, c: m + n,
     "knz_srt_inverse_kernel": lambda n, m, c: 2 * n,
     "knz_huf_hist_kernel": lambda n, m, c: m, "knz_huf_lengths_kernel": lambda n, m, c: 768 * ((m + 16383) // 16384),
-    "knz_huf_encode_kernel": lambda n, m, c: m + c, "knz_huf_walk_decode_kernel": lambda n, m, c: c + m,
+    "knz_huf_encode_kernel": lambda n, m, c: m + c, "knz_huf_encode_kernel<false>": lambda n, m, c: m + c,
+    "knz_huf_encode_kernel<true>": lambda n, m, c: 2048 * ((m + 16383) // 16384), "knz_huf_walk_decode_kernel": lambda n, m, c: c + m,
     "knz_huf_decode_par_kernel": lambda n, m, c: c + m, "knz_ans0_encode_kernel": lambda n, m, c: m + c,
     "knz_ans0_walk_decode_kernel": lambda n, m, c: c + m, "knz_ans0_decode_kernel": lambda n, m, c: c + m,
     "knz_gather_kernel": lambda n, m, c: 2 * c, "knz_utf_forward_kernel": lambda n, m, c: 2 * n, "knz_utf_inverse_kernel": lambda n, m, c: 2 * n,
@@ -104,8 +105,39 @@ FETCH_FACTOR = {"knz_rank_inverse_chain_kernel": 1.0}
 
 
 def kernel_key(name):
-    m = re.search(r"knz_\w+", name)
-    return m.group(0) if m else name
+    m = re.search(r"knz_\w+(?:<(?:true|false)>)?", name)        # (the bool of a template is part of the name: sizes pass / encoder of the Huffman kernel)
+    if not m:
+        return name
+    k = m.group(0)
+    return k if k.startswith("knz_huf_encode_kernel") else k.split("<")[0]
+
+
+def fpaq_stage_comparison(base, nblocks, enc_ms, dec_ms, m_bytes):
+    """FPAQ is one serial chain per block on either side: the honest comparison is chain against chain. The oracle's FPAQ stage alone
+    (knzo_entropy_encode / decode) on min(cores, blocks) slices of 4 MiB side by side, one per host thread, against the device kernels'
+    rate per chain (the kernels' time is that of the longest chain: every block of the stream in flight at once)."""
+    import concurrent.futures as cf
+    import oracle_lib as O
+    threads = max(1, min(os.cpu_count() or 1, nblocks))
+    slices = [np.ascontiguousarray(base[(i * (4 << 20)) % max(len(base) - (4 << 20), 1):][: 4 << 20]) for i in range(threads)]
+    O.lib()
+    with cf.ThreadPoolExecutor(threads) as ex:                        # (ctypes releases the GIL inside the calls)
+        t0 = time.perf_counter()
+        enc = list(ex.map(lambda a: O.entropy_encode(O.E_FPAQ, a), slices))
+        t1 = time.perf_counter()
+        list(ex.map(lambda pr: O.entropy_decode(O.E_FPAQ, pr[0][0], len(pr[1])), zip(enc, slices)))
+        t2 = time.perf_counter()
+    per = (4 << 20) / 1e6
+    cpu_enc, cpu_dec = per / (t1 - t0), per / (t2 - t1)               # MB/s of one thread while all `threads` run
+    gpu_enc = m_bytes / nblocks / 1e6 / (enc_ms / 1e3) if enc_ms else 0.0
+    gpu_dec = m_bytes / nblocks / 1e6 / (dec_ms / 1e3) if dec_ms else 0.0
+    return {"gpu_MBps_per_chain": {"encode": round(gpu_enc, 2), "decode": round(gpu_dec, 2)},
+            "cpu_port_MBps_per_thread": {"encode": round(cpu_enc, 2), "decode": round(cpu_dec, 2)}, "cpu_threads_side_by_side": threads,
+            "chains_in_flight_on_the_gpu": nblocks,
+            "gpu_slower_than_host_per_chain": bool(gpu_enc < cpu_enc or gpu_dec < cpu_dec),
+            "gpu_chains_needed_to_match_the_host_threads": {"encode": int(np.ceil(threads * cpu_enc / max(gpu_enc, 1e-9))), "decode": int(np.ceil(threads * cpu_dec / max(gpu_dec, 1e-9)))},
+            "what": "FPAQ stage alone, 4 MiB slices of the corpus, one per host thread, against the device kernels (whole blocks behind BWT+RANK+ZRLT, time of the "
+                    "longest chain). The device loses per chain (a lone wave issues one instruction per ~2.5 ns); it only wins on blocks in flight"}
 
 
 def load_pkg():
@@ -540,6 +572,11 @@ def main():
                 out["fallback_counters_last_batch"] = fb
         if entropy == "FPAQ":
             out["chain_bound"] = True          # one binary arithmetic-coding chain per block by format (DESIGN.md "FPAQ"): flat in the block count
+            if world == 1 and not emu and not args.no_cpu_baseline:
+                try:
+                    out["fpaq_stage"] = fpaq_stage_comparison(base, nblocks, kern_ms.get("knz_fpaq_encode_kernel", 0.0) / K_, kern_ms.get("knz_fpaq_decode_kernel", 0.0) / K_, m_local)
+                except Exception as e:   # noqa: BLE001
+                    out["fpaq_stage"] = {"error": str(e)}
         if entropy == "HUFFMAN" and not emu:
             # the single-launch walk + decode hands a chunk to the serial kernel when a decoder gives up waiting for its walker:
             # 0 for every stream a kanzi encoder wrote unless the dispatch order went against the kernel

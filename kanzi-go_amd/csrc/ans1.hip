@@ -15,6 +15,7 @@
 #define KNZ_ANS1_CHUNK (4u << 20)
 #define KNZ_ANS1_LR 11
 #define KNZ_ANS1_SCALE 2048
+#define KNZ_ANS1_LDS_MAX_CHUNKS 1280u                     // batches up to this many chunks decode from LDS (knz_host_api.inc)
 #define KNZ_ANS1_CTXHDR_BYTES 448                     // 3454 bits worst case per context header
 #define KNZ_ANS1_U0_CAP (256 * KNZ_ANS1_CTXHDR_BYTES + 64)
 #define KNZ_ANS1_U1_OFF KNZ_ANS1_U0_CAP

@@ -116,6 +116,27 @@ __device__ __forceinline__ void knz_histogram_256t(const uint8_t* src, uint32_t 
     }
 }
 
+// One wave, 4 histograms (picked by lane & 3; hist is [4][256], zeroed by the caller): the bytes of one fragment of a Huffman chunk
+__device__ __forceinline__ void knz_histogram_64t_x4(const uint8_t* src, uint32_t n, uint32_t (*hist)[256], int lane) {
+    uint32_t* h = hist[lane & 3];
+    if ((((uintptr_t)src) & 15) == 0) {
+        const uint32_t nvec = n >> 4;
+        const uint4* v = (const uint4*)src;
+        for (uint32_t i = lane; i < nvec; i += 64) {
+            uint4 x = v[i];
+            uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                atomicAdd(&h[w[j] & 255], 1u); atomicAdd(&h[(w[j] >> 8) & 255], 1u);
+                atomicAdd(&h[(w[j] >> 16) & 255], 1u); atomicAdd(&h[w[j] >> 24], 1u);
+            }
+        }
+        for (uint32_t i = (nvec << 4) + lane; i < n; i += 64) atomicAdd(&h[src[i]], 1u);
+    } else {
+        for (uint32_t i = lane; i < n; i += 64) atomicAdd(&h[src[i]], 1u);
+    }
+}
+
 // Same with 16 histograms (4 per wave, picked by lane & 3): frequent symbols (spaces, zeros) make the lanes of a wave collide
 // on one LDS counter, 4 counters per wave cut that serialisation by 4. hist is [16][256], zeroed by the caller.
 __device__ __forceinline__ void knz_histogram_256t_x16(const uint8_t* src, uint32_t n, uint32_t (*hist)[256], int tid) {

@@ -188,7 +188,28 @@ struct HufEncArgs {
     uint16_t* st_count;           // [chunks] alphabet size (0: chunk absent or stored raw)
     uint8_t* st_maxlen;           // [chunks] longest code length
     uint32_t nchunks;
+    // Encode at the final bit positions (round 4): the histogram kernel also leaves the symbol counts of each of the chunk's four fragments,
+    // knz_huf_encode_kernel<true> turns them into the exact bit count of every unit WITHOUT encoding (sum of count x code length, the header built
+    // as it will be), the layout kernels scan those, and knz_huf_encode_kernel<false> then writes its units straight to where the stream has them
+    // (dst_words != null): the compressed bytes no longer make a round trip through the scratch slots and knz_gather_kernel.
+    uint16_t* st_fhist;           // [chunks][4][256] symbol counts per fragment (null: not wanted)
+    uint32_t* dst_words;          // the stream (null: units go to the scratch slots)
+    const uint64_t* chunk_rel; const uint64_t* blk_dst_bit; const uint64_t* total_bits;
 };
+
+// 32 bits of an MSB-first bit string held as 32-bit words in LDS, from bit `off` of the string (negative: the string starts inside the word);
+// bits at or behind `len` read as zero (the words behind the string are not touched)
+__device__ __forceinline__ uint32_t knz_lds_fetch32(const uint32_t* w, int64_t off, int64_t len) {
+    if (off <= -32 || off >= len || len <= 0) return 0;
+    uint32_t lead = 0;
+    if (off < 0) { lead = (uint32_t)(-off); off = 0; }
+    const uint32_t i = (uint32_t)(off >> 5), sh = (uint32_t)off & 31;
+    uint32_t v = w[i] << sh;
+    if (sh && (int64_t)(i + 1) * 32 < len) v |= w[i + 1] >> (32 - sh);
+    const int64_t avail = len - off;
+    if (avail < 32) v &= 0xFFFFFFFFu << (32 - (uint32_t)avail);
+    return v >> lead;
+}
 
 __device__ __forceinline__ size_t knz_huf_st(uint32_t chunk, uint32_t i) { return ((size_t)(chunk >> 6) * 256 + i) * 64 + (chunk & 63); }
 
@@ -211,11 +232,19 @@ __global__ __launch_bounds__(256) void knz_huf_hist_kernel(HufEncArgs a) {
     const uint8_t* src = a.data + a.blk_off[b] + (size_t)k * KNZ_HUF_CHUNK;
     for (int i = tid; i < 16 * 256; i += 256) (&s_hist[0][0])[i] = 0;
     __syncthreads();
-    knz_histogram_256t_x16(src, n, s_hist, tid);
+    // wave j counts fragment j = symbols [j * F, (j + 1) * F), F = n / 4 (encodeChunk :435-492), into its own four histograms: their sum is the
+    // fragment's symbol count (the sizes pass needs it), the sum over the waves plus the n & 3 tail bytes the chunk's
+    const uint32_t F = n >> 2;
+    knz_histogram_64t_x4(src + (size_t)(tid >> 6) * F, F, s_hist + 4 * (tid >> 6), tid & 63);
     __syncthreads();
     uint32_t myFreq = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) myFreq += s_hist[i][tid];
+    for (int j = 0; j < 4; j++) {
+        const uint32_t fj = s_hist[4 * j][tid] + s_hist[4 * j + 1][tid] + s_hist[4 * j + 2][tid] + s_hist[4 * j + 3][tid];
+        if (a.st_fhist) a.st_fhist[((size_t)blockIdx.x * 4 + j) * 256 + tid] = (uint16_t)fj;      // <= 4096
+        myFreq += fj;
+    }
+    for (uint32_t i = 4 * F; i < n; i++) myFreq += src[i] == (uint32_t)tid ? 1u : 0u;
     const uint32_t myKey = myFreq ? ((myFreq << 8) | (uint32_t)tid) : 0xFFFFFFFFu;
     s_key[tid] = myKey;
     __syncthreads();
@@ -304,6 +333,10 @@ __global__ __launch_bounds__(64) void knz_huf_lengths_kernel(HufEncArgs a) {
 }
 
 // ---- kernel 3: canonical codes, the 4 fragments, the header ------------------------------------------------------------------
+// SIZES: everything but the encoding itself: code lengths behind the limiter, the header as it will be written, the fragments' bit counts from
+// the per-fragment symbol counts -> unit_bits (what the layout scans need). !SIZES: the encoder; with a.dst_words it places its units at
+// their final bit positions, else into the chunk's scratch slot.
+template <bool SIZES>
 __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
     __shared__ uint32_t s_out[4][KNZ_FRAG_BYTES / 4];
     __shared__ uint32_t s_freq[256];
@@ -325,18 +358,20 @@ __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
     const uint32_t b = blockIdx.x / cpb, k = blockIdx.x % cpb;
     const uint32_t postLen = a.blk_len[b];
     uint32_t* ubits = a.unit_bits + (size_t)blockIdx.x * KNZ_UNITS_PER_CHUNK;
-    if (tid < KNZ_UNITS_PER_CHUNK)
+    const bool direct = !SIZES && a.dst_words != nullptr;
+    if (tid < KNZ_UNITS_PER_CHUNK && !direct)
         a.unit_src[(size_t)blockIdx.x * KNZ_UNITS_PER_CHUNK + tid] = tid == 0 ? 0u : (uint32_t)(KNZ_U0_BYTES + (tid - 1) * KNZ_FRAG_BYTES);
     if ((uint64_t)k * KNZ_HUF_CHUNK >= postLen) {
-        if (tid < KNZ_UNITS_PER_CHUNK) ubits[tid] = 0;
+        if (tid < KNZ_UNITS_PER_CHUNK && !direct) ubits[tid] = 0;
         return;
     }
+    if (direct && a.total_bits[1] != 0) return;                          // the stream does not fit its buffer: nothing is written
     const uint32_t n = min((uint32_t)KNZ_HUF_CHUNK, postLen - k * KNZ_HUF_CHUNK);
     const uint8_t* src = a.data + a.blk_off[b] + (size_t)k * KNZ_HUF_CHUNK;
     uint8_t* slot = a.scratch + (size_t)blockIdx.x * KNZ_CHUNK_STRIDE;
 
     // ---- zero LDS staging ---------------------------------------------------------------------------------
-    for (int i = tid; i < 4 * (KNZ_FRAG_BYTES / 4); i += 256) (&s_out[0][0])[i] = 0;
+    if (!SIZES) for (int i = tid; i < 4 * (KNZ_FRAG_BYTES / 4); i += 256) (&s_out[0][0])[i] = 0;   // (the sizes pass stages no fragment)
     if (tid < KNZ_U0_BYTES / 4) s_hdr[tid] = 0;
     s_freq[tid] = 0; s_len[tid] = 0; s_code[tid] = 0;
     if (tid == 0) { s_panic = 0; s_fallback = 0; }
@@ -345,7 +380,16 @@ __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
     if (n < 32) { // HuffmanCodec.go:411-413: raw bytes
         if (tid < (int)n) atomicOr(&s_hdr[tid >> 2], (uint32_t)src[tid] << (24 - 8 * (tid & 3)));
         __syncthreads();
-        if (tid < 8) ((uint32_t*)slot)[tid] = knz_bswap32(s_hdr[tid]);
+        if (direct) {
+            const uint64_t p0 = a.blk_dst_bit[b] + a.chunk_rel[blockIdx.x], p1 = p0 + 8ull * n;
+            const uint64_t w0 = p0 >> 5, w1 = (p1 - 1) >> 5;
+            for (uint64_t w = w0 + tid; w <= w1; w += 256) {
+                const uint32_t sw = knz_bswap32(knz_lds_fetch32(s_hdr, (int64_t)(w << 5) - (int64_t)p0, 8 * (int64_t)n));
+                if (w == w0 || w == w1) atomicOr(&a.dst_words[w], sw); else a.dst_words[w] = sw;
+            }
+            return;
+        }
+        if (!SIZES && tid < 8) ((uint32_t*)slot)[tid] = knz_bswap32(s_hdr[tid]);
         if (tid < KNZ_UNITS_PER_CHUNK) ubits[tid] = (tid == 0) ? 8u * n : 0u;
         return;
     }
@@ -388,7 +432,7 @@ __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
     }
     if (s_panic) { // Go would panic (index out of range) -> encodingTask recovers it as ERR_PROCESS_BLOCK
         if (tid == 0) a.blk_status[b] = 13;
-        if (tid < KNZ_UNITS_PER_CHUNK) ubits[tid] = 0;
+        if (tid < KNZ_UNITS_PER_CHUNK && !direct) ubits[tid] = 0;
         return;
     }
 
@@ -419,7 +463,18 @@ __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
 
     // ---- fragments: wave j encodes symbols [j*F, (j+1)*F) (encodeChunk :435-492) -------------------------------
     const uint32_t F = n >> 2;
-    if (count > 1) {
+    if (SIZES) {
+        // bit count of fragment `wave` = sum over the symbols of (count in the fragment) x (code length)
+        uint32_t nb = 0;
+        if (count > 1) {
+            const uint16_t* fh = a.st_fhist + ((size_t)blockIdx.x * 4 + wave) * 256;
+#pragma unroll
+            for (int q = 0; q < 4; q++) nb += (uint32_t)fh[64 * q + lane] * (uint32_t)(s_code[64 * q + lane] >> 12);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) nb += wave_shfl(nb, lane ^ d);
+        }
+        if (lane == 0) s_fragbits[wave] = nb;
+    } else if (count > 1) {
         const uint32_t S = (F + 63) >> 6;                 // symbols per lane
         const uint32_t first = min(F, (uint32_t)lane * S);
         const uint32_t last = min(F, first + S);
@@ -518,17 +573,56 @@ __global__ __launch_bounds__(256) void knz_huf_encode_kernel(HufEncArgs a) {
     }
     // tail bytes go behind fragment 3 (encodeChunk :505-510)
     if (tid == 64 && count > 1) {
-        KnzBitWriter bw;
-        bw.init(s_out[3]);
-        bw.pos = s_fragbits[3];
-        for (uint32_t i = 4 * F; i < n; i++) bw.put(src[i], 8);
-        s_data[1] = bw.pos;
+        if (SIZES) s_data[1] = s_fragbits[3] + 8 * (n - 4 * F);
+        else {
+            KnzBitWriter bw;
+            bw.init(s_out[3]);
+            bw.pos = s_fragbits[3];
+            for (uint32_t i = 4 * F; i < n; i++) bw.put(src[i], 8);
+            s_data[1] = bw.pos;
+        }
     }
     __syncthreads();
 
-    // ---- copy the units to the scratch slot (byte-swapped BE words) -------------------------------------------------
     const uint32_t u0bits = s_data[0];
     const uint32_t u4bits = count > 1 ? s_data[1] : 0;
+    if (SIZES) {
+        if (tid == 0) {
+            ubits[0] = u0bits;
+            ubits[1] = s_fragbits[0]; ubits[2] = s_fragbits[1]; ubits[3] = s_fragbits[2];
+            ubits[4] = u4bits;
+        }
+        return;
+    }
+    if (direct) {
+        // ---- the units go straight to their final bit positions: every thread owns destination words and ORs in what each of the five units
+        //      contributes (the funnel shift of knz_gather_kernel, fed from LDS); only the chunk's first and last word are shared with neighbours
+        //      (zeroed by knz_layout_stream_kernel, which has run: it only needs the bit counts) ---------------------------------------------
+        uint64_t ustart[KNZ_UNITS_PER_CHUNK + 1];
+        ustart[0] = a.blk_dst_bit[b] + a.chunk_rel[blockIdx.x];
+        ustart[1] = ustart[0] + u0bits; ustart[2] = ustart[1] + s_fragbits[0]; ustart[3] = ustart[2] + s_fragbits[1];
+        ustart[4] = ustart[3] + s_fragbits[2]; ustart[5] = ustart[4] + u4bits;
+        if (tid == 0 && (ubits[0] != u0bits || ubits[1] != s_fragbits[0] || ubits[2] != s_fragbits[1] || ubits[3] != s_fragbits[2] || ubits[4] != u4bits))
+            a.blk_status[b] = KNZ_ERR_UNKNOWN;                             // the sizes pass and the encoder disagree: must not happen
+        const uint64_t p0 = ustart[0], p1 = ustart[KNZ_UNITS_PER_CHUNK];
+        if (p1 == p0) return;
+        const uint64_t w0 = p0 >> 5, w1 = (p1 - 1) >> 5;
+        for (uint64_t w = w0 + tid; w <= w1; w += 256) {
+            const int64_t wbit = (int64_t)(w << 5);
+            uint32_t v = knz_lds_fetch32(s_hdr, wbit - (int64_t)ustart[0], (int64_t)u0bits);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int64_t us = (int64_t)ustart[j + 1], ue = (int64_t)ustart[j + 2];
+                if (ue <= wbit || us >= wbit + 32 || ue == us) continue;
+                v |= knz_lds_fetch32(s_out[j], wbit - us, ue - us);
+            }
+            const uint32_t sw = knz_bswap32(v);
+            if (w == w0 || w == w1) atomicOr(&a.dst_words[w], sw);
+            else a.dst_words[w] = sw;
+        }
+        return;
+    }
+    // ---- copy the units to the scratch slot (byte-swapped BE words) -------------------------------------------------
     {
         uint32_t* g = (uint32_t*)slot;
         for (uint32_t i = tid; i < ((u0bits + 31) >> 5); i += 256) g[i] = knz_bswap32(s_hdr[i]);

@@ -359,6 +359,8 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
         hipLaunchKernelGGL(knz_enc_tables_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, st, ta);
     }
     const bool skipOpt = (cfg.flags & KNZ_FLAG_SKIP_BLOCKS) != 0 && !eb.payload_only && nblocks != 0;
+    bool hufDirect = false;                                              // Huffman units encoded at their final bit positions (below)
+    HufEncArgs hufArgs;
     if (skipOpt) {                                                       // -s: incompressible blocks become copy blocks (:778-800)
         SkipArgs ka;
         ka.nblocks = nblocks; ka.blk_off = h->blk_off.as<uint64_t>(); ka.blk_len = h->blk_len.as<uint32_t>();
@@ -400,9 +402,18 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
                     return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
                 a.st_freq = h->huf_stfreq.as<uint16_t>(); a.st_sym = h->huf_stsym.as<uint8_t>(); a.st_len = h->huf_stlen.as<uint8_t>();
                 a.st_count = h->huf_stcnt.as<uint16_t>(); a.st_maxlen = h->huf_stmax.as<uint8_t>(); a.nchunks = nc;
+                // The units are encoded at their final bit positions (sizes pass -> layout scans -> encoder, further down) unless copy blocks of -s
+                // have to overwrite chunks afterwards or the test switch asks for the scratch-slot form (units to slots, knz_gather_kernel).
+                hufDirect = !skipOpt && knz_test_switch("KNZ_HUF_SCRATCH") == nullptr;
+                a.st_fhist = nullptr; a.dst_words = nullptr; a.chunk_rel = nullptr; a.blk_dst_bit = nullptr; a.total_bits = nullptr;
+                if (hufDirect) {
+                    if (h->huf_fhist.reserve((size_t)nc * 4 * 256 * 2 + 64)) return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
+                    a.st_fhist = h->huf_fhist.as<uint16_t>();
+                }
                 KNZ_LAUNCH_PROBED(knz_huf_hist_kernel, dim3(nc), dim3(256), 0, st, a);
                 KNZ_LAUNCH_PROBED(knz_huf_lengths_kernel, dim3(groups), dim3(64), 0, st, a);
-                KNZ_LAUNCH_PROBED(knz_huf_encode_kernel, dim3(nc), dim3(256), 0, st, a);
+                if (hufDirect) { KNZ_LAUNCH_PROBED(knz_huf_encode_kernel<true>, dim3(nc), dim3(256), 0, st, a); hufArgs = a; }
+                else KNZ_LAUNCH_PROBED(knz_huf_encode_kernel<false>, dim3(nc), dim3(256), 0, st, a);
             }
             else hipLaunchKernelGGL(knz_raw_units_kernel, dim3(nblocks * cpb), dim3(256), 0, st, a);
         } else if (cfg.entropy == KNZ_E_FPAQ) {
@@ -413,9 +424,9 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             KNZ_LAUNCH_PROBED(knz_fpaq_encode_kernel, dim3(nblocks), dim3(64), 0, st, a);
         } else if (cfg.entropy == KNZ_E_ANS1) {
             // bounded groups of blocks (like the UTF stage and the suffix sort): a chunk slot takes 768 KiB of count / coder tables, 112 KiB of
-            // context headers and the 64 MiB expanded-step stream; the workspace is sized to at most ~8 GiB of them, not to the batch
+            // context headers and the 64 MiB expanded-step stream; the workspace is sized to at most ~64 GiB of them (up to ~960 chunks side by side: the chains of a group run as one wave each, 25 ms whatever their number), not to the batch
             const size_t perSlot = (size_t)65536 * 12 + (size_t)256 * KNZ_ANS1_CTXHDR_BYTES + 1024 + KNZ_ANS1_ENT_STRIDE * 16;
-            const uint32_t slotsPerGroup = (uint32_t)std::max<size_t>(cpb, std::min<size_t>((size_t)nblocks * cpb, ((size_t)8 << 30) / perSlot));
+            const uint32_t slotsPerGroup = (uint32_t)std::max<size_t>(cpb, std::min<size_t>((size_t)nblocks * cpb, ((size_t)64 << 30) / perSlot));
             uint32_t GB = std::max<uint32_t>(1, slotsPerGroup / cpb);                   // whole blocks per group
             if (const char* e = knz_test_switch("KNZ_ANS1_GROUP_BLOCKS")) GB = std::max(1, atoi(e));   // (tests: several groups on small inputs)
             const uint32_t gs = GB * cpb;
@@ -484,6 +495,11 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     sa.blk_status = h->blk_status.as<int32_t>();
     hipLaunchKernelGGL(knz_layout_stream_kernel, dim3(1), dim3(256), 0, st, sa);
     hipEventRecord(h->ev[3], st);
+    if (hufDirect && nblocks) {                                          // Huffman: the encoder itself places the units (no scratch round trip, no gather)
+        hufArgs.dst_words = (uint32_t*)eb.d_dst; hufArgs.chunk_rel = h->chunk_rel.as<uint64_t>(); hufArgs.blk_dst_bit = h->blk_dst_bit.as<uint64_t>();
+        hufArgs.total_bits = h->total_bits.as<uint64_t>();
+        KNZ_LAUNCH_PROBED(knz_huf_encode_kernel<false>, dim3(nblocks * cpb), dim3(256), 0, st, hufArgs);
+    }
 
     GatherArgs ga;
     ga.chunks_per_block = cpb; ga.chunk_size = chunkSize; ga.blk_len = h->blk_len.as<uint32_t>(); ga.unit_bits = h->unit_bits.as<uint32_t>();
@@ -491,7 +507,7 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     ga.unit_src = h->unit_src.as<uint32_t>();
     ga.chunk_rel = h->chunk_rel.as<uint64_t>(); ga.blk_dst_bit = h->blk_dst_bit.as<uint64_t>(); ga.dst_words = (uint32_t*)eb.d_dst;
     ga.total_bits = h->total_bits.as<uint64_t>();
-    if (nblocks) KNZ_LAUNCH_PROBED(knz_gather_kernel, dim3(nblocks * cpb, (cfg.entropy == KNZ_E_ANS1 || cfg.entropy == KNZ_E_FPAQ) ? 64 : 1), dim3(256), 0, st, ga);
+    if (nblocks && !hufDirect) KNZ_LAUNCH_PROBED(knz_gather_kernel, dim3(nblocks * cpb, (cfg.entropy == KNZ_E_ANS1 || cfg.entropy == KNZ_E_FPAQ) ? 64 : 1), dim3(256), 0, st, ga);
     hipEventRecord(h->ev[4], st);
     h->ev_valid = true;
 

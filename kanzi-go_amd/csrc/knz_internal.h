@@ -55,6 +55,7 @@ struct Handle {
     bool text_stat_ready = false;
     DevBuf srt_tab, srt_tmp, srt_ptrs;                               // parallel SRT forward: per-block tables, MTFT ranks, pointer / dummy arrays
     DevBuf blk_copy;                                                 // [nblocks] 1 = copy block (<= 15 bytes, or skipped by -s)
+    DevBuf huf_fhist;                                                // symbol counts per fragment (sizes pass of the Huffman encoder)
     DevBuf huf_stfreq, huf_stsym, huf_stlen, huf_stcnt, huf_stmax;   // sorted chunk statistics between the Huffman encode kernels
     size_t huf_fallback_n = 0;        // chunks covered by huf_fallback in the last decode batch
     DevBuf huf_fallback;              // [chunks] 1 = the parallel Huffman decoder handed the chunk to the serial one

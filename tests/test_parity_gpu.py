@@ -202,6 +202,15 @@ def test_4m_blocks_next_row_transforms(be, cfg):
     c.close()
 
 
+def test_huffman_encoder_scratch_form(be, monkeypatch):
+    # default = units encoded at their final bit positions (sizes pass, layout scans, encoder); KNZ_HUF_SCRATCH = the round-1 form (units to
+    # scratch slots, knz_gather_kernel), which -s streams still take
+    monkeypatch.setenv("KNZ_HUF_SCRATCH", "1")
+    P.check_entropy_encode(be, "HUFFMAN")
+    P.check_stream(be, "NONE", "HUFFMAN", 1 << 16, 300000)
+    P.check_stream(be, "NONE", "HUFFMAN", 4096, 4096 * 3 + 15)
+
+
 def test_huffman_decoder_paths(be):
     P.check_huffman_shapes(be)
 
