@@ -241,19 +241,20 @@ def pmc_traffic(argv_child, timeout_s=900):
             res[counter] = P.per_kernel(dbs[0], counter)
             if counter == "FETCH_SIZE":
                 try:
-                    times = {kernel_key(k): v for k, v in P.per_kernel_time(dbs[0]).items()}
+                    times = dict(P.per_kernel_time(dbs[0]).items())
                 except Exception:   # noqa: BLE001
                     times = {}
         out = {}
+        # one entry per kernel INSTANCE (template arguments kept: the instances of a kernel move different amounts); "key" = the name the events use
         for k in set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"]):
             f, w = res["FETCH_SIZE"].get(k, 0.0), res["WRITE_SIZE"].get(k, 0.0)
             key = kernel_key(k)
             fac = FETCH_FACTOR.get(key, 2.0)
-            o = out.setdefault(key, {"bytes": 0, "fetch_KB_raw": 0.0, "write_KB_raw": 0.0, "fetch_factor": fac})
-            o["bytes"] += int(fac * f * 1024 + w * 1024); o["fetch_KB_raw"] += round(f, 1); o["write_KB_raw"] += round(w, 1)
-        for key, (avg_us, calls) in times.items():
-            if key in out:
-                out[key]["avg_us_under_counters"] = round(avg_us, 1); out[key]["launches"] = calls
+            full = k.replace("void ", "").strip()
+            o = {"key": key, "bytes": int(fac * f * 1024 + w * 1024), "fetch_KB_raw": round(f, 1), "write_KB_raw": round(w, 1), "fetch_factor": fac}
+            if k in times:
+                o["avg_us_under_counters"] = round(times[k][0], 1); o["launches"] = times[k][1]
+            out[full] = o
         return out, ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per-launch averages; bytes = fetch_factor x "
                      "FETCH_SIZE + WRITE_SIZE (factor 2 = the guide's gfx950 correction for wide vector loads, 1 = calibrated scalar-cache reads)")
     except Exception as e:   # noqa: BLE001 (a profiler problem must not cost the bench line)
@@ -526,26 +527,37 @@ def main():
                         child += [flag, val]
                 tr, how = pmc_traffic(child)
                 roof["traffic_source"] = how
-                if tr is not None and dom in tr:
-                    roof["traffic"] = int(tr[dom]["bytes"])
-                    roof["traffic_over_algorithmic"] = round(tr[dom]["bytes"] / max(alg, 1), 3)
-                    roof["traffic_counters"] = {k: tr[dom][k] for k in ("fetch_KB_raw", "write_KB_raw", "fetch_factor")}
+                by_key = {}
+                for full, t in (tr or {}).items():
+                    by_key.setdefault(t["key"], []).append(full)
+                if tr is not None and dom in by_key:
+                    # (a kernel with several instances: launch-weighted mean of their per-launch bytes)
+                    inst = by_key[dom]
+                    wsum = sum(max(tr[f].get("launches", 1), 1) for f in inst)
+                    domBytes = sum(tr[f]["bytes"] * max(tr[f].get("launches", 1), 1) for f in inst) / max(wsum, 1)
+                    roof["traffic"] = int(domBytes)
+                    roof["traffic_over_algorithmic"] = round(domBytes / max(alg, 1), 3)
+                    roof["traffic_counters"] = {k: round(sum(tr[f][k] * max(tr[f].get("launches", 1), 1) for f in inst) / max(wsum, 1), 1) for k in ("fetch_KB_raw", "write_KB_raw")}
+                    roof["traffic_counters"]["fetch_factor"] = tr[inst[0]]["fetch_factor"]
                 if tr is not None:
-                    # every kernel of the step that moves at least 1 MB per launch or runs for 50 us: time (HIP events of this run where the launch is
-                    # probed, else the trace of the counter pass), algorithmic bytes of ONE launch (the stage's bytes / launches per step),
-                    # counter bytes per launch, and what the counters say about the HBM rate while the kernel runs
+                    # every kernel instance of the step that moves at least 1 MB per launch or runs for 50 us: time (HIP events of this run where the
+                    # launch is probed and the kernel has one instance, else the trace of the counter pass), algorithmic bytes of ONE launch (the stage's
+                    # bytes / launches per step), counter bytes per launch, and what the counters say about the HBM rate while the kernel runs
                     table = []
                     steps_child = 1 if args.config == "fpaq" else 3           # (the child runs warm-up + steps launches of everything)
-                    for k, t in tr.items():
+                    for full, t in tr.items():
+                        k = t["key"]
                         if not k.startswith("knz_"):
                             continue
-                        lps = kern_launches[k] / K_ if k in kern_launches else t.get("launches", 0) / steps_child
-                        ms = kern_ms[k] / max(kern_launches[k], 1) if k in kern_ms else t.get("avg_us_under_counters", 0.0) / 1e3
+                        single = len(by_key[k]) == 1
+                        ev = single and k in kern_ms
+                        lps = kern_launches[k] / K_ if ev else t.get("launches", 0) / steps_child
+                        ms = kern_ms[k] / max(kern_launches[k], 1) if ev else t.get("avg_us_under_counters", 0.0) / 1e3
                         if ms <= 0 or (t["bytes"] < 1e6 and ms < 0.05):
                             continue
-                        ab = alg_bytes(k)
-                        row = {"kernel": k, "avg_launch_ms": round(ms, 4), "launches_per_step": round(lps, 2), "ms_per_step": round(ms * lps, 3),
-                               "timing": "events" if k in kern_ms else "trace of the counter pass",
+                        ab = alg_bytes(k) if single else None
+                        row = {"kernel": full if not single else k, "avg_launch_ms": round(ms, 4), "launches_per_step": round(lps, 2), "ms_per_step": round(ms * lps, 3),
+                               "timing": "events" if ev else "trace of the counter pass",
                                "counter_bytes_per_launch": int(t["bytes"]), "counter_GBps": round(t["bytes"] / 1e9 / (ms / 1e3), 1),
                                "counter_frac_of_peak": round(t["bytes"] / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4)}
                         if ab is not None and lps > 0:

@@ -29,7 +29,6 @@
 #define KNZ_LZS_SEG 8192u
 #define KNZ_LZS_MAX_ROUNDS 48
 #define KNZ_LZS_NEVER 0xFFFFFFFFu
-#define KNZ_LZS_SCOUT 1024u                         // positions in front of a segment's end the scout round parses (below)
 #define KNZ_LZS_COARSE 512u                          // words of the coarse hole map (one bit per 2^cs positions)
 
 struct LzSegArgs {
@@ -101,12 +100,6 @@ __global__ __launch_bounds__(64) void knz_lzs_init_kernel(LzSegArgs g) {
     g.blk_state[b] = st;
 }
 
-// SCOUT (round 0 of a batch, round 4): the first full round used to start every segment from a guessed state, and everything it wrote (tokens, hole
-// maps) was replaced in the next round: only its EXIT states mattered, as the next round's entry states. A parse forgets its start within a match
-// or two, so the scout round parses only the last KNZ_LZS_SCOUT positions of every segment from the same guess, writes no token and no map, and
-// hands its exit state on as a guess (its recorded entry state is one no real parse can have, so every segment runs in the round behind it): an
-// eighth of a round's work instead of a whole one. What is exact is still only a fixed point of the full rounds.
-template <bool SCOUT>
 __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
     __shared__ uint32_t s_coarse[KNZ_LZS_COARSE];                       // 2 KiB: the waves of a CU are limited by their wave slots, not by LDS
     __shared__ uint32_t s_q[KNZ_LZS_COARSE];                            // the cells in front of the entry state this parse asks about
@@ -124,11 +117,7 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
     const int segEnd = (int)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
     const uint32_t* E = g.entry + 5 * si;
     int srcIdx = (int)E[0], anchor = (int)E[1], repd0 = (int)E[2], repd1 = (int)E[3], srcInc = (int)(E[4] & 0x7FFFFFFFu), repdIdx = (int)(E[4] >> 31);
-    if (SCOUT) {
-        const int at = max(srcIdx, segEnd - (int)KNZ_LZS_SCOUT);
-        srcIdx = at; anchor = at; repd0 = count; repd1 = count; srcInc = 0; repdIdx = s ? 1 : 0;
-        if (writer) { uint32_t* U = g.used + 5 * si; U[0] = (uint32_t)at; U[1] = (uint32_t)at; U[2] = (uint32_t)count; U[3] = (uint32_t)count; U[4] = 0x7FFFFFFFu; }
-    } else if (writer) { uint32_t* U = g.used + 5 * si; U[0] = E[0]; U[1] = E[1]; U[2] = E[2]; U[3] = E[3]; U[4] = E[4]; }
+    if (writer) { uint32_t* U = g.used + 5 * si; U[0] = E[0]; U[1] = E[1]; U[2] = E[2]; U[3] = E[3]; U[4] = E[4]; }
     const int eSrc = srcIdx, eAnchor = anchor;                                // where this segment's own knowledge of the holes begins
     const uint8_t* cand8 = (const uint8_t*)(g.pa.cand + g.pa.gstart[b]);
     const uint8_t* cp8 = g.pa.cp8 + g.pa.gstart[b];
@@ -221,7 +210,7 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
                 else if ((uint32_t)p == knz_sle32(src + ref)) { bestLen = knz_lz_match_wave(src, srcIdx, ref, mm, lane); if (bestLen >= minMatch) found = 1; }
             }
             if (found == 0) {
-                if (!SCOUT && nextPos > srcIdx1) {                            // positions jumped over: not hashed until a match covers them
+                if (nextPos > srcIdx1) {                                      // positions jumped over: not hashed until a match covers them
                     for (int q0 = srcIdx1; q0 < nextPos; q0 += 64) {
                         const int q = q0 + lane;
                         if (q < nextPos) {
@@ -289,14 +278,13 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
         repd1 = repd0;
         repd0 = dist;
         repdIdx = 1;
-        if (SCOUT) { }
-        else if (ntok < g.tok_cap) { if (writer) { uint4 t; t.x = (uint32_t)anchor; t.y = (uint32_t)(srcIdx - anchor); t.z = (uint32_t)bestLen | (tflag << 24); t.w = (uint32_t)dist; tokOut[ntok] = t; } }
+        if (ntok < g.tok_cap) { if (writer) { uint4 t; t.x = (uint32_t)anchor; t.y = (uint32_t)(srcIdx - anchor); t.z = (uint32_t)bestLen | (tflag << 24); t.w = (uint32_t)dist; tokOut[ntok] = t; } }
         else overflow = true;
         ntok++;
         anchor = srcIdx + bestLen;
         // the reference hashes every position of the match now (:517-553): jumped-over positions under it are holes no longer
         // (in a block with holes: all of them, so that the M bits of a trace do not depend on where other segments' holes were)
-        if (!SCOUT && anyHoles) {
+        if (anyHoles) {
             for (int q0 = srcIdx + 1; q0 < anchor; q0 += 64) { const int q = q0 + lane; if (q < anchor) atomicOr(&Mn[q >> 5], 1u << (q & 31)); }
             wave_order_lanes();
         }
@@ -305,7 +293,7 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
     if (writer) {
         uint32_t* X = g.exit_ + 5 * si;
         X[0] = (uint32_t)srcIdx; X[1] = (uint32_t)anchor; X[2] = (uint32_t)repd0; X[3] = (uint32_t)repd1; X[4] = (uint32_t)srcInc | ((uint32_t)repdIdx << 31);
-        g.ntok[si] = SCOUT ? 0u : (overflow ? KNZ_LZS_NEVER : ntok);
+        g.ntok[si] = overflow ? KNZ_LZS_NEVER : ntok;
     }
     if (g.sprof && writer) {
         const unsigned long long dt = KNZ_LZS_NOW() - t0;

@@ -16,9 +16,9 @@ def per_kernel(path, counter):
 
 
 def per_kernel_time(path):
-    """{kernel: (average launch duration in us, launches)} from the kernel trace of the same database (view top_kernels)."""
+    """{kernel: (average launch duration in us, launches)} from the kernel trace of the same database (view top_kernels: durations in us)."""
     cur = sqlite3.connect(path).cursor()
-    return {name.split("(")[0]: (avg / 1e3 if avg > 1e5 else avg, calls) for name, calls, avg in cur.execute("select name,total_calls,average from top_kernels")}
+    return {name.split("(")[0]: (avg, calls) for name, calls, avg in cur.execute("select name,total_calls,average from top_kernels")}
 
 
 def main():
