@@ -117,28 +117,29 @@ __device__ __forceinline__ SsTile knz_ss_tile(const SsGeom& g, uint32_t tile) {
 // output slot with the blocks kept apart
 template <bool FIRST>
 __global__ __launch_bounds__(KNZ_RS_THREADS) void knz_ss_hist_kernel(SsGeom g, const uint64_t* keys, unsigned shift, uint32_t* hist) {
-    __shared__ uint32_t s_cnt[KNZ_RS_THREADS / 64][256];
+    // counts only (no ranks): plain LDS atomics into four copies per wave (lane & 3), which costs a few LDS cycles per row of 64 keys even when
+    // many lanes share a digit; the one-ballot-per-bit matching of the scatter costs ~70 instructions per row and made this kernel compute-bound
+    __shared__ uint32_t s_cnt[KNZ_RS_THREADS / 64][4][256];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const SsTile t = knz_ss_tile(g, blockIdx.x);
     const uint8_t* src = (const uint8_t*)g.in_ptr[t.b];
-    for (uint32_t i = tid; i < (KNZ_RS_THREADS / 64) * 256; i += KNZ_RS_THREADS) (&s_cnt[0][0])[i] = 0;
+    for (uint32_t i = tid; i < (KNZ_RS_THREADS / 64) * 4 * 256; i += KNZ_RS_THREADS) (&s_cnt[0][0][0])[i] = 0;
     __syncthreads();
+    uint32_t* mine = s_cnt[w][lane & 3];
+#pragma unroll
     for (int r = 0; r < KNZ_RS_ITEMS; r++) {
         const uint32_t loc = t.t0 + w * (64 * KNZ_RS_ITEMS) + (uint32_t)r * 64 + lane;
-        const bool valid = loc < t.n;
-        uint32_t d = 0;
-        if (valid) {
+        if (loc < t.n) {
+            uint32_t d;
             if (FIRST) d = loc + (KNZ_SS_K0 - 1) < t.n ? src[loc + (KNZ_SS_K0 - 1)] : 0u;
             else d = (uint32_t)(keys[t.gs0 + loc] >> shift) & 0xFFu;
+            atomicAdd(&mine[d], 1u);
         }
-        const uint64_t m = knz_match_digit(d, valid);
-        if (valid && (m & ((1ull << lane) - 1)) == 0) s_cnt[w][d] += (uint32_t)__popcll(m);
-        wave_sync();
     }
     __syncthreads();
-    uint32_t s = 0;
-    for (int k = 0; k < KNZ_RS_THREADS / 64; k++) s += s_cnt[k][tid];
-    hist[(size_t)256 * g.tile_base[t.b] + (size_t)tid * t.tpb + t.lt] = s;
+    uint32_t sum = 0;
+    for (int k = 0; k < KNZ_RS_THREADS / 64; k++) sum += s_cnt[k][0][tid] + s_cnt[k][1][tid] + s_cnt[k][2][tid] + s_cnt[k][3][tid];
+    hist[(size_t)256 * g.tile_base[t.b] + (size_t)tid * t.tpb + t.lt] = sum;
 }
 
 template <bool FIRST>
@@ -164,18 +165,27 @@ __global__ __launch_bounds__(KNZ_RS_THREADS) void knz_ss_scatter_kernel(SsGeom g
         if (FIRST) { key[r] = valid ? knz_ss_text_key(src, loc, t.n) : 0; val[r] = t.gs0 + loc; }
         else { key[r] = valid ? kin[t.gs0 + loc] : 0; val[r] = valid ? vin[t.gs0 + loc] : 0u; }
     }
+    // rank of a pair among the wave's pairs with the same digit: the lanes of a row that share a digit find each other with one ballot per bit, the first
+    // of them adds the row's count to the wave's counter with an LDS atomic whose returned value is the count of the rows in front (LDS atomics of
+    // one wave execute in program order): every row is issued before the first result is looked at, no LDS round trip per row
+    uint32_t old[KNZ_RS_ITEMS];
 #pragma unroll
     for (int r = 0; r < KNZ_RS_ITEMS; r++) {
         const uint32_t loc = t.t0 + w * (64 * KNZ_RS_ITEMS) + (uint32_t)r * 64 + lane;
         const bool valid = loc < t.n;
         const uint32_t d = valid ? (uint32_t)(key[r] >> shift) & 0xFFu : 0u;
         const uint64_t m = knz_match_digit(d, valid);
-        const uint32_t before = valid ? s_cnt[w][d] : 0u;
-        const uint32_t below = (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        wave_sync();
-        if (valid && below == 0) s_cnt[w][d] = before + (uint32_t)__popcll(m);
-        wave_sync();
-        rank[r] = (d << 24) | (before + below);
+        const uint32_t below = wave_mbcnt64(m);
+        const uint32_t leader = valid ? (uint32_t)__ffsll((unsigned long long)m) - 1 : 0u;
+        old[r] = 0;
+        if (valid && below == 0) old[r] = atomicAdd(&s_cnt[w][d], (uint32_t)__popcll(m));
+        wave_order_lanes();
+        rank[r] = (d << 24) | (leader << 8) | below;
+    }
+#pragma unroll
+    for (int r = 0; r < KNZ_RS_ITEMS; r++) {
+        const uint32_t before = wave_shfl(old[r], (int)((rank[r] >> 8) & 63u));
+        rank[r] = (rank[r] & 0xFF000000u) | (before + (rank[r] & 0xFFu));
     }
     __syncthreads();
     {

@@ -485,7 +485,10 @@ __global__ __launch_bounds__(256) void knz_lzs_emit_count_kernel(LzSegArgs g, ui
     __shared__ uint32_t s_w[4];
     const LzArgs& a = g.pa.a;
     const uint32_t b = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
-    if (g.blk_state[b] != 1) return;
+    __shared__ uint32_t s_state;                                          // (other workgroups of the block may set the state to 2 meanwhile: read once per workgroup)
+    if (tid == 0) s_state = g.blk_state[b];
+    __syncthreads();
+    if (s_state != 1) return;
     const int count = (int)a.in_len[b];
     int srcEnd, maxDist, minMatch; uint32_t hf; bool decline;
     knz_lzs_geom(a, b, count, srcEnd, maxDist, minMatch, hf, decline);

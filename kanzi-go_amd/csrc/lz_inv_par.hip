@@ -397,7 +397,11 @@ __global__ __launch_bounds__(256) void knz_lzi_b_count_kernel(LziArgs g) {
     __shared__ LziRep s_r[4];
     const uint32_t b = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     uint32_t* G = g.geo + 16 * (size_t)b;
-    if (!G[LZI_PAR] || s * KNZ_LZI_SEG >= G[LZI_NTOK]) return;
+    // (other workgroups of the block clear the flag while this kernel runs: the workgroup reads it ONCE, so that all its waves reach the barriers below or none)
+    __shared__ uint32_t s_par;
+    if (tid == 0) s_par = G[LZI_PAR];
+    __syncthreads();
+    if (!s_par || s * KNZ_LZI_SEG >= G[LZI_NTOK]) return;
     LziTok8 T;
     knz_lzi_b_tokens(g, b, G, s * KNZ_LZI_SEG + tid * 8, T);
     uint32_t len = 0;
@@ -464,7 +468,10 @@ __global__ __launch_bounds__(256) void knz_lzi_b_apply_kernel(LziArgs g) {
     const uint32_t b = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     uint32_t* G = g.geo + 16 * (size_t)b;
     const uint32_t nTok = G[LZI_NTOK];
-    if (!G[LZI_PAR] || s * KNZ_LZI_SEG >= nTok) return;
+    __shared__ uint32_t s_par;                                            // (read once per workgroup, see knz_lzi_b_count_kernel)
+    if (tid == 0) s_par = G[LZI_PAR];
+    __syncthreads();
+    if (!s_par || s * KNZ_LZI_SEG >= nTok) return;
     const uint32_t k0 = s * KNZ_LZI_SEG + tid * 8;
     LziTok8 T;
     knz_lzi_b_tokens(g, b, G, k0, T);

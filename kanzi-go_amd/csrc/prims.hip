@@ -59,23 +59,22 @@ __device__ __forceinline__ uint64_t knz_match_digit(uint32_t d, bool valid) {
 
 template <typename K>
 __global__ __launch_bounds__(KNZ_RS_THREADS) void knz_rs_hist_kernel(const K* keys, uint32_t n, unsigned shift, uint32_t mask, uint32_t* hist, uint32_t tiles) {
-    __shared__ uint32_t s_cnt[KNZ_RS_THREADS / 64][256];
+    // counts only: plain LDS atomics into four copies per wave (round 4; the matching of the scatter made this kernel compute-bound)
+    __shared__ uint32_t s_cnt[KNZ_RS_THREADS / 64][4][256];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, tile = blockIdx.x;
-    for (uint32_t i = tid; i < (KNZ_RS_THREADS / 64) * 256; i += KNZ_RS_THREADS) (&s_cnt[0][0])[i] = 0;
+    for (uint32_t i = tid; i < (KNZ_RS_THREADS / 64) * 4 * 256; i += KNZ_RS_THREADS) (&s_cnt[0][0][0])[i] = 0;
     __syncthreads();
+    uint32_t* mine = s_cnt[w][lane & 3];
     const uint64_t base = (uint64_t)tile * KNZ_RS_TILE + (uint64_t)w * (64 * KNZ_RS_ITEMS);
+#pragma unroll
     for (int r = 0; r < KNZ_RS_ITEMS; r++) {
         const uint64_t idx = base + (uint64_t)r * 64 + lane;
-        const bool valid = idx < n;
-        const uint32_t d = valid ? (uint32_t)(keys[idx] >> shift) & mask : 0u;
-        const uint64_t m = knz_match_digit(d, valid);
-        if (valid && (m & ((1ull << lane) - 1)) == 0) s_cnt[w][d] += (uint32_t)__popcll(m);      // the group's first lane adds the group
-        wave_sync();
+        if (idx < n) atomicAdd(&mine[(uint32_t)(keys[idx] >> shift) & mask], 1u);
     }
     __syncthreads();
-    uint32_t s = 0;
-    for (int k = 0; k < KNZ_RS_THREADS / 64; k++) s += s_cnt[k][tid];
-    hist[(size_t)tid * tiles + tile] = s;
+    uint32_t sum = 0;
+    for (int k = 0; k < KNZ_RS_THREADS / 64; k++) sum += s_cnt[k][0][tid] + s_cnt[k][1][tid] + s_cnt[k][2][tid] + s_cnt[k][3][tid];
+    hist[(size_t)tid * tiles + tile] = sum;
 }
 
 template <typename K>
@@ -101,18 +100,26 @@ __global__ __launch_bounds__(KNZ_RS_THREADS) void knz_rs_scatter_kernel(const K*
         key[r] = valid ? kin[idx] : (K)0;
         val[r] = valid ? vin[idx] : 0u;
     }
+    // (round 4) the first lane of every group of equal digits adds the row's count with a returned LDS atomic; the results are looked at behind the last
+    // row: LDS atomics of one wave execute in program order, so the returned values are the counts of the rows in front
+    uint32_t old[KNZ_RS_ITEMS];
 #pragma unroll
     for (int r = 0; r < KNZ_RS_ITEMS; r++) {
         const uint64_t idx = base + (uint64_t)r * 64 + lane;
         const bool valid = idx < n;
         const uint32_t d = valid ? (uint32_t)(key[r] >> shift) & mask : 0u;
         const uint64_t m = knz_match_digit(d, valid);
-        const uint32_t before = valid ? s_cnt[w][d] : 0u;
-        const uint32_t below = (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        wave_sync();
-        if (valid && below == 0) s_cnt[w][d] = before + (uint32_t)__popcll(m);
-        wave_sync();
-        rank[r] = (d << 24) | (before + below);
+        const uint32_t below = wave_mbcnt64(m);
+        const uint32_t leader = valid ? (uint32_t)__ffsll((unsigned long long)m) - 1 : 0u;
+        old[r] = 0;
+        if (valid && below == 0) old[r] = atomicAdd(&s_cnt[w][d], (uint32_t)__popcll(m));
+        wave_order_lanes();
+        rank[r] = (d << 24) | (leader << 8) | below;
+    }
+#pragma unroll
+    for (int r = 0; r < KNZ_RS_ITEMS; r++) {
+        const uint32_t before = wave_shfl(old[r], (int)((rank[r] >> 8) & 63u));
+        rank[r] = (rank[r] & 0xFF000000u) | (before + (rank[r] & 0xFFu));
     }
     __syncthreads();
     {   // digit `tid`: its pairs start at `first` inside the sorted tile, each wave's share behind the waves in front of it
