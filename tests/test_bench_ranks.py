@@ -46,13 +46,25 @@ def test_bench_ranks_weak_scaling(nproc):
 @pytest.mark.timeout(1000)
 @pytest.mark.parametrize("nproc,nblk", [(2, 5), (3, 2)])
 def test_bench_ranks_strong_scaling_default_config(nproc, nblk):
-    """The default N>1 mode: ONE fixed job of BASELINE configs[3]'s pipeline (BWT+RANK+ZRLT / ANS1) split over the ranks by
+    """--scaling strong: ONE fixed job of BASELINE configs[3]'s pipeline (BWT+RANK+ZRLT / ANS1) split over the ranks by
     contiguous block ranges; (3 ranks, 2 blocks) leaves a rank without any block."""
     bs = 16384
     size = (nblk - 1) * bs + 4321
-    out = _run(nproc, ["--size", str(size), "--block-size", str(bs)])
+    out = _run(nproc, ["--scaling", "strong", "--size", str(size), "--block-size", str(bs)])
     assert out["scaling"] == "strong" and out["n_gpus"] == nproc
     assert "configs[3]" in out["config"]["workload"] and "BWT+RANK+ZRLT" in out["config"]["workload"]
     assert out["config"]["blocks"] == nblk
     assert out["roundtrip_ok"] is True and out["bit_exact_vs_oracle"] is True
     assert out["roofline"]["kernel"] is not None and out["roofline"]["avg_launch_ms"] >= 0
+
+
+@pytest.mark.timeout(1000)
+def test_bench_ranks_default_is_weak_on_the_default_config():
+    """What the driver launches (no --scaling): one corpus copy per rank in one stream, BASELINE configs[3]'s pipeline."""
+    bs = 16384
+    size = 2 * bs + 999
+    out = _run(2, ["--size", str(size), "--block-size", str(bs)])
+    assert out["scaling"] == "weak" and out["n_gpus"] == 2
+    assert "configs[3]" in out["config"]["workload"] and "2 copies" in out["config"]["workload"]
+    assert out["config"]["blocks"] == (2 * size + bs - 1) // bs
+    assert out["roundtrip_ok"] is True and out["bit_exact_vs_oracle"] is True
