@@ -367,8 +367,9 @@ __global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a, const u
 // The same kernel with the dependent loop written by hand (device build; the emulator runs the C++ form above, which stays the A/B form on the
 // device: KNZ_ANS1_ENC_PLAIN). A lone wave pays ~2.5 ns for every instruction it issues (profiles/r02_lone_wave_latencies.md); the compiler's loop
 // has 11.5-12 per step: the renormalisation shift and its select are two instructions, every step folds its four ballot bits into a scalar mask
-// (s_and + s_or / s_mov), and every step has its own s_waitcnt. Here a step is 7 instructions + its entry load:
-//   ds_write_b32   the state BEFORE the renormalisation goes to the fixed LDS slot of (step, state): its low half is the candidate word, and
+// (s_and + s_or / s_mov), and every step has its own s_waitcnt. Here a step is 6 instructions + a quarter of an LDS store + its entry load:
+//   (no store)     the state BEFORE the renormalisation stays in its register (every step writes a new one) and leaves with three others in one
+//                  16-byte LDS store per four steps, to the fixed slot of (state, step): its low half is the candidate word, and
 //                  whether it is a real word is decided once per 48 steps by all 64 lanes (lane = 4 * step + state compares its slot with the
 //                  xMax of its (step, state), which it loaded together with the group's entries): no mask bookkeeping on the chain;
 //   v_cmp_ge_u32 / v_cndmask_b32_sdwa (src1_sel:WORD_1)   st = st >= xMax ? st >> 16 : st  in one select;
@@ -376,34 +377,36 @@ __global__ __launch_bounds__(64) void knz_ans1_encode_kernel(Ans1Args a, const u
 // Four steps per statement (an asm statement takes at most 30 operands); the compiler places the loads between the statements and one
 // s_waitcnt in front of each (the loads of a group return in order).
 #define KNZ_A1E_SDWA " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
-#define KNZ_A1E_STEP(J) \
-    "ds_write_b32 %[ad], %[st] offset:%[o" J "]\n\t" \
-    "v_cmp_ge_u32_e32 vcc, %[st], %[y" J "]\n\t" \
-    "v_cndmask_b32_sdwa %[st], %[st], %[st], vcc" KNZ_A1E_SDWA \
-    "v_mul_hi_u32 %[q], %[st], %[x" J "]\n\t" \
+// one step: state %[sA] -> %[sB]; %[sA] stays what it was (the state in front of the renormalisation: the candidate word and the flag test need it)
+#define KNZ_A1E_STEP(J, A, B) \
+    "v_cmp_ge_u32_e32 vcc, %[" A "], %[y" J "]\n\t" \
+    "v_cndmask_b32_sdwa %[t], %[" A "], %[" A "], vcc" KNZ_A1E_SDWA \
+    "v_mul_hi_u32 %[q], %[t], %[x" J "]\n\t" \
     "v_lshrrev_b32_e32 %[q], %[w" J "], %[q]\n\t" \
     "v_mul_u32_u24_sdwa %[q], %[q], %[w" J "]" KNZ_A1E_SDWA \
-    "v_add3_u32 %[st], %[st], %[z" J "], %[q]\n\t"
-template <int OFF>
-__device__ __forceinline__ void knz_a1e_run4(uint32_t& st, const uint4& e0, const uint4& e1, const uint4& e2, const uint4& e3, uint32_t ad) {
-    uint32_t q;
-    asm volatile(KNZ_A1E_STEP("0") KNZ_A1E_STEP("1") KNZ_A1E_STEP("2") KNZ_A1E_STEP("3")
-                 : [st] "+v"(st), [q] "=&v"(q)
-                 : [x0] "v"(e0.x), [y0] "v"(e0.y), [z0] "v"(e0.z), [w0] "v"(e0.w), [x1] "v"(e1.x), [y1] "v"(e1.y), [z1] "v"(e1.z), [w1] "v"(e1.w),
-                   [x2] "v"(e2.x), [y2] "v"(e2.y), [z2] "v"(e2.z), [w2] "v"(e2.w), [x3] "v"(e3.x), [y3] "v"(e3.y), [z3] "v"(e3.z), [w3] "v"(e3.w),
-                   [ad] "v"(ad), [o0] "n"(OFF), [o1] "n"(OFF + 16), [o2] "n"(OFF + 32), [o3] "n"(OFF + 48)
+    "v_add3_u32 %[" B "], %[t], %[z" J "], %[q]\n\t"
+// four steps; the four states in front of their renormalisations leave as ONE 16-byte LDS store (slot layout [group][state][step])
+__device__ __forceinline__ void knz_a1e_run4(uint32_t& st, const uint4& e0, const uint4& e1, const uint4& e2, const uint4& e3, uint32_t* slot) {
+    uint32_t q, t, s1, s2, s3, s4;
+    asm volatile(KNZ_A1E_STEP("0", "s0", "s1") KNZ_A1E_STEP("1", "s1", "s2") KNZ_A1E_STEP("2", "s2", "s3") KNZ_A1E_STEP("3", "s3", "s4")
+                 : [s1] "=&v"(s1), [s2] "=&v"(s2), [s3] "=&v"(s3), [s4] "=&v"(s4), [q] "=&v"(q), [t] "=&v"(t)
+                 : [s0] "v"(st), [x0] "v"(e0.x), [y0] "v"(e0.y), [z0] "v"(e0.z), [w0] "v"(e0.w), [x1] "v"(e1.x), [y1] "v"(e1.y), [z1] "v"(e1.z), [w1] "v"(e1.w),
+                   [x2] "v"(e2.x), [y2] "v"(e2.y), [z2] "v"(e2.z), [w2] "v"(e2.w), [x3] "v"(e3.x), [y3] "v"(e3.y), [z3] "v"(e3.z), [w3] "v"(e3.w)
                  : "vcc");
+    uint4 sv; sv.x = st; sv.y = s1; sv.z = s2; sv.w = s3;
+    *(uint4*)slot = sv;
+    st = s4;
 }
 template <int R>
-__device__ __forceinline__ void knz_a1e_run_group(uint32_t& st, const uint4* e, uint32_t ad) {
-    knz_a1e_run4<R * 256>(st, e[0], e[1], e[2], e[3], ad);
-    knz_a1e_run4<R * 256 + 64>(st, e[4], e[5], e[6], e[7], ad);
-    knz_a1e_run4<R * 256 + 128>(st, e[8], e[9], e[10], e[11], ad);
-    knz_a1e_run4<R * 256 + 192>(st, e[12], e[13], e[14], e[15], ad);
+__device__ __forceinline__ void knz_a1e_run_group(uint32_t& st, const uint4* e, uint32_t* mine) {
+    knz_a1e_run4(st, e[0], e[1], e[2], e[3], mine + R * 64);
+    knz_a1e_run4(st, e[4], e[5], e[6], e[7], mine + R * 64 + 4);
+    knz_a1e_run4(st, e[8], e[9], e[10], e[11], mine + R * 64 + 8);
+    knz_a1e_run4(st, e[12], e[13], e[14], e[15], mine + R * 64 + 12);
 }
 
 __global__ __launch_bounds__(64) void knz_ans1_encode_asm_kernel(Ans1Args a, const uint4* ent) {
-    __shared__ uint32_t s_w[3 * KNZ_ANS1_GROUP * 4];                    // state in front of the renormalisation of (step, state) of the current 48 steps
+    __shared__ __attribute__((aligned(16))) uint32_t s_w[3 * KNZ_ANS1_GROUP * 4];   // state in front of the renormalisation of (group, state, step) of the current 48 steps
     const int lane = threadIdx.x;
     const uint32_t slotId = blockIdx.x;
     uint32_t b, n; const uint8_t* src; bool bad;
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(64) void knz_ans1_encode_asm_kernel(Ans1Args a, con
     uint8_t* payEnd = slot + KNZ_ANS1_PAY_OFF + KNZ_ANS1_PAY_CAP;
     const uint4* __restrict__ base = ent + (size_t)slotId * KNZ_ANS1_ENT_STRIDE;
     const uint4* __restrict__ my = base + (size_t)(lane & 3);           // lanes 4..63 mirror lanes 0..3 (same entries, same state, same LDS words)
-    const uint32_t ad = knz_lds_addr(s_w) + 4u * (uint32_t)(lane & 3);
+    uint32_t* mine = s_w + 16 * (lane & 3);                            // this lane's state: 16 steps of a group side by side
     uint32_t st = 1u << 15;
     uint32_t flushed = 0;
     uint4 buf0[KNZ_ANS1_GROUP], buf1[KNZ_ANS1_GROUP], buf2[KNZ_ANS1_GROUP];
@@ -426,7 +429,8 @@ __global__ __launch_bounds__(64) void knz_ans1_encode_asm_kernel(Ans1Args a, con
     auto flush = [&](uint32_t x0, uint32_t x1, uint32_t x2) {
         wave_sync_lds();
         const uint64_t below = ((uint64_t)1 << lane) - 1;
-        const uint32_t v0 = s_w[lane], v1 = s_w[64 + lane], v2 = s_w[128 + lane];
+        const uint32_t fi = 16u * (uint32_t)(lane & 3) + (uint32_t)(lane >> 2);     // lane = 4 * step + state reads slot [state][step]
+        const uint32_t v0 = s_w[fi], v1 = s_w[64 + fi], v2 = s_w[128 + fi];
         const uint64_t m0 = wave_ballot(v0 >= x0), m1 = wave_ballot(v1 >= x1), m2 = wave_ballot(v2 >= x2);
         const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2);
 #pragma unroll
@@ -447,11 +451,11 @@ __global__ __launch_bounds__(64) void knz_ans1_encode_asm_kernel(Ans1Args a, con
 #pragma unroll
     for (int j = 0; j < KNZ_ANS1_GROUP; j++) { buf0[j].x = 0; buf0[j].y = 0xFFFFFFFFu; buf0[j].z = 0; buf0[j].w = 0; buf1[j] = buf0[j]; }
     for (uint32_t t0 = 0; t0 < steps + 2 * KNZ_ANS1_GROUP && steps; t0 += 3 * KNZ_ANS1_GROUP) {
-        load_group(t0, buf2, xm2); knz_a1e_run_group<0>(st, buf0, ad);
+        load_group(t0, buf2, xm2); knz_a1e_run_group<0>(st, buf0, mine);
         const uint32_t f0 = xm0;
-        load_group(t0 + KNZ_ANS1_GROUP, buf0, xm0); knz_a1e_run_group<1>(st, buf1, ad);
+        load_group(t0 + KNZ_ANS1_GROUP, buf0, xm0); knz_a1e_run_group<1>(st, buf1, mine);
         const uint32_t f1 = xm1;
-        load_group(t0 + 2 * KNZ_ANS1_GROUP, buf1, xm1); knz_a1e_run_group<2>(st, buf2, ad);
+        load_group(t0 + 2 * KNZ_ANS1_GROUP, buf1, xm1); knz_a1e_run_group<2>(st, buf2, mine);
         flush(f0, f1, xm2);
     }
     const uint32_t s1 = wave_shfl(st, 1), s2 = wave_shfl(st, 2), s3 = wave_shfl(st, 3);
