@@ -116,6 +116,10 @@ def test_bwt_suffix_sort_forms(be, monkeypatch):
     P.check_bwt_sort_forms(be, monkeypatch)
 
 
+def test_bwt_suffix_sort_fuzz(be, monkeypatch):
+    P.check_bwt_sort_fuzz(be, monkeypatch)
+
+
 def test_rank_chain_variants(be, monkeypatch):
     P.check_rank_chain_variants(be, monkeypatch, max_len=4100, bwt_len=12000)
 
