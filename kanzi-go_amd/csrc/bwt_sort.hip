@@ -6,13 +6,15 @@
 //             (no key array is built first).
 //   classify  equal keys = a group. Groups live as head bits; a group of one suffix is final. Unresolved suffixes go to one of two
 //             lists by the size of their group: "normal" (2..KNZ_SG_T members) or "large".
-//   round h   the groups of the normal list are refined by a SEGMENTED sort: a workgroup takes the groups that start inside its
-//             stretch of the list (< 2 * KNZ_SG_T items), gathers rank[i + h], sorts (group, rank) in LDS with 9-bit digits and
-//             writes the suffixes back in place: one read and one write of the list per round instead of seven device-wide radix
-//             passes over (group start : 28 | rank : 28) keys. Only the large groups (long runs, very frequent words) take the
-//             device-wide radix sort, on (dense group index | rank) keys.
-//   update    ranks are scattered and the lists compacted in a second kernel (every gather of a round reads the ranks of the
-//             round before).
+//   round h   the groups of the normal list are refined by a SEGMENTED sort: knz_sg_keys_kernel gathers rank[i + h] for every entry (a streaming
+//             kernel: the random gathers are what costs, they want every lane of the chip), knz_sg_sort_kernel: a workgroup takes the groups
+//             that start inside its stretch of the list (< 2 * KNZ_SG_T items), sorts (group, rank) in LDS with 9-bit digits and writes the
+//             suffixes back in place: one read and one write of the list per round instead of seven device-wide radix passes over
+//             (group start : 28 | rank : 28) keys. Only the large groups (the most frequent words, long runs) take the device-wide radix sort,
+//             on (dense group index | rank) keys; once that list is short its keys are run-aware (knz_sl_keys_kernel): a run of one symbol is
+//             resolved in one round whatever its length.
+//   update    knz_sg_update_kernel scatters the ranks that changed and compacts the list (every gather of a round reads the ranks of the
+//             round before, so the scatter is a kernel of its own).
 // rank[i] = 1 + first slot of i's group, counted from the block's first slot (block-local: 8 bits fewer to sort than global ranks).
 // A suffix that ends within the next h symbols sorts in front of every member of its group that goes on (second key: its length - 1,
 // which is < h; the others carry rank + h), as in rounds 1-3.

@@ -462,9 +462,12 @@ __global__ __launch_bounds__(64) void knz_zrlt_carry_kernel(XfArgs a) {
 // 5) (scatter = true) write them at seg_b (now the segment's output offset)
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void knz_zrlt_seg_kernel(XfArgs a) {
+    // Round 4: the segment (8 KiB = 256 threads x 32 consecutive bytes) is staged in LDS with 16-byte loads and its output leaves through LDS as
+    // whole words: the thread-per-32-bytes loops used to read and write global memory a byte at a time (64 lanes = 64 different 32-byte
+    // stretches per load instruction), which kept both passes at 3 % of the HBM rate.
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[KNZ_SEG + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_o[2 * KNZ_SEG + 64];                    // (8192 literals of two bytes, or a few less behind the digits of a run that ends here)
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_carry;
-    __shared__ int s_lastnz;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t b = blockIdx.x / a.segs_per_block, s = blockIdx.x % a.segs_per_block;
     if (!a.active[b]) return;
@@ -472,65 +475,77 @@ __global__ __launch_bounds__(256) void knz_zrlt_seg_kernel(XfArgs a) {
     const uint32_t n = a.in_len[b];
     const uint32_t lo = s * KNZ_SEG;
     if (lo >= n) return;
-    const uint32_t hi = min(n, lo + KNZ_SEG);
+    const uint32_t hi = min(n, lo + KNZ_SEG), cnt = hi - lo;
     const uint8_t* src = (const uint8_t*)a.in_ptr[b];
     uint8_t* dst = (uint8_t*)a.out_ptr[b];
-    if (tid == 0) { s_carry = SCATTER ? (uint32_t)a.seg_b[blockIdx.x] : 0u; s_lastnz = a.seg_a[blockIdx.x]; }
-    __syncthreads();
-    // 32 consecutive positions per thread per pass keeps the running "last non-zero" in a register
-    for (uint32_t base = lo; base < hi; base += 256 * 32) {
-        const uint32_t p0 = base + (uint32_t)tid * 32;
-        // last non-zero before p0: scan of the per-thread maxima of the previous threads
-        int myMax = -1;
-        for (uint32_t j = 0; j < 32 && p0 + j < hi; j++) if (src[p0 + j] != 0) myMax = (int)(p0 + j);
-        // inclusive max-scan across the workgroup
-        int m = myMax;
-        for (int d = 1; d < 64; d <<= 1) { int t = (int)wave_shfl((uint32_t)m, lane - d); if (lane >= d && t > m) m = t; }
-        __syncthreads();
-        if (lane == 63) s_wave[wave] = (uint32_t)m;
-        __syncthreads();
-        int before = s_lastnz;
-        for (int w = 0; w < wave; w++) { int t = (int)s_wave[w]; if (t > before) before = t; }
-        int exclusive = (int)wave_shfl((uint32_t)m, lane - 1);
-        if (lane == 0) exclusive = -1;
-        if (exclusive > before) before = exclusive;
-        int passMax = (int)s_wave[0];
-        for (int w = 1; w < 4; w++) if ((int)s_wave[w] > passMax) passMax = (int)s_wave[w];
-        // sizes of my 32 elements
-        uint32_t sz = 0;
-        int lnz = before;
-        for (uint32_t j = 0; j < 32 && p0 + j < hi; j++) {
-            sz += knz_zrlt_elem_size(src, n, p0 + j, lnz);
-            if (src[p0 + j] != 0) lnz = (int)(p0 + j);
+    const uint32_t carry0 = SCATTER ? (uint32_t)a.seg_b[blockIdx.x] : 0u;
+    const int lastnz0 = a.seg_a[blockIdx.x];
+    if ((((uintptr_t)(src + lo)) & 15) == 0) {
+        for (uint32_t i = (uint32_t)tid * 16; i < cnt; i += 256 * 16) {
+            if (i + 16 <= cnt) *(uint4*)(s_in + i) = *(const uint4*)(src + lo + i);
+            else for (uint32_t k = i; k < cnt; k++) s_in[k] = src[lo + k];
         }
-        const uint32_t incl = wave_scan_incl(sz);
-        __syncthreads();
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t off = s_carry + incl - sz;
-        for (int w = 0; w < wave; w++) off += s_wave[w];
-        const uint32_t passTotal = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        if (SCATTER) {
-            lnz = before;
-            for (uint32_t j = 0; j < 32 && p0 + j < hi; j++) {
-                const uint32_t i = p0 + j;
-                const uint8_t v = src[i];
-                if (v != 0) {
-                    if (v >= 0xFE) { dst[off++] = 0xFF; dst[off++] = (uint8_t)(v - 0xFE); }
-                    else dst[off++] = (uint8_t)(v + 1);
-                    lnz = (int)i;
-                } else if (!(i + 1 < n && src[i + 1] == 0)) {
-                    const uint32_t run = (uint32_t)((int)i - lnz) + 1;          // runLength = k + 1 (:88)
-                    uint32_t lg = 31u - (uint32_t)__builtin_clz(run);
-                    while (lg > 0) { lg--; dst[off++] = (uint8_t)((run >> lg) & 1); }
-                }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) { s_carry += passTotal; if (passMax > s_lastnz) s_lastnz = passMax; }
-        __syncthreads();
+    } else {
+        for (uint32_t i = tid; i < cnt; i += 256) s_in[i] = src[lo + i];
     }
-    if (!SCATTER && tid == 0) a.seg_b[blockIdx.x] = (int32_t)s_carry;
+    if (tid == 0) s_in[cnt] = hi < n ? src[hi] : (uint8_t)1;                // the byte behind the segment (a zero run may go on there); behind the block: "not zero"
+    __syncthreads();
+    const uint32_t x0 = (uint32_t)tid * 32, p0 = lo + x0;
+    const uint32_t mine = x0 < cnt ? min(32u, cnt - x0) : 0u;
+    // last non-zero before p0: scan of the per-thread maxima of the previous threads
+    int myMax = -1;
+    for (uint32_t j = 0; j < mine; j++) if (s_in[x0 + j] != 0) myMax = (int)(p0 + j);
+    int m = myMax;
+    for (int d = 1; d < 64; d <<= 1) { int t = (int)wave_shfl((uint32_t)m, lane - d); if (lane >= d && t > m) m = t; }
+    if (lane == 63) s_wave[wave] = (uint32_t)m;
+    __syncthreads();
+    int before = lastnz0;
+    for (int w = 0; w < wave; w++) { int t = (int)s_wave[w]; if (t > before) before = t; }
+    int exclusive = (int)wave_shfl((uint32_t)m, lane - 1);
+    if (lane == 0) exclusive = -1;
+    if (exclusive > before) before = exclusive;
+    // sizes of my elements (element = literal, or a zero run accounted at its last zero: ZRLT.go:76-124)
+    uint32_t sz = 0;
+    int lnz = before;
+    for (uint32_t j = 0; j < mine; j++) {
+        const uint8_t v = s_in[x0 + j];
+        if (v != 0) { sz += v >= 0xFE ? 2u : 1u; lnz = (int)(p0 + j); }
+        else if (s_in[x0 + j + 1] != 0) sz += 31u - (uint32_t)__builtin_clz((uint32_t)((int)(p0 + j) - lnz) + 1);
+    }
+    const uint32_t incl = wave_scan_incl(sz);
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t off = incl - sz;                                               // inside the segment's output
+    for (int w = 0; w < wave; w++) off += s_wave[w];
+    const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (!SCATTER) { if (tid == 0) a.seg_b[blockIdx.x] = (int32_t)total; return; }
+    lnz = before;
+    for (uint32_t j = 0; j < mine; j++) {
+        const uint32_t i = p0 + j;
+        const uint8_t v = s_in[x0 + j];
+        if (v != 0) {
+            if (v >= 0xFE) { s_o[off++] = 0xFF; s_o[off++] = (uint8_t)(v - 0xFE); }
+            else s_o[off++] = (uint8_t)(v + 1);
+            lnz = (int)i;
+        } else if (s_in[x0 + j + 1] != 0) {
+            const uint32_t run = (uint32_t)((int)i - lnz) + 1;              // runLength = k + 1 (:88)
+            uint32_t lg = 31u - (uint32_t)__builtin_clz(run);
+            while (lg > 0) { lg--; s_o[off++] = (uint8_t)((run >> lg) & 1); }
+        }
+    }
+    __syncthreads();
+    // the segment's output: bytes up to the first 4-byte boundary of the destination, whole words, the rest
+    uint8_t* out = dst + carry0;
+    const uint32_t head = min(total, (uint32_t)((4 - ((uintptr_t)out & 3)) & 3));
+    if ((uint32_t)tid < head) out[tid] = s_o[tid];
+    const uint32_t words = (total - head) >> 2;
+    for (uint32_t wq = tid; wq < words; wq += 256) {
+        const uint8_t* q = s_o + head + 4 * wq;
+        *(uint32_t*)(out + head + 4 * wq) = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+    }
+    const uint32_t done = head + 4 * words;
+    if ((uint32_t)tid < total - done) out[done + tid] = s_o[done + tid];
 }
 
 // 4) per block: exclusive scan of the segment sizes, total, and the "would not fit in len(src)" test (ZRLT.go:93,109,118,132):
