@@ -279,6 +279,8 @@ def main():
     ap.add_argument("--transform", default="", help="override the transform sequence of the config, e.g. LZP or BWT+SRT+ZRLT (debug)")
     ap.add_argument("--entropy", default="", help="override the entropy codec of the config (debug)")
     ap.add_argument("--copies", type=int, default=1, help="corpus copies in the one stream (single-GPU saturation curve: MB/s against blocks in flight)")
+    ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, sharded encode, gather, assembly, collectives) at world size 1: "
+                                                              "puts RCCL under bench.py on a one-GPU box (debug / pre-flight of the driver's multi-GPU run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes (roofline.traffic = null)")
@@ -293,11 +295,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     emu = os.environ.get("KNZ_BENCH_EMU") == "1"          # test harness only, see the module docstring
+    multi = world > 1 or args.force_dist                  # the distributed code path
+    if args.force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
     if emu:
         import knz
         dev = torch.device("cpu")
         sync = lambda: None
-        if world > 1:
+        if multi:
             dist.init_process_group("gloo")
         K = knz.package()
         lib = knz.emu_library()
@@ -307,7 +313,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         sync = torch.cuda.synchronize
-        if world > 1:
+        if multi:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group("nccl", device_id=dev)
         K = load_pkg()
@@ -356,7 +362,7 @@ def main():
     cap = (per * bs + (per * bs) // 2 + (1 << 20) + 15) & ~15
     d_seg = dev_zeros(cap)
     d_back = dev_zeros(n_my + 4096)
-    d_stream = dev_zeros(size + size // 2 + (1 << 20)) if rank == 0 and world > 1 else None
+    d_stream = dev_zeros(size + size // 2 + (1 << 20)) if rank == 0 and multi else None
     # the steps run on a stream of their own (non-blocking): a NULL stream would mean the handle's own stream, which is ordered against
     # the legacy default stream and pays that ordering on every launch (visible on the microsecond-scale configs)
     bench_stream = None if emu else torch.cuda.Stream(device=dev)
@@ -376,7 +382,7 @@ def main():
     def one_step(timed):
         nonlocal t_enc, t_dec
         t0 = time.perf_counter()
-        if world == 1:
+        if not multi:
             nb = codec.dev_compress(d_src.data_ptr(), n_my, d_seg.data_ptr(), cap, header_input_size=size, stream=stream)
             result["stream_bytes"] = nb
         else:
@@ -387,19 +393,19 @@ def main():
         tm = codec.last_timing()
         if timed:
             add_kernels(codec)
-        if world == 1:
+        if not multi:
             sync()
         t1 = time.perf_counter()
-        if world == 1:
+        if not multi:
             nd = codec.dev_decompress(d_seg.data_ptr(), result["stream_bytes"], d_back.data_ptr(), d_back.numel(), stream=stream)
         else:
             nd = codec.dev_decompress_blocks(d_seg.data_ptr(), result["seg_bits"], d_back.data_ptr(), d_back.numel(), stream=stream) if n_my else 0
-        td = codec.last_timing() if (world == 1 or n_my) else [0.0] * 4
-        if timed and (world == 1 or n_my):
+        td = codec.last_timing() if (not multi or n_my) else [0.0] * 4
+        if timed and (not multi or n_my):
             add_kernels(codec)
         sync()
         t2 = time.perf_counter()
-        if world > 1:
+        if multi:
             nb, _ = pending.finish()
             sync()
             t3 = time.perf_counter()
@@ -418,18 +424,18 @@ def main():
         torch.cuda.set_stream(bench_stream)                   # torch.distributed orders its collectives against the current stream
     for _ in range(args.warmup):
         one_step(False)
-    if world > 1:
+    if multi:
         dist.barrier()
     sync()
     t_start = time.perf_counter()
     for _ in range(args.steps):
         one_step(True)
     sync()
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     rank_kernel_max = None
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed, t_enc, t_dec], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, t_enc, t_dec = [float(x) for x in tt.tolist()]
@@ -441,7 +447,7 @@ def main():
         rank_kernel_max = {k: max(g.get(k, 0.0) for g in gathered) for k in allk}
 
     ok_roundtrip = bool(torch.equal(d_back[:n_my], d_src[:n_my])) if n_my else True
-    if world > 1:                                            # every rank's decode must have come back right
+    if multi:                                            # every rank's decode must have come back right
         okt = torch.tensor([1 if ok_roundtrip else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok_roundtrip = bool(int(okt.item()))
@@ -469,7 +475,7 @@ def main():
             out["reference_published"] = PUBLISHED[args.config]
         # roofline of the dominant KERNEL: HIP events around its launches on the launch stream (knz_last_kernel_times)
         n_local = n_my
-        c_local = (result.get("seg_bits", C_bytes * 8) + 7) // 8 if world > 1 else C_bytes
+        c_local = (result.get("seg_bits", C_bytes * 8) + 7) // 8 if multi else C_bytes
         try:
             m_local = codec.last_counter(1) or n_local            # bytes behind the transforms (entropy coder input) of the last encode batch
         except Exception:   # noqa: BLE001
@@ -519,7 +525,7 @@ def main():
                          "timing": "HIP events around the kernel's launches on the launch stream (knz_last_kernel_times)",
                          "kernel_ms_per_step": {k: round(v / K_, 3) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])[:12]},
                          "kernel_launches_per_step": {k: round(kern_launches[k] / K_, 2) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])[:12]}})
-            if not args.no_pmc and world == 1 and not emu:
+            if not args.no_pmc and not multi and not emu:
                 # (fpaq: one 10^9-byte step is ~35 s of two serial chains per block; its counter passes run a single step)
                 child = ["--config", args.config, "--steps", "1" if args.config == "fpaq" else "2", "--warmup", "0" if args.config == "fpaq" else "1",
                          "--no-cpu-baseline", "--no-verify", "--no-pmc", "--no-host-hook"]
@@ -588,7 +594,7 @@ def main():
                 out["fallback_counters_last_batch"] = fb
         if entropy == "FPAQ":
             out["chain_bound"] = True          # one binary arithmetic-coding chain per block by format (DESIGN.md "FPAQ"): flat in the block count
-            if world == 1 and not emu and not args.no_cpu_baseline:
+            if not multi and not emu and not args.no_cpu_baseline:
                 try:
                     out["fpaq_stage"] = fpaq_stage_comparison(base, nblocks, kern_ms.get("knz_fpaq_encode_kernel", 0.0) / K_, kern_ms.get("knz_fpaq_decode_kernel", 0.0) / K_, m_local)
                 except Exception as e:   # noqa: BLE001
@@ -600,18 +606,18 @@ def main():
         if not args.no_verify:
             import oracle_lib as O
             exp = O.compress(tiled(0, size), transform, entropy, bs, 0, jobs=os.cpu_count() or 1)
-            got = (d_seg if world == 1 else d_stream)[:C_bytes].cpu().numpy().tobytes()
+            got = (d_seg if not multi else d_stream)[:C_bytes].cpu().numpy().tobytes()
             out["bit_exact_vs_oracle"] = bool(got == exp)
             out["parity_note"] = "oracle = in-repo C++ restatement of kanzi-go; no Go toolchain in the image, so no reference-generated stream pins it (DESIGN.md section 2)"
-        if world == 1 and not emu and not args.no_host_hook:
+        if not multi and not emu and not args.no_host_hook:
             try:
                 out["host_hook_MBps"] = host_hook_rate(K, (transform, entropy, bs, 0, local_rank), base[:size], bs)
             except Exception as e:   # noqa: BLE001
                 out["host_hook_MBps"] = {"error": str(e)}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not multi:
             out["cpu_baseline"] = cpu_baseline(base, transform, entropy, bs)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
