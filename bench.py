@@ -296,6 +296,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     emu = os.environ.get("KNZ_BENCH_EMU") == "1"          # test harness only, see the module docstring
     multi = world > 1 or args.force_dist                  # the distributed code path
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to the C stdout of every rank (seen behind the JSON line when the
+    # buffer is flushed at exit), so with a process group every rank sends file descriptor 1 to stderr and rank 0 keeps the real one for its line
+    json_out = sys.stdout
+    if multi:
+        sys.stdout.flush()
+        real = os.dup(1)
+        os.dup2(2, 1)
+        json_out = os.fdopen(real, "w")
     if args.force_dist and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
@@ -616,7 +624,7 @@ def main():
                 out["host_hook_MBps"] = {"error": str(e)}
         if not args.no_cpu_baseline and not multi:
             out["cpu_baseline"] = cpu_baseline(base, transform, entropy, bs)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
