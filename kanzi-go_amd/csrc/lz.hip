@@ -46,12 +46,6 @@ __device__ __forceinline__ uint32_t knz_le32(const uint8_t* p) {
 }
 __device__ __forceinline__ uint64_t knz_le64(const uint8_t* p) { return (uint64_t)knz_le32(p) | ((uint64_t)knz_le32(p + 4) << 32); }
 
-// per-lane unaligned 8-byte load (one global_load_dwordx2: gfx950 runs with unaligned access enabled)
-struct __attribute__((packed)) KnzPacked64 { uint64_t v; };
-__device__ __forceinline__ uint64_t knz_vle64(const uint8_t* p) { return ((const KnzPacked64*)p)->v; }
-struct __attribute__((packed)) KnzPacked32 { uint32_t v; };
-__device__ __forceinline__ uint32_t knz_vle32(const uint8_t* p) { return ((const KnzPacked32*)p)->v; }
-
 // wave-uniform little-endian reads of the (read-only) source through the scalar cache: the aligned dwords around p, shifted
 __device__ __forceinline__ uint64_t knz_sle64(const uint8_t* p) {
     const uintptr_t a = (uintptr_t)p & ~(uintptr_t)3;

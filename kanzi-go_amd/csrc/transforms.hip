@@ -234,10 +234,28 @@ __global__ __launch_bounds__(64) void knz_sbrt_seg_last2_kernel(XfArgs a) {
     const uint8_t* src = (const uint8_t*)a.in_ptr[b];
     for (int i = lane; i < 256; i += 64) { s_last[i] = -1; s_prev[i] = -1; }
     wave_sync();
-    for (uint32_t i = lo + lane; i < hi; i += 64) atomicMax(&s_last[src[i]], (int)i);
-    wave_sync();
-    for (uint32_t i = lo + lane; i < hi; i += 64) { const uint8_t c = src[i]; if ((int)i != s_last[c]) atomicMax(&s_prev[c], (int)i); }
-    wave_sync();
+    // A lane takes 16 consecutive positions per trip (one 16-byte read) and leaves out the positions that cannot be an answer: one followed by
+    // the same symbol is not its last occurrence, one followed by it twice is not the last but one either (behind a BWT most positions are
+    // inside a run: a byte per lane and trip with every position an LDS atomic on the same counter was 0.96 ms for 212 MB).
+    for (int pass = 0; pass < 2; pass++) {
+        for (uint32_t p0 = lo + 16u * lane; p0 < hi; p0 += 16u * 64u) {
+            const uint32_t cnt = min(16u, hi - p0);
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            if (cnt == 16u) { const uint64_t a0 = knz_vle64(src + p0), a1 = knz_vle64(src + p0 + 8); w[0] = (uint32_t)a0; w[1] = (uint32_t)(a0 >> 32); w[2] = (uint32_t)a1; w[3] = (uint32_t)(a1 >> 32); }
+            else for (uint32_t j = 0; j < cnt; j++) w[j >> 2] |= (uint32_t)src[p0 + j] << (8u * (j & 3u));
+#pragma unroll
+            for (uint32_t j = 0; j < 16u; j++) {
+                if (j >= cnt) break;
+                const uint32_t c = (w[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
+                const bool same1 = j + 1u < cnt && ((w[(j + 1u) >> 2] >> (8u * ((j + 1u) & 3u))) & 0xFFu) == c;
+                const bool same2 = j + 2u < cnt && ((w[(j + 2u) >> 2] >> (8u * ((j + 2u) & 3u))) & 0xFFu) == c;
+                const int i = (int)(p0 + j);
+                if (pass == 0) { if (!same1) atomicMax(&s_last[c], i); }
+                else if (!(same1 && same2)) { if (i != s_last[c]) atomicMax(&s_prev[c], i); }
+            }
+        }
+        wave_sync();
+    }
     for (int i = lane; i < 256; i += 64) { oa[i] = s_last[i]; ob[i] = s_prev[i]; }
 }
 
@@ -249,12 +267,18 @@ __global__ __launch_bounds__(256) void knz_sbrt_carry_kernel(XfArgs a) {
     const uint32_t n = a.in_len[b];
     const uint32_t nseg = (n + KNZ_SEG - 1) / KNZ_SEG;
     int last = -1, prev = -1;
-    for (uint32_t s = 0; s < nseg; s++) {
-        int32_t* pa = a.seg_a + ((size_t)b * a.segs_per_block + s) * 256 + d;
-        int32_t* pb = a.seg_b + ((size_t)b * a.segs_per_block + s) * 256 + d;
-        const int li = *pa, pi = *pb;
-        *pa = last; *pb = prev;
-        if (li >= 0) { prev = pi >= 0 ? pi : last; last = li; }
+    int32_t* pa = a.seg_a + (size_t)b * a.segs_per_block * 256 + d;
+    int32_t* pb = a.seg_b + (size_t)b * a.segs_per_block * 256 + d;
+    for (uint32_t s0 = 0; s0 < nseg; s0 += 8) {                             // (eight segments' reads in flight: the in-place update read and wrote one segment per memory latency)
+        int li[8], pi[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) { const bool in = s0 + k < nseg; li[k] = in ? pa[(size_t)(s0 + k) * 256] : -1; pi[k] = in ? pb[(size_t)(s0 + k) * 256] : -1; }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) {
+            if (s0 + k >= nseg) break;
+            pa[(size_t)(s0 + k) * 256] = last; pb[(size_t)(s0 + k) * 256] = prev;
+            if (li[k] >= 0) { prev = pi[k] >= 0 ? pi[k] : last; last = li[k]; }
+        }
     }
 }
 
