@@ -311,7 +311,7 @@ __device__ __forceinline__ bool knz_lzs_live(const LzSegArgs& g, uint32_t b, uin
     return (int)(s * (uint64_t)g.seg_size) < srcEnd && g.entry[5 * ((size_t)b * g.segs + s)] < segEnd;
 }
 
-// one thread per block: the entry states of the next round, and which segments run in it. The exit of a segment is known for the entry
+// one wave per block: the entry states of the next round, and which segments run in it. The exit of a segment is known for the entry
 // state its last parse started from; a segment whose entry state lies at or behind its end has nothing to parse and hands the state on
 // unchanged.
 //   * A block that has never had a jumped-over position has empty maps whatever its segments do: the segments whose entry state is new run.
@@ -322,37 +322,61 @@ __device__ __forceinline__ bool knz_lzs_live(const LzSegArgs& g, uint32_t b, uin
 //     about a cell whose words moved in this round run again (qhit); the others' stretches of the maps are copied into the next
 //     generation [knz_lzs_carry_kernel]. A trace that is not run again is, by induction over the rounds, what a parse against the
 //     latest maps would produce, so "nothing to run" is the same fixed point as before.
+// (Round 4: one WAVE per block. The walk over the segments is sequential in the state it hands on, but nothing it reads depends on that state: the
+// (used, exit) pairs of 512 segments are staged in LDS by all lanes, lane 0 walks them there, the new entry states go back in rows, and the
+// "who runs" pass is one segment per lane. One thread per block did the same walk through ~15 dependent global reads per segment: 0.8 ms per round.)
+#define KNZ_LZS_RL_CHUNK 512u
 __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_t round) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_u[KNZ_LZS_RL_CHUNK * 5], s_x[KNZ_LZS_RL_CHUNK * 5], s_e[KNZ_LZS_RL_CHUNK * 5];
+    __shared__ uint32_t s_nt[KNZ_LZS_RL_CHUNK];
+    __shared__ uint32_t s_res[8];
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
     const LzArgs& a = g.pa.a;
     if (b >= a.nblocks || g.blk_state[b] != 0) return;
     const int count = (int)a.in_len[b];
     const int srcEnd = count - 18;
     const uint32_t ns = srcEnd > 0 ? ((uint32_t)srcEnd + g.seg_size - 1) / g.seg_size : 0;
     const bool mapsChanged = g.blk_flags[4 * b + 1] != 0;
-    g.blk_flags[4 * b + 1] = 0;
     uint32_t cur[5] = {0, 0, (uint32_t)count, (uint32_t)count, 0};
     bool changed = false, overflow = false;
-    for (uint32_t s = 0; s < ns; s++) {
-        const size_t si = (size_t)b * g.segs + s;
-        uint32_t* E = g.entry + 5 * si;
-        const uint32_t* U = g.used + 5 * si;
-        const uint32_t* X = g.exit_ + 5 * si;
-        for (int k = 0; k < 5; k++) E[k] = cur[k];
-        const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
-        if (cur[0] >= segEnd) {                                               // nothing to parse here: the state passes through
-            // A trace this segment recorded while it still had something to parse is dead now, but its bits may sit in the maps (its stretch was
-            // carried while it was live, and the stretch of the predecessor that now runs over it is carried from then on): forget the trace and
-            // have every live segment run, so that the next generation of the maps is written by live traces only.
-            if (g.used[5 * si] != KNZ_LZS_NEVER) { g.used[5 * si] = KNZ_LZS_NEVER; changed = true; }
-            continue;
+    for (uint32_t c0 = 0; c0 < ns; c0 += KNZ_LZS_RL_CHUNK) {
+        const uint32_t cnt = min(KNZ_LZS_RL_CHUNK, ns - c0);
+        const size_t si0 = (size_t)b * g.segs + c0;
+        for (uint32_t i = lane; i < cnt * 5; i += 64) { s_u[i] = g.used[5 * si0 + i]; s_x[i] = g.exit_[5 * si0 + i]; }
+        for (uint32_t i = lane; i < cnt; i += 64) s_nt[i] = g.ntok[si0 + i];
+        wave_sync();
+        if (lane == 0) {
+            for (uint32_t k = 0; k < cnt; k++) {
+                const uint32_t s = c0 + k;
+                uint32_t* E = s_e + 5 * k;
+                const uint32_t* U = s_u + 5 * k;
+                const uint32_t* X = s_x + 5 * k;
+                for (int q = 0; q < 5; q++) E[q] = cur[q];
+                const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
+                if (cur[0] >= segEnd) {                                           // nothing to parse here: the state passes through
+                    // A trace this segment recorded while it still had something to parse is dead now, but its bits may sit in the maps (its stretch was
+                    // carried while it was live, and the stretch of the predecessor that now runs over it is carried from then on): forget the trace and
+                    // have every live segment run, so that the next generation of the maps is written by live traces only.
+                    if (U[0] != KNZ_LZS_NEVER) { s_u[5 * k] = KNZ_LZS_NEVER; changed = true; }
+                    continue;
+                }
+                const bool same = U[0] == cur[0] && U[1] == cur[1] && U[2] == cur[2] && U[3] == cur[3] && U[4] == cur[4];
+                if (!same) changed = true;
+                else if (s_nt[k] == KNZ_LZS_NEVER) overflow = true;
+                if (U[0] != KNZ_LZS_NEVER) for (int q = 0; q < 5; q++) cur[q] = X[q];   // exact when `same`, the best guess otherwise
+            }
         }
-        const bool same = U[0] == cur[0] && U[1] == cur[1] && U[2] == cur[2] && U[3] == cur[3] && U[4] == cur[4];
-        if (!same) changed = true;
-        else if (g.ntok[si] == KNZ_LZS_NEVER) overflow = true;
-        if (U[0] != KNZ_LZS_NEVER) for (int k = 0; k < 5; k++) cur[k] = X[k];   // exact when `same`, the best guess otherwise
+        wave_sync();
+        for (uint32_t i = lane; i < cnt * 5; i += 64) g.entry[5 * si0 + i] = s_e[i];
+        for (uint32_t i = lane; i < cnt; i += 64) g.used[5 * (si0 + i)] = s_u[5 * i];
+        wave_sync();
     }
-    if (g.rprof) {
+    if (lane == 0) { s_res[0] = changed ? 1u : 0u; s_res[1] = overflow ? 1u : 0u; s_res[2] = cur[1]; }
+    __threadfence();
+    wave_sync();
+    changed = s_res[0] != 0; overflow = s_res[1] != 0;
+    const uint32_t lastAnchor = s_res[2];
+    if (g.rprof && lane == 0) {
         uint32_t firstSeg = ns;
         for (uint32_t s = 0; s < ns; s++) {
             const size_t si = (size_t)b * g.segs + s;
@@ -364,50 +388,70 @@ __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_
         uint32_t* R = g.rprof + ((size_t)round * a.nblocks + b) * 3;
         R[0] = firstSeg | (ns << 16); R[1] = g.blk_flags[4 * b + 3];
     }
-    g.blk_flags[4 * b + 3] = 0xFFFFFFFFu;
     const bool holey = (g.Sp[2 * b] | g.Sn[2 * b]) != 0;
     const bool everyone = holey && (changed || (g.Sp[2 * b] != 0) != (g.Sn[2 * b] != 0) || (g.all_again && mapsChanged));
-    bool again = false;
     uint32_t nrun = 0;
-    for (uint32_t s = 0; s < ns; s++) {
-        const size_t si = (size_t)b * g.segs + s;
-        const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
-        const uint32_t* E = g.entry + 5 * si;
-        const uint32_t* U = g.used + 5 * si;
-        const bool same = U[0] == E[0] && U[1] == E[1] && U[2] == E[2] && U[3] == E[3] && U[4] == E[4];
-        const bool run = E[0] < segEnd && (everyone || !same || (holey && !g.all_again && g.qhit[si] != 0));
-        g.need[si] = run ? 1 : 0;
-        again |= run;
-        nrun += run ? 1u : 0u;
+    for (uint32_t s0 = 0; s0 < ns; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        bool run = false;
+        if (s < ns) {
+            const size_t si = (size_t)b * g.segs + s;
+            const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
+            const uint32_t* E = g.entry + 5 * si;
+            const uint32_t* U = g.used + 5 * si;
+            const bool same = U[0] == E[0] && U[1] == E[1] && U[2] == E[2] && U[3] == E[3] && U[4] == E[4];
+            run = E[0] < segEnd && (everyone || !same || (holey && !g.all_again && g.qhit[si] != 0));
+            g.need[si] = run ? 1 : 0;
+        }
+        nrun += (uint32_t)__popcll((unsigned long long)wave_ballot(run));
     }
-    if (g.rprof) g.rprof[((size_t)round * a.nblocks + b) * 3 + 2] = nrun;
-    g.blk_flags[4 * b] = cur[1];                                              // anchor behind the last match (used when the block has settled)
-    g.blk_flags[4 * b + 2] = round + 1;
-    if (overflow) g.blk_state[b] = 2;
-    else if (!again) g.blk_state[b] = 1;
-    else if (round + 1 >= KNZ_LZS_MAX_ROUNDS) g.blk_state[b] = 2;
+    if (lane == 0) {
+        if (g.rprof) g.rprof[((size_t)round * a.nblocks + b) * 3 + 2] = nrun;
+        g.blk_flags[4 * b + 1] = 0;
+        g.blk_flags[4 * b + 3] = 0xFFFFFFFFu;
+        g.blk_flags[4 * b] = lastAnchor;                                          // anchor behind the last match (used when the block has settled)
+        g.blk_flags[4 * b + 2] = round + 1;
+        if (overflow) g.blk_state[b] = 2;
+        else if (nrun == 0) g.blk_state[b] = 1;
+        else if (round + 1 >= KNZ_LZS_MAX_ROUNDS) g.blk_state[b] = 2;
+    }
 }
 
-// which map words differ from the previous round's, as coarse cells; grid (ceil(words / 256), nblocks)
+// which map words differ from the previous round's, as coarse cells
+// (Round 4: four words per thread through 16-byte reads; the cells and the "first word that moved" of a workgroup are combined in LDS and leave
+// through a few global atomics; one atomic per moved word and two per wave on a handful of addresses per block were most of the kernel's 0.48 ms.)
+// grid (ceil(words / 1024), nblocks); map_stride is a multiple of 4 words
 __global__ __launch_bounds__(256) void knz_lzs_compare_kernel(LzSegArgs g, uint32_t words) {
+    __shared__ uint32_t s_c[17];                                              // 1024 words = 32768 positions = at most 512 cells
+    __shared__ uint32_t s_first;
     const uint32_t b = blockIdx.y;
     if (g.blk_state[b] != 0) return;
-    const uint32_t w = blockIdx.x * 256 + threadIdx.x;
-    bool diff = false;
-    if (w < words) {
-        const size_t i = (size_t)b * g.map_stride + w;
-        diff = g.Jp[i] != g.Jn[i] || g.Mp[i] != g.Mn[i];
+    if (threadIdx.x < 17) s_c[threadIdx.x] = 0;
+    if (threadIdx.x == 17) s_first = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t w0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    uint32_t dmask = 0;
+    if (w0 < words) {                                                         // (words is a multiple of 4 too)
+        const size_t i = (size_t)b * g.map_stride + w0;
+        const uint4 jp = *(const uint4*)(g.Jp + i), jn = *(const uint4*)(g.Jn + i), mp = *(const uint4*)(g.Mp + i), mn = *(const uint4*)(g.Mn + i);
+        dmask = ((jp.x != jn.x || mp.x != mn.x) ? 1u : 0u) | ((jp.y != jn.y || mp.y != mn.y) ? 2u : 0u) |
+                ((jp.z != jn.z || mp.z != mn.z) ? 4u : 0u) | ((jp.w != jn.w || mp.w != mn.w) ? 8u : 0u);
     }
-    if (diff) {
-        unsigned cs = 6;
-        while ((g.pa.a.in_len[b] >> cs) >= 32u * KNZ_LZS_COARSE) cs++;
-        const uint32_t cell = (w * 32u) >> cs;                               // a word of 32 positions lies inside one cell (cs >= 6)
-        atomicOr(&g.cmap[(size_t)b * KNZ_LZS_COARSE + (cell >> 5)], 1u << (cell & 31));
+    unsigned cs = 6;
+    while ((g.pa.a.in_len[b] >> cs) >= 32u * KNZ_LZS_COARSE) cs++;
+    const uint32_t cw0 = ((blockIdx.x * 1024u * 32u) >> cs) >> 5;            // first word of the coarse map this workgroup can touch
+    if (dmask) {
+        for (uint32_t k = 0; k < 4u; k++) if (dmask & (1u << k)) {
+            const uint32_t cell = ((w0 + k) * 32u) >> cs;                    // a word of 32 positions lies inside one cell (cs >= 6)
+            atomicOr(&s_c[(cell >> 5) - cw0], 1u << (cell & 31));
+        }
+        atomicMin(&s_first, w0 + (uint32_t)__ffs((int)dmask) - 1u);
     }
-    const uint64_t dm = wave_ballot(diff);
-    if (dm != 0 && (threadIdx.x & 63) == 0) {
+    __syncthreads();
+    if (threadIdx.x < 17) { const uint32_t v = s_c[threadIdx.x]; if (v) atomicOr(&g.cmap[(size_t)b * KNZ_LZS_COARSE + cw0 + threadIdx.x], v); }
+    if (threadIdx.x == 17 && s_first != 0xFFFFFFFFu) {
         g.blk_flags[4 * b + 1] = 1;
-        atomicMin(&g.blk_flags[4 * b + 3], w + (uint32_t)(__ffsll((unsigned long long)dm) - 1));   // (diagnostics: the first word that moved)
+        atomicMin(&g.blk_flags[4 * b + 3], s_first);                          // (diagnostics: the first word that moved)
     }
 }
 
