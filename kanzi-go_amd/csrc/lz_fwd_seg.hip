@@ -66,6 +66,14 @@ __device__ __forceinline__ void knz_lzs_geom(const LzArgs& a, uint32_t b, int co
     flag |= ((minMatch - 2) & 7) << 1;
 }
 
+// a question about a position in front of the segment's entry: sets the cell's bit in the query log (.x) and returns the cell's bit of the coarse
+// hole map (.y); every lane writes the same word and the wave is the only writer of its log, so no atomic is needed
+__device__ __forceinline__ uint32_t knz_lzs_query_logged(uint32_t* qc, uint32_t q, uint32_t sh5, uint32_t sh) {
+    const uint32_t cw = q >> sh5, cb = 1u << ((q >> sh) & 31);
+    qc[2 * cw] |= cb;
+    return wave_uniform(qc[2 * cw + 1] & cb);
+}
+
 // one thread per block: does the block take part, initial entry states
 __global__ __launch_bounds__(64) void knz_lzs_init_kernel(LzSegArgs g) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -101,8 +109,9 @@ __global__ __launch_bounds__(64) void knz_lzs_init_kernel(LzSegArgs g) {
 }
 
 __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
-    __shared__ uint32_t s_coarse[KNZ_LZS_COARSE];                       // 2 KiB: the waves of a CU are limited by their wave slots, not by LDS
-    __shared__ uint32_t s_q[KNZ_LZS_COARSE];                            // the cells in front of the entry state this parse asks about
+    // per coarse word: .x = the cells in front of the entry state this parse asks about (its query log), .y = the coarse hole map; side by side, so
+    // that a query is ONE LDS read (4 KiB: the waves of a CU are limited by their wave slots, not by LDS)
+    __shared__ uint2 s_qc[KNZ_LZS_COARSE];
     const LzArgs& a = g.pa.a;
     const int lane = threadIdx.x;
     const bool writer = lane == 0;
@@ -128,30 +137,52 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
     uint32_t* Cn = g.Cn + (size_t)b * KNZ_LZS_COARSE;
     unsigned cs = 6;
     while (((uint32_t)count >> cs) >= 32u * KNZ_LZS_COARSE) cs++;
-    { const uint32_t* Cp = g.Cp + (size_t)b * KNZ_LZS_COARSE; for (int i = lane; i < (int)KNZ_LZS_COARSE; i += 64) { s_coarse[i] = Cp[i]; s_q[i] = 0; } }
+    { const uint32_t* Cp = g.Cp + (size_t)b * KNZ_LZS_COARSE; for (int i = lane; i < (int)KNZ_LZS_COARSE; i += 64) { uint2 v; v.x = 0; v.y = Cp[i]; s_qc[i] = v; } }
     wave_sync();
     // What a parse takes from the previous round: whether the block had any jumped-over position (a change of that runs every segment
-    // again), and the hole bits of the cells it asks about (logged in s_q; relink runs it again when one of those cells moved).
+    // again), and the hole bits of the cells it asks about (logged in s_qc[].x; relink runs it again when one of those cells moved).
     // Nothing else: the largest hole only gates questions about positions this parse has passed itself.
-    bool anyHoles = g.Sp[2 * b] != 0;
+    uint32_t anyHoles = g.Sp[2 * b] != 0 ? 1u : 0u;                          // (an integer, like the other wave-uniform flags the loop carries: a carried `bool` lives in a 64-bit lane mask and costs three scalar instructions wherever paths meet)
     int maxHole = -1;                                                         // the largest position this parse jumped over
     uint32_t ntok = 0;
     uint4* tokOut = g.tok + si * g.tok_cap;
-    bool overflow = false;
+    uint32_t overflow = 0;
 #if !defined(KNZ_HIP_EMU)
 #define KNZ_LZS_NOW() (unsigned long long)__builtin_readcyclecounter()
 #else
 #define KNZ_LZS_NOW() 0ull
 #endif
     const unsigned long long t0 = g.sprof ? KNZ_LZS_NOW() : 0ull;
-    uint32_t nSteps = 0, nChain = 0;
+#ifdef KNZ_MEASURE
+    uint32_t nSteps = 0, nChain = 0;                                          // (KNZ_LZS_PROF diagnostics: two scalar instructions per step that the product build does not pay)
+#define KNZ_LZS_COUNT(X) (X)++
+#else
+    const uint32_t nSteps = 0, nChain = 0;
+#define KNZ_LZS_COUNT(X) (void)0
+#endif
 
+// (an empty statement with side effects between two nested tests of wave-uniform values: without it the compiler merges them into one
+// condition, which it evaluates as two 64-bit lane masks and an AND: eight scalar instructions where two compares and two branches do.
+// Measured on S-silesia, 5 rounds of parse: 73.6 ms without any, 71.6 with the three in the repeat / candidate tests, 69.6 with the ones in the
+// hole chain and the common-prefix test as well; more of them in the checkNext probes changed nothing. The loop-carried flags as integers
+// instead of `bool` and one compare for the loop's exit were 77.2 -> 73.6 before that.)
+#if !defined(KNZ_HIP_EMU)
+#define KNZ_LZS_KEEP_NESTED() asm volatile("")
+#else
+#define KNZ_LZS_KEEP_NESTED() (void)0
+#endif
 #define KNZ_LZS_CAND(P) ((int)wave_sload_u32(cand8 + (size_t)(uint32_t)(4u * (uint32_t)(P))))                       // (32-bit offsets: the scalar load takes base + offset, no 64-bit address arithmetic)
 #define KNZ_LZS_CP(P) ((int)((wave_sload_u32(cpA + (size_t)((cpo + (uint32_t)(P)) & ~3u)) >> (8 * ((cpo + (uint32_t)(P)) & 3u))) & 0xFFu))
     auto is_hole = [&](int q) -> bool {
-        if (q < eSrc) s_q[(uint32_t)q >> (cs + 5)] |= 1u << (((uint32_t)q >> cs) & 31);       // (every lane writes the same word: the wave is the only writer of its log, no atomic needed)
-        else if (q > maxHole) return false;
-        if (!((s_coarse[(uint32_t)q >> (cs + 5)] >> (((uint32_t)q >> cs) & 31)) & 1u)) return false;
+        // (the form of these lines is measured, like the nesting statements: the log update and the coarse test of a foreign question as one helper, each
+        // branch with its own wave-uniform result: 70.1 ms of parse; the same three steps written in line, 73.5; a hand-written 13-instruction block, 71.6)
+        uint32_t hit;
+        if (q < eSrc) hit = knz_lzs_query_logged((uint32_t*)s_qc, (uint32_t)q, cs + 5, cs);
+        else {
+            if (q > maxHole) return false;
+            hit = wave_uniform(s_qc[(uint32_t)q >> (cs + 5)].y & (1u << (((uint32_t)q >> cs) & 31)));
+        }
+        if (hit == 0) return false;
         const uint32_t w = (uint32_t)q >> 5, m = 1u << (q & 31);
         uint32_t bits;
         if (q >= eAnchor) {                                                   // own generation (written by this wave: device-scope loads, the bits are set by atomics at L2)
@@ -162,7 +193,7 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
     };
     auto true_cand = [&](int raw) -> int {
         int q = raw;
-        if (anyHoles) while (q > 0 && is_hole(q)) { q = KNZ_LZS_CAND(q); nChain++; }
+        if (anyHoles) while (q > 0) { KNZ_LZS_KEEP_NESTED(); if (!is_hole(q)) break; q = KNZ_LZS_CAND(q); KNZ_LZS_COUNT(nChain); }
         return q;
     };
     auto len_from_cp = [&](int cp, int maxMatch) -> int { const int whole = maxMatch & ~7; return cp < whole ? cp : whole; };
@@ -171,9 +202,8 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
     // kept by the compiler as a 64-bit lane mask, four scalar instructions where a compare and a branch do, and the rounds are bound by the
     // scalar unit.)
     for (;;) {
-        if (srcIdx >= srcEnd) break;
-        if (srcIdx >= segEnd) { if (srcInc < 64) break; }                     // hand over only when not skipping
-        nSteps++;
+        { const int stopAt = srcInc < 64 ? segEnd : srcEnd; if (srcIdx >= stopAt) break; }   // hand over only when not skipping (segEnd <= srcEnd; one select + one compare)
+        KNZ_LZS_COUNT(nSteps);
         int bestLen = 0;
         const int srcIdx1 = srcIdx + 1;
         const int nextPos = srcIdx1 + (srcInc >> 6);
@@ -193,8 +223,8 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
         int ref = refB;                                                       // (what the reference leaves in `ref` when neither repeat distance matches)
         const uint32_t p1 = (uint32_t)(p >> 8);
         int rep = 0;                                                          // 1: the first repeat distance matches, 2: the second
-        if (refA > minRef) { if (p1 == vA) rep = 1; }
-        if (rep == 0) { if (refB > minRef) { if (p1 == vB) rep = 2; } }
+        if (refA > minRef) { KNZ_LZS_KEEP_NESTED(); if (p1 == vA) rep = 1; }
+        if (rep == 0) { if (refB > minRef) { KNZ_LZS_KEEP_NESTED(); if (p1 == vB) rep = 2; } }
         if (rep != 0) {
             ref = rep == 1 ? refA : refB;
             bestLen = knz_lz_match_wave(src, srcIdx1, ref, maxMatch, lane);
@@ -205,8 +235,8 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
             if (ref > minRef) {
                 const int mm = min(srcEnd - srcIdx, KNZ_LZ_MAX_MATCH);
                 int viaCp = 0;
-                if (ref == raw0) { if (cp0 < 255) viaCp = 1; }
-                if (viaCp) { if (cp0 >= 4) { bestLen = len_from_cp(cp0, mm); if (bestLen >= minMatch) found = 1; } }
+                if (ref == raw0) { KNZ_LZS_KEEP_NESTED(); if (cp0 < 255) viaCp = 1; }
+                if (viaCp) { KNZ_LZS_KEEP_NESTED(); if (cp0 >= 4) { bestLen = len_from_cp(cp0, mm); KNZ_LZS_KEEP_NESTED(); if (bestLen >= minMatch) found = 1; } }
                 else if ((uint32_t)p == knz_sle32(src + ref)) { bestLen = knz_lz_match_wave(src, srcIdx, ref, mm, lane); if (bestLen >= minMatch) found = 1; }
             }
             if (found == 0) {
@@ -215,14 +245,14 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
                         const int q = q0 + lane;
                         if (q < nextPos) {
                             atomicOr(&Jn[q >> 5], 1u << (q & 31));
-                            atomicOr(&s_coarse[(uint32_t)q >> (cs + 5)], 1u << (((uint32_t)q >> cs) & 31));
+                            atomicOr(&s_qc[(uint32_t)q >> (cs + 5)].y, 1u << (((uint32_t)q >> cs) & 31));
                             atomicOr(&Cn[(uint32_t)q >> (cs + 5)], 1u << (((uint32_t)q >> cs) & 31));
                         }
                     }
                     wave_sync_lds();
                     wave_order_lanes();
                     if (writer) { atomicOr(&g.Sn[2 * b], 1u); atomicMax(&g.Sn[2 * b + 1], (uint32_t)(nextPos - 1)); }
-                    anyHoles = true;
+                    anyHoles = 1u;
                     maxHole = max(maxHole, nextPos - 1);
                 }
                 srcIdx = nextPos;
@@ -230,15 +260,18 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
                 repdIdx = 0;
                 continue;
             }
-            if (ref != srcIdx - repd0 && ref != srcIdx - repd1) {          // checkNext (:362-398)
+            int checkNext = 0;                                             // checkNext (:362-398)
+            if (ref != srcIdx - repd0) { if (ref != srcIdx - repd1) checkNext = 1; }
+            if (checkNext) {
                 {
                     const int raw1 = KNZ_LZS_CAND(srcIdx1), cp1 = KNZ_LZS_CP(srcIdx1);
                     const int ref1 = true_cand(raw1);
-                    if (ref1 > minRef + 1 && !(ref1 == raw1 && cp1 < 255 && cp1 < bestLen) &&
-                        knz_sle32(src + srcIdx1 + bestLen - 3) == knz_sle32(src + ref1 + bestLen - 3)) {
+                    int probe = 0;
+                    if (ref1 > minRef + 1) { if (!(ref1 == raw1 && cp1 < 255 && cp1 < bestLen)) probe = 1; }
+                    if (probe) { if (knz_sle32(src + srcIdx1 + bestLen - 3) == knz_sle32(src + ref1 + bestLen - 3)) {
                         const int bestLen1 = (ref1 == raw1 && cp1 < 255) ? len_from_cp(cp1, maxMatch) : knz_lz_match_wave(src, srcIdx1, ref1, maxMatch, lane);
                         if (bestLen1 >= bestLen) { ref = ref1; bestLen = bestLen1; srcIdx = srcIdx1; }
-                    }
+                    } }
                 }
                 if (a.extra) {
                     const int srcIdx2 = srcIdx1 + 1;
@@ -279,7 +312,7 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
         repd0 = dist;
         repdIdx = 1;
         if (ntok < g.tok_cap) { if (writer) { uint4 t; t.x = (uint32_t)anchor; t.y = (uint32_t)(srcIdx - anchor); t.z = (uint32_t)bestLen | (tflag << 24); t.w = (uint32_t)dist; tokOut[ntok] = t; } }
-        else overflow = true;
+        else overflow = 1u;
         ntok++;
         anchor = srcIdx + bestLen;
         // the reference hashes every position of the match now (:517-553): jumped-over positions under it are holes no longer
@@ -300,8 +333,10 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
         unsigned long long* P = g.sprof + 4 * si; P[0] += dt; P[1] = nSteps; P[2] = nChain; P[3] = dt;
     }
     wave_sync_lds();
-    { uint32_t* Q = g.qmap + si * KNZ_LZS_COARSE; for (int i = lane; i < (int)KNZ_LZS_COARSE; i += 64) Q[i] = s_q[i]; }
+    { uint32_t* Q = g.qmap + si * KNZ_LZS_COARSE; for (int i = lane; i < (int)KNZ_LZS_COARSE; i += 64) Q[i] = s_qc[i].x; }
 #undef KNZ_LZS_CAND
+#undef KNZ_LZS_KEEP_NESTED
+#undef KNZ_LZS_COUNT
 #undef KNZ_LZS_NOW
 #undef KNZ_LZS_CP
 }
