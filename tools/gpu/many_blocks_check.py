@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Batches of very many small blocks (default 70,000 blocks of 1 KiB) through the bench pipeline and the BWT alone: stream == oracle, round trip.
+"""Batches of very many small blocks (default 70,000 blocks of 1 KiB; arguments: blocks, block size, "transform/entropy,...") through the bench pipeline and the BWT alone: stream == oracle, round trip.
 (The suffix sort takes them as ONE group since round 4; rounds 1-3 split batches into groups of 1023 blocks.)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,10 @@ dev = torch.device("cuda", 0)
 src = torch.from_numpy(np.ascontiguousarray(data)).to(dev)
 dst = torch.zeros(2 * n + 64 * nblk + (1 << 20), dtype=torch.uint8, device=dev)
 back = torch.zeros(n + 4096, dtype=torch.uint8, device=dev)
-for transform, entropy in (("BWT", "NONE"), ("BWT+RANK+ZRLT", "ANS0"), ("BWT+RANK+ZRLT", "HUFFMAN")):
+pairs = (("BWT", "NONE"), ("BWT+RANK+ZRLT", "ANS0"), ("BWT+RANK+ZRLT", "HUFFMAN"))
+if len(sys.argv) > 3:                                                     # e.g. "BWT+RANK+ZRLT/ANS1,LZ/ANS0"
+    pairs = tuple(tuple(p.split("/")) for p in sys.argv[3].split(","))
+for transform, entropy in pairs:
     c = K.Codec(transform, entropy, bs)
     t0 = time.perf_counter()
     nb = c.dev_compress(src.data_ptr(), n, dst.data_ptr(), dst.numel())
