@@ -20,7 +20,9 @@
 // which is < h; the others carry rank + h), as in rounds 1-3.
 #include "bits.h"
 
-#define KNZ_SS_K0 6                       // symbols of the first key
+#ifndef KNZ_SS_K0
+#define KNZ_SS_K0 8                       // symbols of the first key (measured on S-silesia, DESIGN.md "Suffix sort": 4, 5, 6, 7, 8)
+#endif
 #define KNZ_SS_MASK 0x3FFFFFFFu           // slot numbers stay below 2^30 (KNZ_BWT_GROUP_BYTES)
 #define KNZ_SS_HEAD 0x80000000u           // list entry: the slot starts a group
 #define KNZ_SS_SINGLE 0x80000000u         // sort result: the item's new group has one member (final)

@@ -26,7 +26,7 @@
 #pragma once
 #include "bits.h"
 
-#define KNZ_LZS_SEG 8192u
+#define KNZ_LZS_SEG 4096u
 #define KNZ_LZS_MAX_ROUNDS 48
 #define KNZ_LZS_NEVER 0xFFFFFFFFu
 #define KNZ_LZS_COARSE 512u                          // words of the coarse hole map (one bit per 2^cs positions)
