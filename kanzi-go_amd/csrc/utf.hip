@@ -59,7 +59,9 @@ __global__ __launch_bounds__(KNZ_UTF_FWD_THREADS) void knz_utf_forward_kernel(Ut
     __shared__ uint32_t s_bad, s_cont;
     __shared__ int s_last;
     __shared__ uint64_t s_keys[1024];
-    const int tid = threadIdx.x;                                         // pass 1 (validation + histogram) runs on all 16 waves, the rest on wave 0
+    __shared__ uint32_t s_wt[KNZ_UTF_FWD_THREADS / 64];
+    __shared__ int s_go, s_stop;
+    const int tid = threadIdx.x;                                         // passes 1 (validation + histogram) and 3 (emission) run on all 16 waves, pass 2 on wave 0
     const int lane = tid & 63;
     const uint32_t b = blockIdx.x;
     if (!a.active[b]) return;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(KNZ_UTF_FWD_THREADS) void knz_utf_forward_kernel(Ut
     if (src[1] == 0xEF && src[2] == 0xBB && src[3] == 0xBF) start = 3;   // BigEndian.Uint32(src) & 0x00FFFFFF == 0xEFBBBF (:118)
     else while (start < 4 && knz_utf_size(src[start]) == 0) start++;
     const int end = count - 4;                                           // code points start in [start, end)
-    if (tid == 0) { s_n = 0; s_bad = 0; s_cont = 0; s_last = -1; }
+    if (tid == 0) { s_n = 0; s_bad = 0; s_cont = 0; s_last = -1; s_go = 0; s_stop = 0; }
     bool bad = false;
     if (chainMode && tid < 64) {
         // the reference's walk (:141-166), lane 0; marks the starts. (Only reachable with UTF twice in one sequence.)
@@ -149,19 +151,20 @@ __global__ __launch_bounds__(KNZ_UTF_FWD_THREADS) void knz_utf_forward_kernel(Ut
     }
     __threadfence();
     __syncthreads();
-    if (tid >= 64) return;
+    const int maxTarget = count - count / 10;
+    if (tid < 64) do {                                                   // wave 0: the decisions and the ranks; a decline leaves s_go at 0
     lastLead = s_last;
     const uint32_t n = s_n;
     const uint32_t contAll = s_cont;
     bad = s_bad != 0;
     if (!chainMode && contAll < (uint32_t)((end - start) / 8)) bad = true;   // ad-hoc threshold (:518)
-    const int maxTarget = count - count / 10;
-    if (bad || n == 0 || n >= KNZ_UTF_MAX_SYMS || 3 * (int)n + 6 >= maxTarget) { if (lane == 0) { a.ok[b] = 0; a.out_len[b] = 0; } return; }
+    if (bad || n == 0 || n >= KNZ_UTF_MAX_SYMS || 3 * (int)n + 6 >= maxTarget) { if (lane == 0) { a.ok[b] = 0; a.out_len[b] = 0; } break; }
     // where the walk stops: behind the last code point that starts in front of count - 4
     int lastP = lastLead;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const int o = (int)wave_shfl((uint32_t)lastP, lane ^ d); lastP = o > lastP ? o : lastP; }
     const int srcStop = lastP + (int)knz_utf_size(src[lastP]);
+    if (lane == 0) s_stop = srcStop;
     // ---- pass 2: ranks by (frequency, code point), increasing (:186-193); symbol of sort position r gets index n - 1 - r ------
     unsigned long long est = 0;
     for (uint32_t j0 = 0; j0 < n; j0 += 64) {
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(KNZ_UTF_FWD_THREADS) void knz_utf_forward_kernel(Ut
         const uint32_t lo = wave_reduce_add((uint32_t)est), hi = wave_reduce_add((uint32_t)(est >> 32));   // (lo cannot carry out: < 2^31 bytes)
         est = ((unsigned long long)hi << 32) + lo;
     }
-    if (est + 10 >= (unsigned long long)maxTarget) { if (lane == 0) { a.ok[b] = 0; a.out_len[b] = 0; } return; }   // estimate (:200,:212-223)
+    if (est + 10 >= (unsigned long long)maxTarget) { if (lane == 0) { a.ok[b] = 0; a.out_len[b] = 0; } break; }   // estimate (:200,:212-223)
     wave_sync();
     for (uint32_t j = lane; j < n; j += 64) {                            // aliases replace the frequencies (:214-219)
         const uint32_t i = ranks[j];
@@ -197,26 +200,53 @@ __global__ __launch_bounds__(KNZ_UTF_FWD_THREADS) void knz_utf_forward_kernel(Ut
     }
     wave_sync();
     __threadfence();
-    // ---- pass 3: emission ------------------------------------------------------------------------------------------------
+    if (lane == 0) s_go = 1;
+    } while (0);
+    __syncthreads();
+    if (!s_go) return;
+    // ---- pass 3: emission, all 16 waves (round 4: one wave walked the block 64 positions at a time, 6.5 of the stage's 8.6 ms) ----------------
+    // A tile is 16 K positions, 1 K per wave in 16 rows of 64: the aliases and their offsets inside the wave's stretch stay in registers, the
+    // 16 stretch sizes meet in LDS once per tile.
+    const uint32_t n = s_n;
+    const int srcStop = s_stop;
+    const int wave = tid >> 6;
     int dstIdx = 4 + 3 * (int)n;
-    if (lane < start) dst[dstIdx + lane] = src[lane];
+    if (tid < start) dst[dstIdx + tid] = src[tid];
     dstIdx += start;
-    for (int p0 = start; p0 < end; p0 += 64) {
-        const int p = p0 + lane;
-        uint32_t w = 0, alias = 0;
-        if (p < end) {
-            const uint32_t b0 = src[p];
-            const uint32_t s = knz_utf_size(b0);
-            const bool isSym = chainMode ? (((cbits[p >> 3] >> (p & 7)) & 1) != 0) : s != 0;
-            if (isSym) {
-                alias = (uint32_t)map[knz_utf_pack(s, b0, src[p + 1], src[p + 2], src[p + 3])];
-                w = 1 + (alias >> 16);
+    for (int t0 = start; t0 < end; t0 += 16 * KNZ_UTF_FWD_THREADS) {
+        uint32_t al[16], off[16];
+        uint32_t wsum = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int p = t0 + wave * 1024 + r * 64 + lane;
+            uint32_t w = 0, alias = 0;
+            if (p < end) {
+                const uint32_t b0 = src[p];
+                const uint32_t s = knz_utf_size(b0);
+                const bool isSym = chainMode ? (((cbits[p >> 3] >> (p & 7)) & 1) != 0) : s != 0;
+                if (isSym) {
+                    alias = (uint32_t)map[knz_utf_pack(s, b0, src[p + 1], src[p + 2], src[p + 3])];
+                    w = 1 + (alias >> 16);
+                }
             }
+            const uint32_t incl = wave_scan_incl(w);
+            al[r] = (alias & 0xFFFFu) | (w << 16);
+            off[r] = wsum + incl - w;
+            wsum += wave_bcast(incl, 63);
         }
-        const uint32_t incl = wave_scan_incl(w);
-        if (w) { uint8_t* o = dst + dstIdx + (incl - w); o[0] = (uint8_t)alias; if (w == 2) o[1] = (uint8_t)(alias >> 8); }
-        dstIdx += (int)wave_bcast(incl, 63);
+        if (lane == 0) s_wt[wave] = wsum;
+        __syncthreads();
+        uint32_t base = 0, tot = 0;
+        for (int k = 0; k < KNZ_UTF_FWD_THREADS / 64; k++) { const uint32_t v = s_wt[k]; base += k < wave ? v : 0u; tot += v; }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t w = al[r] >> 16;
+            if (w) { uint8_t* o = dst + dstIdx + base + off[r]; o[0] = (uint8_t)al[r]; if (w == 2) o[1] = (uint8_t)(al[r] >> 8); }
+        }
+        dstIdx += (int)tot;
+        __syncthreads();
     }
+    if (tid >= 64) return;
     if (lane == 0) { dst[0] = (uint8_t)start; dst[1] = (uint8_t)(srcStop - end); dst[2] = (uint8_t)(n >> 8); dst[3] = (uint8_t)n; }
     const int tail = count - srcStop;                                    // last (possibly truncated) bytes (:255-259)
     if (lane < tail) dst[dstIdx + lane] = src[srcStop + lane];
