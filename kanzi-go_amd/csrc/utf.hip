@@ -3,14 +3,15 @@
 // (v2/transform/UTFCodec.go:84-265, 268-383, 393-519, 521-546, 578-609).
 //
 // Unlike the list and dictionary transforms this one is data parallel once a block is known to be well-formed: a code point
-// starts at every byte that is not a continuation byte. One wave per block (the batch has tens of blocks), every pass strides
-// the block 64 positions at a time:
+// starts at every byte that is not a continuation byte. One workgroup of 16 waves per block (the batch has tens of blocks); passes 1 and 3
+// stride the block with all of them, pass 2 runs on the first wave:
 //   1. validation = the reference's statistics (validateUTF: no byte that never occurs in UTF-8, every lead byte followed by
 //      a second byte of its legal range, at least 1/8 continuation bytes) plus the checks of its main loop (third / fourth
 //      bytes, no stray continuation byte), all of them local to a position, and, in the same pass, the histogram of the
-//      packed code points in a 2^22-entry table with the list of distinct code points built from the first touch;
+//      packed code points in a 2^22-entry table with the list of distinct code points built from the first touch (1- and 2-byte code
+//      points are counted in LDS and join the table once per block);
 //   2. ranks of the (at most 32767) code points by (frequency, code point) by counting, aliases written back into the table;
-//   3. emission: per row of 64 positions the alias widths are prefix-summed and the bytes stored.
+//   3. emission: per tile of 16 K positions the alias widths are prefix-summed (in the wave, then over the waves) and the bytes stored.
 // The inverse finds the alias boundaries (a byte >= 128 takes the next byte with it, whatever that is) with a wave scan over
 // the two-state automaton, prefix-sums the code point lengths and stores.
 // A UTF stage behind another UTF stage that applied (ctx["dataType"] == DT_UTF8: the reference skips validateUTF then) takes
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(KNZ_UTF_FWD_THREADS) void knz_utf_forward_kernel(Ut
     __shared__ uint64_t s_keys[1024];
     __shared__ uint32_t s_wt[KNZ_UTF_FWD_THREADS / 64];
     __shared__ int s_go, s_stop;
+    __shared__ uint32_t s_c1[128], s_c2[2048];                           // counts of the 1- and 2-byte code points (the frequent ones) for the workgroup
     const int tid = threadIdx.x;                                         // passes 1 (validation + histogram) and 3 (emission) run on all 16 waves, pass 2 on wave 0
     const int lane = tid & 63;
     const uint32_t b = blockIdx.x;
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(KNZ_UTF_FWD_THREADS) void knz_utf_forward_kernel(Ut
     else while (start < 4 && knz_utf_size(src[start]) == 0) start++;
     const int end = count - 4;                                           // code points start in [start, end)
     if (tid == 0) { s_n = 0; s_bad = 0; s_cont = 0; s_last = -1; s_go = 0; s_stop = 0; }
+    for (int i = tid; i < 128 + 2048; i += KNZ_UTF_FWD_THREADS) { if (i < 128) s_c1[i] = 0; else s_c2[i - 128] = 0; }
     bool bad = false;
     if (chainMode && tid < 64) {
         // the reference's walk (:141-166), lane 0; marks the starts. (Only reachable with UTF twice in one sequence.)
@@ -131,14 +134,32 @@ __global__ __launch_bounds__(KNZ_UTF_FWD_THREADS) void knz_utf_forward_kernel(Ut
                     }
                 }
                 if (isSym) {
-                    const uint32_t val = knz_utf_pack(s, b0, b1, b2, b3);
-                    if (atomicAdd(&map[val], 1) == 0) {
-                        const uint32_t idx = atomicAdd(&s_n, 1u);
-                        if (idx < KNZ_UTF_MAX_SYMS) syms[idx] = val;
+                    // (Round 4: code points of one and two bytes are counted in LDS and reach the table once per workgroup: a returned global
+                    // atomic per code point - a thread waits for it before its next row, and the frequent ones share an address - was ~8 of the
+                    // stage's 8.6 ms. Longer code points keep the table's own counters.)
+                    if (s == 1) atomicAdd(&s_c1[b0], 1u);
+                    else if (s == 2 && (b1 & 0xC0u) == 0x80u) atomicAdd(&s_c2[((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu)], 1u);   // (a lead byte at the region's last position may be followed by anything: that pair keeps its exact bytes through the table's counter)
+                    else {
+                        const uint32_t val = knz_utf_pack(s, b0, b1, b2, b3);
+                        if (atomicAdd(&map[val], 1) == 0) {
+                            const uint32_t idx = atomicAdd(&s_n, 1u);
+                            if (idx < KNZ_UTF_MAX_SYMS) syms[idx] = val;
+                        }
                     }
                     lastLead = p;
                 }
             }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 128 + 2048; i += KNZ_UTF_FWD_THREADS) {        // the LDS counts join the table (nobody else touches these entries)
+        const uint32_t c = i < 128 ? s_c1[i] : s_c2[i - 128];
+        if (c) {
+            const uint32_t j = (uint32_t)i - 128u;
+            const uint32_t val = i < 128 ? (uint32_t)i : knz_utf_pack(2, 0xC0u | (j >> 6), 0x80u | (j & 63u), 0, 0);
+            map[val] = (int32_t)c;
+            const uint32_t idx = atomicAdd(&s_n, 1u);
+            if (idx < KNZ_UTF_MAX_SYMS) syms[idx] = val;
         }
     }
     {   // the 16 waves' findings

@@ -311,6 +311,11 @@ def utf_inputs():
             bad[i + 2] = 0x20                                           # third byte of a 3-byte sequence
             break
     yield "badthird", bytes(bad)
+    # a two-byte lead byte at the last position of the region (count - 5) with anything behind it: the reference checks pairs inside the region
+    # only and packs the two bytes as they are (UTFCodec.go:459-499, :521-546); three shapes of the byte behind it
+    for k, nxt in enumerate((0x41, 0x95, 0xD1)):
+        body = utf_text(20000, 15 + k, (1,)).decode("utf-8", errors="ignore").encode("utf-8")     # (ends on a code point boundary)
+        yield "lastlead%d" % k, body + b"  " + bytes([0xD0, nxt]) + b"abc"
     yield "magic", bytes([0x1F, 0x8B]) + utf_text(30000, 13, (1,))      # gzip magic (only through the stream API)
     yield "binary", np.random.default_rng(14).integers(0, 256, 20000, dtype=np.uint8).tobytes()
 
