@@ -256,6 +256,7 @@ template <typename K>
 static int knz_own_sort_pairs(DevBuf& tmp, K* kin, K* kout, uint32_t* vin, uint32_t* vout, size_t n, unsigned b0, unsigned b1, hipStream_t st) {
     if (n == 0) return 0;
     if (n > 0xFFFFFFF0ull) return -1;
+    if (b1 > 8 * sizeof(K) || b0 > b1) return -1;      // a digit beyond the key would shift by >= its width
     const unsigned passes = b1 > b0 ? (b1 - b0 + 7) / 8 : 0;
     if (passes == 0) {
         if (hipMemcpyAsync(kout, kin, n * sizeof(K), hipMemcpyDeviceToDevice, st) != hipSuccess || hipMemcpyAsync(vout, vin, n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;

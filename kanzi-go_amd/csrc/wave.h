@@ -9,6 +9,11 @@
 
 #ifndef KNZ_HIP_EMU
 // ------------------------------------------------------------------ device (gfx950)
+// The kernels lean on gfx950 behaviour that the HIP memory model does not promise (wave_order_lanes below, the LDS-atomic order of the radix
+// and segmented sorts in prims.hip / bwt_sort.hip): the device pass refuses any other target instead of losing parity silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libknz_gpu is written for gfx950 (MI355X) only: --offload-arch=gfx950"
+#endif
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint32_t wave_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 __device__ __forceinline__ uint64_t wave_shfl64(uint64_t v, int src) {

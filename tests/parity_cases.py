@@ -1268,6 +1268,16 @@ def check_bwt_sort_fuzz(be, monkeypatch, cases=60, seed=7, max_n=40000, segs=("1
         c.close()
 
 
+def check_bwt_sort_wide_keys(be, monkeypatch, scale=1, block_sizes=(4096,), segs=("128", None), check=True):
+    """Blocks of 64 MiB and more need more than 64 bits for (group id | run-aware key): the large list then keeps the plain doubling keys.
+    KNZ_SS_RUN_BITS_PAD widens the run-aware payload for the decision only, so that small inputs with many large groups take that branch
+    (pad 12: some rounds fit, some do not; pad 40: never fits); stream == oracle either way."""
+    for pad in ("12", "40"):
+        monkeypatch.setenv("KNZ_SS_RUN_BITS_PAD", pad)
+        check_bwt_sort_forms(be, monkeypatch, scale=scale, block_sizes=block_sizes, segs=segs, check=check)
+    monkeypatch.delenv("KNZ_SS_RUN_BITS_PAD", raising=False)
+
+
 class pytest_raises_knz:
     def __init__(self, code):
         self.code = code

@@ -116,6 +116,10 @@ def test_bwt_suffix_sort_forms(be, monkeypatch):
     P.check_bwt_sort_forms(be, monkeypatch)
 
 
+def test_bwt_suffix_sort_wide_keys(be, monkeypatch):
+    P.check_bwt_sort_wide_keys(be, monkeypatch)
+
+
 def test_bwt_suffix_sort_fuzz(be, monkeypatch):
     P.check_bwt_sort_fuzz(be, monkeypatch)
 

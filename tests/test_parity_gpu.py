@@ -272,6 +272,10 @@ def test_bwt_suffix_sort_forms(be, monkeypatch):
     P.check_bwt_sort_forms(be, monkeypatch, scale=60, block_sizes=(1 << 16, 1 << 20), segs=(None,), check=False)
 
 
+def test_bwt_suffix_sort_wide_keys(be, monkeypatch):
+    P.check_bwt_sort_wide_keys(be, monkeypatch, scale=60, block_sizes=(1 << 20,), segs=(None,), check=False)
+
+
 def test_bwt_suffix_sort_fuzz(be, monkeypatch):
     P.check_bwt_sort_fuzz(be, monkeypatch, cases=120, seed=8, max_n=3000000, segs=("",))
 
