@@ -273,7 +273,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="bwt", choices=sorted(CONFIGS))
-    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"], help="N>1: one corpus copy per GPU in one stream (weak, default) or one fixed job split over the GPUs (strong)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N>1: ONE fixed job (the BASELINE corpus) split over the GPUs (strong, default: the figure BASELINE.json's "
+                                                                                    "metric and north_star name; the weak figure rides along as roofline.weak_value_MBps) or one corpus copy per GPU in one stream (weak)")
+    ap.add_argument("--no-weak", action="store_true", help="N>1, strong: skip the second (weak-scaling) timed region")
     ap.add_argument("--size", type=int, default=0, help="override the corpus size (debug; the defaults are the BASELINE sizes: 211957760 / 10^9 for fpaq)")
     ap.add_argument("--block-size", type=int, default=0, help="override the block size (debug)")
     ap.add_argument("--transform", default="", help="override the transform sequence of the config, e.g. LZP or BWT+SRT+ZRLT (debug)")
@@ -340,12 +342,7 @@ def main():
         base_size = args.size or bench_corpus.SILESIA_SIZE
         base = bench_corpus.s_silesia(base_size)
         corpus_name = "S-silesia"
-    strong = args.scaling == "strong" or world == 1
-    size = (base_size if strong else base_size * world) * max(1, args.copies)   # strong: ONE job whatever N; weak: one corpus copy per GPU, one stream
-    nblocks = (size + bs - 1) // bs
-    lo_b, hi_b = kd.block_range(nblocks, rank, world)
-    per = kd.max_blocks_per_rank(nblocks, world)
-    lo, hi = min(lo_b * bs, size), min(hi_b * bs, size)
+    from types import SimpleNamespace
 
     def tiled(a, b):                                         # bytes [a, b) of the corpus repeated back to back
         parts = []
@@ -356,61 +353,72 @@ def main():
             a += take
         return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
 
-    my = tiled(lo, hi)
-    n_my = len(my)
-
     def dev_zeros(n):                                        # 16-byte aligned (the emulator's "device" memory is host memory)
         t = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
         return t[(-t.data_ptr()) % 16:][:n]
 
     codec = K.Codec(transform, entropy, bs, device=local_rank, lib=lib)
-    d_src = dev_zeros(max(n_my, 16))
-    if n_my:
-        d_src[:n_my] = torch.from_numpy(np.ascontiguousarray(my)).to(dev)
-    cap = (per * bs + (per * bs) // 2 + (1 << 20) + 15) & ~15
-    d_seg = dev_zeros(cap)
-    d_back = dev_zeros(n_my + 4096)
-    d_stream = dev_zeros(size + size // 2 + (1 << 20)) if rank == 0 and multi else None
+
+    def make_job(strong_):
+        """The buffers of one workload: strong = ONE job (the BASELINE corpus) whatever N; weak = one corpus copy per GPU, still one stream."""
+        j = SimpleNamespace()
+        j.size = (base_size if strong_ else base_size * world) * max(1, args.copies)
+        j.nblocks = (j.size + bs - 1) // bs
+        lo_b, hi_b = kd.block_range(j.nblocks, rank, world)
+        j.per = kd.max_blocks_per_rank(j.nblocks, world)
+        lo, hi = min(lo_b * bs, j.size), min(hi_b * bs, j.size)
+        my = tiled(lo, hi)
+        j.n_my = len(my)
+        j.d_src = dev_zeros(max(j.n_my, 16))
+        if j.n_my:
+            j.d_src[:j.n_my] = torch.from_numpy(np.ascontiguousarray(my)).to(dev)
+        j.cap = (j.per * bs + (j.per * bs) // 2 + (1 << 20) + 15) & ~15
+        j.d_seg = dev_zeros(j.cap)
+        j.d_back = dev_zeros(j.n_my + 4096)
+        j.d_stream = dev_zeros(j.size + j.size // 2 + (1 << 20)) if rank == 0 and multi else None
+        j.stage = {"enc_transform": 0.0, "enc_entropy": 0.0, "enc_layout": 0.0, "enc_gather": 0.0, "dec_walk": 0.0, "dec_entropy": 0.0, "dec_transform": 0.0}
+        j.kern_ms, j.kern_launches = {}, {}
+        j.t_enc = j.t_dec = 0.0
+        j.result = {}
+        return j
+
+    strong = args.scaling == "strong" or world == 1
+    job = make_job(strong)
     # the steps run on a stream of their own (non-blocking): a NULL stream would mean the handle's own stream, which is ordered against
     # the legacy default stream and pays that ordering on every launch (visible on the microsecond-scale configs)
     bench_stream = None if emu else torch.cuda.Stream(device=dev)
     stream = 0 if emu else bench_stream.cuda_stream
 
-    stage = {"enc_transform": 0.0, "enc_entropy": 0.0, "enc_layout": 0.0, "enc_gather": 0.0, "dec_walk": 0.0, "dec_entropy": 0.0, "dec_transform": 0.0}
-    kern_ms, kern_launches = {}, {}
-    t_enc = t_dec = 0.0
-    result = {}
-
-    def add_kernels(codec_):
+    def add_kernels(j, codec_):
         for name, ms in codec_.last_kernel_times():
             k = kernel_key(name)
-            kern_ms[k] = kern_ms.get(k, 0.0) + ms
-            kern_launches[k] = kern_launches.get(k, 0) + 1
+            j.kern_ms[k] = j.kern_ms.get(k, 0.0) + ms
+            j.kern_launches[k] = j.kern_launches.get(k, 0) + 1
 
-    def one_step(timed):
-        nonlocal t_enc, t_dec
+    def one_step(j, timed):
+        result, stage = j.result, j.stage
         t0 = time.perf_counter()
         if not multi:
-            nb = codec.dev_compress(d_src.data_ptr(), n_my, d_seg.data_ptr(), cap, header_input_size=size, stream=stream)
+            nb = codec.dev_compress(j.d_src.data_ptr(), j.n_my, j.d_seg.data_ptr(), j.cap, header_input_size=j.size, stream=stream)
             result["stream_bytes"] = nb
         else:
             # every rank encodes its blocks; the gather of the segments to rank 0 over RCCL/xGMI is started and stays in flight
             # while the rank decodes its own segment (which needs nothing from the others); then rank 0 assembles the stream
-            pending, nbits = kd.sharded_compress_begin(codec, d_src, n_my, d_seg, size, d_stream if rank == 0 else d_seg, stream=stream)
+            pending, nbits = kd.sharded_compress_begin(codec, j.d_src, j.n_my, j.d_seg, j.size, j.d_stream if rank == 0 else j.d_seg, stream=stream)
             result["seg_bits"] = nbits
         tm = codec.last_timing()
         if timed:
-            add_kernels(codec)
+            add_kernels(j, codec)
         if not multi:
             sync()
         t1 = time.perf_counter()
         if not multi:
-            nd = codec.dev_decompress(d_seg.data_ptr(), result["stream_bytes"], d_back.data_ptr(), d_back.numel(), stream=stream)
+            nd = codec.dev_decompress(j.d_seg.data_ptr(), result["stream_bytes"], j.d_back.data_ptr(), j.d_back.numel(), stream=stream)
         else:
-            nd = codec.dev_decompress_blocks(d_seg.data_ptr(), result["seg_bits"], d_back.data_ptr(), d_back.numel(), stream=stream) if n_my else 0
-        td = codec.last_timing() if (not multi or n_my) else [0.0] * 4
-        if timed and (not multi or n_my):
-            add_kernels(codec)
+            nd = codec.dev_decompress_blocks(j.d_seg.data_ptr(), result["seg_bits"], j.d_back.data_ptr(), j.d_back.numel(), stream=stream) if j.n_my else 0
+        td = codec.last_timing() if (not multi or j.n_my) else [0.0] * 4
+        if timed and (not multi or j.n_my):
+            add_kernels(j, codec)
         sync()
         t2 = time.perf_counter()
         if multi:
@@ -420,33 +428,41 @@ def main():
             t0 -= (t3 - t2)                        # the assembly belongs to the encode side of the step
             if rank == 0:
                 result["stream_bytes"] = nb
-        assert nd == n_my, (nd, n_my)
+        assert nd == j.n_my, (nd, j.n_my)
         if timed:
-            t_enc += t1 - t0
-            t_dec += t2 - t1
+            j.t_enc += t1 - t0
+            j.t_dec += t2 - t1
             stage["enc_transform"] += tm[0]; stage["enc_entropy"] += tm[1]; stage["enc_layout"] += tm[2]; stage["enc_gather"] += tm[3]
             stage["dec_walk"] += td[0]; stage["dec_entropy"] += td[1]; stage["dec_transform"] += td[2]
+
+    def timed_region(j):
+        """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; the MAX over the ranks."""
+        for _ in range(args.warmup):
+            one_step(j, False)
+        if multi:
+            dist.barrier()
+        sync()
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(j, True)
+        sync()
+        if multi:
+            dist.barrier()
+        el = time.perf_counter() - t_start
+        if multi:
+            tt = torch.tensor([el, j.t_enc, j.t_dec], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el, j.t_enc, j.t_dec = [float(x) for x in tt.tolist()]
+        return el
 
     sync()
     if bench_stream is not None:
         torch.cuda.set_stream(bench_stream)                   # torch.distributed orders its collectives against the current stream
-    for _ in range(args.warmup):
-        one_step(False)
-    if multi:
-        dist.barrier()
-    sync()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(True)
-    sync()
-    if multi:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
+    elapsed = timed_region(job)
+    size, nblocks, n_my, result, stage, kern_ms, kern_launches = job.size, job.nblocks, job.n_my, job.result, job.stage, job.kern_ms, job.kern_launches
+    t_enc, t_dec, d_src, d_seg, d_back, d_stream = job.t_enc, job.t_dec, job.d_src, job.d_seg, job.d_back, job.d_stream
     rank_kernel_max = None
     if multi:
-        tt = torch.tensor([elapsed, t_enc, t_dec], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, t_enc, t_dec = [float(x) for x in tt.tolist()]
         # the slowest rank's time per kernel: what the SCALE line's shape is made of (a chain kernel is flat in the number of blocks a rank owns)
         names = sorted(kern_ms)
         gathered = [None] * world
@@ -459,6 +475,16 @@ def main():
         okt = torch.tensor([1 if ok_roundtrip else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok_roundtrip = bool(int(okt.item()))
+
+    # N > 1, strong: the weak-scaling figure (one corpus copy per GPU in one stream) rides along as a second timed region of the same shape
+    weak = None
+    if multi and world > 1 and strong and not args.no_weak:
+        wj = make_job(False)
+        w_el = timed_region(wj)
+        w_ok = bool(torch.equal(wj.d_back[:wj.n_my], wj.d_src[:wj.n_my])) if wj.n_my else True
+        weak = {"value": round(wj.size / 1e6 / (w_el / max(args.steps, 1)), 2), "ms_per_step": round(w_el / max(args.steps, 1) * 1e3, 3), "size": wj.size,
+                "blocks": wj.nblocks, "roundtrip_ok_rank0": w_ok}
+        del wj
 
     if rank == 0:
         K_ = max(args.steps, 1)
@@ -585,6 +611,12 @@ def main():
                             row["traffic_over_algorithmic"] = round(t["bytes"] / max(ab / lps, 1), 3)
                         table.append(row)
                     roof["per_kernel"] = sorted(table, key=lambda r: -r["ms_per_step"])[:40]
+        # the figures north_star's targets are quoted on, as scalars where the driver's parser keeps them
+        roof["encode_MBps"] = out["encode_MBps"]; roof["decode_MBps"] = out["decode_MBps"]
+        roof["encode_ms"] = round(t_enc / K_ * 1e3, 3); roof["decode_ms"] = round(t_dec / K_ * 1e3, 3)
+        if weak is not None:
+            roof["weak_value_MBps"] = weak["value"]; roof["weak_ms_per_step"] = weak["ms_per_step"]; roof["weak_blocks"] = weak["blocks"]
+            out["weak_scaling"] = weak
         out["roofline"] = roof
         if rank_kernel_max:
             out["kernel_ms_per_step_max_over_ranks"] = {k: round(v / K_, 3) for k, v in sorted(rank_kernel_max.items(), key=lambda kv: -kv[1])[:10]}
@@ -620,10 +652,18 @@ def main():
         if not multi and not emu and not args.no_host_hook:
             try:
                 out["host_hook_MBps"] = host_hook_rate(K, (transform, entropy, bs, 0, local_rank), base[:size], bs)
+                # (the metric of SURVEY 8d "including H2D / D2H": never `value`, kept beside it)
+                roof["host_hook_round_trip_MBps"] = out["host_hook_MBps"]["round_trip"]
+                roof["host_hook_encode_MBps"] = out["host_hook_MBps"]["encode"]; roof["host_hook_decode_MBps"] = out["host_hook_MBps"]["decode"]
             except Exception as e:   # noqa: BLE001
                 out["host_hook_MBps"] = {"error": str(e)}
         if not args.no_cpu_baseline and not multi:
             out["cpu_baseline"] = cpu_baseline(base, transform, entropy, bs)
+            cb = out["cpu_baseline"]
+            # north_star's target: encode >= 10x the CPU encode of the same configuration (vs_baseline stays null: BASELINE.md holds no published number for this metric)
+            cb["gpu_encode_MBps"] = out["encode_MBps"]; cb["gpu_decode_MBps"] = out["decode_MBps"]
+            cb["gpu_encode_over_cpu_encode"] = round(out["encode_MBps"] / max(cb["encode_MBps"], 1e-9), 2)
+            cb["gpu_decode_over_cpu_decode"] = round(out["decode_MBps"] / max(cb["decode_MBps"], 1e-9), 2)
         print(json.dumps(out), file=json_out, flush=True)
     if multi:
         dist.barrier()
