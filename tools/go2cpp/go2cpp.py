@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""go2cpp: mechanical translation of kanzi-go source files to one C++20 translation unit (oracle/_ref).
+
+TEST INFRASTRUCTURE. usage: go2cpp.py --root /root/reference/v2 --out oracle/_ref/kanzi_ref.gen.hpp FILE.go ...
+FILEs are relative to --root; files are grouped into packages by directory, packages are emitted in the order their first
+file is listed (list dependencies first). The generated file is never edited and never committed.
+"""
+import argparse
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import goparse  # noqa: E402
+import emit  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--root", required=True)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("files", nargs="+")
+    a = ap.parse_args()
+    with open(os.path.join(a.root, "go.mod")) as f:
+        module = re.search(r"^module\s+(\S+)", f.read(), re.M).group(1)
+    tr = emit.Translator(module)
+    for rel in a.files:
+        ast = goparse.parse_file(os.path.join(a.root, rel))
+        d = os.path.dirname(rel)
+        tr.add_file(module + ("/" + d if d else ""), ast)
+    text = tr.emit_all()
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+    with open(a.out, "w") as f:
+        f.write(text)
+    print(f"go2cpp: {len(a.files)} files, {sum(len(p.funcs) + sum(len(m) for m in p.methods.values()) for p in tr.pkgs.values())} functions -> {a.out} ({len(text.splitlines())} lines)")
+
+
+if __name__ == "__main__":
+    try:
+        main()
+    except (goparse.GoSyntaxError, emit.EmitError) as e:
+        sys.exit(f"go2cpp: {e}")

@@ -1,0 +1,588 @@
+// Go semantics for the C++ that tools/go2cpp emits from kanzi-go's sources (oracle/_ref).
+//
+// TEST INFRASTRUCTURE. Everything here is a RUNTIME SHIM, i.e. the part of "Go" the emitter does not generate: sized integers
+// with Go's wrap-around / shift rules, untyped constants, slices / arrays with bounds checks that panic, strings, maps,
+// `any`, `error`, panics as C++ exceptions, and the handful of standard-library calls the translated files make
+// (encoding/binary, math/bits, errors, fmt, sort, slices, io, sync). No algorithm of the reference lives in this file.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <type_traits>
+#include <typeinfo>
+#include <utility>
+#include <vector>
+
+namespace go {
+
+// ---------------------------------------------------------------------------------------------------------------- panics
+struct PanicException : std::runtime_error {
+    explicit PanicException(const std::string& m) : std::runtime_error(m) {}
+};
+[[noreturn]] inline void panic_str(const std::string& m) { throw PanicException(m); }
+
+// ---------------------------------------------------------------------------------------------------------------- memory
+// Allocations of the translated code live until the C API call that made them returns (Go has a garbage collector; a test
+// checker has scopes). Outside any scope (static initialisers: package-level tables) memory is never freed.
+struct Arena {
+    std::vector<void*> blocks;
+    ~Arena() { for (void* p : blocks) std::free(p); }
+};
+inline thread_local Arena* g_arena = nullptr;
+struct ArenaScope {
+    Arena a; Arena* prev;
+    ArenaScope() : prev(g_arena) { g_arena = &a; }
+    ~ArenaScope() { g_arena = prev; }
+};
+inline void* alloc_zero(size_t n) {
+    void* p = std::calloc(n ? n : 1, 1);
+    if (!p) panic_str("out of memory");
+    if (g_arena) g_arena->blocks.push_back(p);
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- nil
+struct nil_t {
+    template <class T> constexpr operator T*() const { return nullptr; }
+};
+inline constexpr nil_t nil{};
+template <class T> inline bool operator==(T* p, nil_t) { return p == nullptr; }
+template <class T> inline bool operator!=(T* p, nil_t) { return p != nullptr; }
+template <class T> inline bool operator==(nil_t, T* p) { return p == nullptr; }
+template <class T> inline bool operator!=(nil_t, T* p) { return p != nullptr; }
+
+// ---------------------------------------------------------------------------------------------------------------- integers
+// untyped integer constant: arbitrary precision in Go, 128 bits here (the translated files never exceed 65 bits)
+struct U {
+    __int128 v;
+    constexpr U() : v(0) {}
+    constexpr U(__int128 x) : v(x) {}
+    constexpr explicit operator double() const { return (double)v; }
+};
+constexpr U operator""_u(unsigned long long x) { return U((__int128)x); }
+#define GO_U_BIN(op) constexpr U operator op(U a, U b) { return U(a.v op b.v); }
+GO_U_BIN(+) GO_U_BIN(-) GO_U_BIN(*) GO_U_BIN(&) GO_U_BIN(|) GO_U_BIN(^)
+#undef GO_U_BIN
+constexpr U operator/(U a, U b) { return U(a.v / b.v); }
+constexpr U operator%(U a, U b) { return U(a.v % b.v); }
+constexpr U operator<<(U a, U b) { return U(b.v >= 127 ? (__int128)0 : (__int128)((unsigned __int128)a.v << (int)b.v)); }
+constexpr U operator>>(U a, U b) { return U(b.v >= 127 ? (a.v < 0 ? (__int128)-1 : (__int128)0) : a.v >> (int)b.v); }
+constexpr U operator-(U a) { return U(-a.v); }
+constexpr U operator+(U a) { return a; }
+constexpr U operator~(U a) { return U(~a.v); }
+#define GO_U_CMP(op) constexpr bool operator op(U a, U b) { return a.v op b.v; }
+GO_U_CMP(==) GO_U_CMP(!=) GO_U_CMP(<) GO_U_CMP(<=) GO_U_CMP(>) GO_U_CMP(>=)
+#undef GO_U_CMP
+constexpr U andnot(U a, U b) { return U(a.v & ~b.v); }
+// untyped constants and float64
+constexpr double operator+(U a, double b) { return (double)a.v + b; }
+constexpr double operator+(double a, U b) { return a + (double)b.v; }
+constexpr double operator-(U a, double b) { return (double)a.v - b; }
+constexpr double operator-(double a, U b) { return a - (double)b.v; }
+constexpr double operator*(U a, double b) { return (double)a.v * b; }
+constexpr double operator*(double a, U b) { return a * (double)b.v; }
+constexpr double operator/(U a, double b) { return (double)a.v / b; }
+constexpr double operator/(double a, U b) { return a / (double)b.v; }
+#define GO_UD_CMP(op) constexpr bool operator op(U a, double b) { return (double)a.v op b; } constexpr bool operator op(double a, U b) { return a op (double)b.v; }
+GO_UD_CMP(==) GO_UD_CMP(!=) GO_UD_CMP(<) GO_UD_CMP(<=) GO_UD_CMP(>) GO_UD_CMP(>=)
+#undef GO_UD_CMP
+
+template <class T, class Tag = void> struct I;
+template <class X> struct is_goint : std::false_type {};
+template <class T, class Tag> struct is_goint<I<T, Tag>> : std::true_type {};
+
+// shift count of any integer type (Go: a negative count panics)
+template <class S> constexpr uint64_t shift_count(S s) {
+    if constexpr (std::is_same_v<S, U>) { if (s.v < 0) panic_str("negative shift amount"); return s.v > 1000 ? 1000 : (uint64_t)s.v; }
+    else { if constexpr (std::is_signed_v<decltype(s.v)>) { if (s.v < 0) panic_str("negative shift amount"); } return (uint64_t)s.v; }
+}
+
+template <class T, class Tag> struct I {
+    using raw = T;
+    using UT = std::make_unsigned_t<T>;
+    static constexpr int BITS = 8 * (int)sizeof(T);
+    T v;
+    constexpr I() : v(0) {}
+    constexpr I(U u) : v((T)(UT)(unsigned __int128)u.v) {}                                          // untyped constant -> typed (implicit, as in Go)
+    template <class T2, class Tag2> constexpr explicit I(I<T2, Tag2> o) : v((T)o.v) {}                 // T(x): truncation / sign extension as in Go
+    constexpr explicit I(double d) : v((T)d) {}
+    static constexpr I from_raw(T x) { I r; r.v = x; return r; }
+    constexpr explicit operator double() const { return (double)v; }
+    constexpr explicit operator float() const { return (float)v; }
+
+    // arithmetic wraps (computed in 64-bit unsigned, truncated back)
+    friend constexpr I operator+(I a, I b) { return from_raw((T)((uint64_t)a.v + (uint64_t)b.v)); }
+    friend constexpr I operator-(I a, I b) { return from_raw((T)((uint64_t)a.v - (uint64_t)b.v)); }
+    friend constexpr I operator*(I a, I b) { return from_raw((T)((uint64_t)a.v * (uint64_t)b.v)); }
+    friend constexpr I operator/(I a, I b) {
+        if (b.v == 0) panic_str("integer divide by zero");
+        if constexpr (std::is_signed_v<T>) { if (b.v == (T)-1) return from_raw((T)(0 - (uint64_t)a.v)); }
+        return from_raw((T)(a.v / b.v));
+    }
+    friend constexpr I operator%(I a, I b) {
+        if (b.v == 0) panic_str("integer divide by zero");
+        if constexpr (std::is_signed_v<T>) { if (b.v == (T)-1) return from_raw(0); }
+        return from_raw((T)(a.v % b.v));
+    }
+    friend constexpr I operator&(I a, I b) { return from_raw((T)(a.v & b.v)); }
+    friend constexpr I operator|(I a, I b) { return from_raw((T)(a.v | b.v)); }
+    friend constexpr I operator^(I a, I b) { return from_raw((T)(a.v ^ b.v)); }
+    friend constexpr I andnot(I a, I b) { return from_raw((T)(a.v & ~b.v)); }
+    constexpr I operator-() const { return from_raw((T)(0 - (uint64_t)v)); }
+    constexpr I operator+() const { return *this; }
+    constexpr I operator~() const { return from_raw((T)~v); }
+    // shifts: count >= width gives 0 (or the sign for an arithmetic right shift)
+    template <class S> constexpr I shl(S s) const { uint64_t c = shift_count(s); return c >= (uint64_t)BITS ? from_raw(0) : from_raw((T)((UT)v << c)); }
+    template <class S> constexpr I shr(S s) const {
+        uint64_t c = shift_count(s);
+        if (c >= (uint64_t)BITS) return from_raw(std::is_signed_v<T> && v < 0 ? (T)-1 : (T)0);
+        return from_raw((T)(v >> c));
+    }
+    template <class T2, class G2> friend constexpr I operator<<(I a, I<T2, G2> s) { return a.shl(s); }
+    template <class T2, class G2> friend constexpr I operator>>(I a, I<T2, G2> s) { return a.shr(s); }
+    friend constexpr I operator<<(I a, U s) { return a.shl(s); }
+    friend constexpr I operator>>(I a, U s) { return a.shr(s); }
+    friend constexpr bool operator==(I a, I b) { return a.v == b.v; }
+    friend constexpr bool operator!=(I a, I b) { return a.v != b.v; }
+    friend constexpr bool operator<(I a, I b) { return a.v < b.v; }
+    friend constexpr bool operator<=(I a, I b) { return a.v <= b.v; }
+    friend constexpr bool operator>(I a, I b) { return a.v > b.v; }
+    friend constexpr bool operator>=(I a, I b) { return a.v >= b.v; }
+    constexpr I& operator+=(I b) { return *this = *this + b; }
+    constexpr I& operator-=(I b) { return *this = *this - b; }
+    constexpr I& operator*=(I b) { return *this = *this * b; }
+    constexpr I& operator/=(I b) { return *this = *this / b; }
+    constexpr I& operator%=(I b) { return *this = *this % b; }
+    constexpr I& operator&=(I b) { return *this = *this & b; }
+    constexpr I& operator|=(I b) { return *this = *this | b; }
+    constexpr I& operator^=(I b) { return *this = *this ^ b; }
+    template <class S> constexpr I& operator<<=(S s) { return *this = shl(s); }
+    template <class S> constexpr I& operator>>=(S s) { return *this = shr(s); }
+    constexpr I& operator++() { return *this = *this + from_raw(1); }
+    constexpr I& operator--() { return *this = *this - from_raw(1); }
+    constexpr I operator++(int) { I o = *this; ++*this; return o; }
+    constexpr I operator--(int) { I o = *this; --*this; return o; }
+};
+// an untyped constant shifted by a variable takes the type the context gives it; the translated files only do this where that type is
+// int or where the result is converted at once: computed in 128 bits, truncated by the conversion
+template <class T, class G> constexpr U operator<<(U a, I<T, G> s) { return a << U((__int128)shift_count(s)); }
+template <class T, class G> constexpr U operator>>(U a, I<T, G> s) { return a >> U((__int128)shift_count(s)); }
+
+using Int = I<int64_t>;   using Uint = I<uint64_t>;  using Uintptr = I<uint64_t>;
+using Int8 = I<int8_t>;   using Int16 = I<int16_t>;  using Int32 = I<int32_t>;   using Int64 = I<int64_t>;
+using Uint8 = I<uint8_t>; using Uint16 = I<uint16_t>; using Uint32 = I<uint32_t>; using Uint64 = I<uint64_t>;
+using Byte = Uint8;       using Rune = Int32;
+using Float64 = double;   using Float32 = float;
+static_assert(sizeof(Byte) == 1 && sizeof(Int32) == 4 && sizeof(Uint64) == 8, "sized integers are their payload");
+
+// `x := 5` gives an int, `x := 5.0` a float64; everything else keeps its type
+constexpr Int def(U u) { return Int(u); }
+template <class T> constexpr T def(T&& x) { return std::forward<T>(x); }
+template <class T> constexpr T def(const T& x) { return x; }
+struct UF { double v; };  // (untyped float constants are emitted as plain doubles)
+
+// conversions T(x)
+template <class To, class From> constexpr To conv(const From& x) {
+    if constexpr (std::is_same_v<To, From>) return x;
+    else if constexpr (std::is_floating_point_v<To> && std::is_same_v<From, U>) return (To)(double)x.v;
+    else if constexpr (std::is_floating_point_v<To> && is_goint<From>::value) return (To)x.v;
+    else return To(x);
+}
+// array length / index from any integer
+constexpr size_t csize(U u) { return (size_t)u.v; }
+template <class T, class G> constexpr size_t csize(I<T, G> i) { return (size_t)i.v; }
+constexpr int64_t idx64(U u) { return (int64_t)u.v; }
+template <class T, class G> constexpr int64_t idx64(I<T, G> i) {
+    if constexpr (std::is_same_v<T, uint64_t>) { if (i.v > (uint64_t)INT64_MAX) return -1; }
+    return (int64_t)i.v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- arrays, slices
+struct none_t {};
+inline constexpr none_t none{};
+[[noreturn]] inline void oob(int64_t i, int64_t n) { panic_str("runtime error: index out of range [" + std::to_string(i) + "] with length " + std::to_string(n)); }
+[[noreturn]] inline void oob_slice(int64_t lo, int64_t hi, int64_t cap) {
+    panic_str("runtime error: slice bounds out of range [" + std::to_string(lo) + ":" + std::to_string(hi) + "] with capacity " + std::to_string(cap));
+}
+
+template <class T> struct Slice {
+    T* p = nullptr; int64_t n = 0, c = 0;
+    Slice() = default;
+    Slice(nil_t) {}
+    Slice(T* p_, int64_t n_, int64_t c_) : p(p_), n(n_), c(c_) {}
+    template <class K> T& operator[](K k) const { int64_t i = idx64(k); if ((uint64_t)i >= (uint64_t)n) oob(i, n); return p[i]; }
+    static Slice make(int64_t n, int64_t c) {
+        if (n < 0 || c < n) panic_str("makeslice: len out of range");
+        return Slice((T*)alloc_zero((size_t)c * sizeof(T)), n, c);
+    }
+    static Slice lit(std::initializer_list<T> l) {
+        Slice s = make((int64_t)l.size(), (int64_t)l.size());
+        int64_t i = 0;
+        for (const T& x : l) s.p[i++] = x;
+        return s;
+    }
+    friend bool operator==(const Slice& s, nil_t) { return s.p == nullptr; }
+    friend bool operator!=(const Slice& s, nil_t) { return s.p != nullptr; }
+};
+
+template <class T, size_t N> struct Array {
+    T a[N ? N : 1];
+    template <class K> T& operator[](K k) { int64_t i = idx64(k); if ((uint64_t)i >= (uint64_t)N) oob(i, (int64_t)N); return a[i]; }
+    template <class K> const T& operator[](K k) const { int64_t i = idx64(k); if ((uint64_t)i >= (uint64_t)N) oob(i, (int64_t)N); return a[i]; }
+    friend bool operator==(const Array& x, const Array& y) { for (size_t i = 0; i < N; i++) if (!(x.a[i] == y.a[i])) return false; return true; }
+    friend bool operator!=(const Array& x, const Array& y) { return !(x == y); }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- strings
+struct String {
+    std::string s;
+    String() = default;
+    String(const char* c) : s(c) {}
+    String(const char* c, size_t n) : s(c, n) {}
+    String(std::string x) : s(std::move(x)) {}
+    template <class K> Byte operator[](K k) const { int64_t i = idx64(k); if ((uint64_t)i >= s.size()) oob(i, (int64_t)s.size()); return Byte::from_raw((uint8_t)s[(size_t)i]); }
+    friend String operator+(const String& a, const String& b) { return String(a.s + b.s); }
+    String& operator+=(const String& b) { s += b.s; return *this; }
+    friend bool operator==(const String& a, const String& b) { return a.s == b.s; }
+    friend bool operator!=(const String& a, const String& b) { return a.s != b.s; }
+    friend bool operator<(const String& a, const String& b) { return a.s < b.s; }
+    friend bool operator<=(const String& a, const String& b) { return a.s <= b.s; }
+    friend bool operator>(const String& a, const String& b) { return a.s > b.s; }
+    friend bool operator>=(const String& a, const String& b) { return a.s >= b.s; }
+};
+inline String operator""_s(const char* c, size_t n) { return String(c, n); }
+constexpr String* dummy_string_ptr = nullptr;
+
+// len / cap
+template <class T> inline Int len(const Slice<T>& s) { return Int::from_raw(s.n); }
+template <class T, size_t N> constexpr Int len(const Array<T, N>&) { return Int::from_raw((int64_t)N); }
+inline Int len(const String& s) { return Int::from_raw((int64_t)s.s.size()); }
+template <class T> inline Int cap(const Slice<T>& s) { return Int::from_raw(s.c); }
+template <class T, size_t N> constexpr Int cap(const Array<T, N>&) { return Int::from_raw((int64_t)N); }
+
+// slicing x[lo:hi] (bounds: 0 <= lo <= hi <= cap for slices, <= len for arrays and strings)
+template <class K> inline int64_t bound(K k, int64_t) { return idx64(k); }
+inline int64_t bound(none_t, int64_t d) { return d; }
+template <class T, class L, class H> inline Slice<T> slice(const Slice<T>& s, L lo, H hi) {
+    int64_t l = bound(lo, 0), h = bound(hi, s.n);
+    if (l < 0 || h < l || h > s.c) oob_slice(l, h, s.c);
+    return Slice<T>(s.p + l, h - l, s.c - l);
+}
+template <class T, class L, class H, class M> inline Slice<T> slice3(const Slice<T>& s, L lo, H hi, M mx) {
+    int64_t l = bound(lo, 0), h = bound(hi, s.n), m = bound(mx, s.c);
+    if (l < 0 || h < l || m < h || m > s.c) oob_slice(l, h, s.c);
+    return Slice<T>(s.p + l, h - l, m - l);
+}
+template <class T, size_t N, class L, class H> inline Slice<T> slice(Array<T, N>& a, L lo, H hi) {
+    int64_t l = bound(lo, 0), h = bound(hi, (int64_t)N);
+    if (l < 0 || h < l || h > (int64_t)N) oob_slice(l, h, (int64_t)N);
+    return Slice<T>(a.a + l, h - l, (int64_t)N - l);
+}
+template <class L, class H> inline String slice(const String& s, L lo, H hi) {
+    int64_t l = bound(lo, 0), h = bound(hi, (int64_t)s.s.size());
+    if (l < 0 || h < l || h > (int64_t)s.s.size()) oob_slice(l, h, (int64_t)s.s.size());
+    return String(s.s.substr((size_t)l, (size_t)(h - l)));
+}
+
+// copy
+template <class T> inline Int copy(const Slice<T>& d, const Slice<T>& s) {
+    int64_t n = std::min(d.n, s.n);
+    if (n > 0) std::memmove((void*)d.p, (const void*)s.p, (size_t)n * sizeof(T));
+    return Int::from_raw(n);
+}
+inline Int copy(const Slice<Byte>& d, const String& s) {
+    int64_t n = std::min<int64_t>(d.n, (int64_t)s.s.size());
+    if (n > 0) std::memcpy((void*)d.p, s.s.data(), (size_t)n);
+    return Int::from_raw(n);
+}
+
+// make / new
+template <class T, class N> inline Slice<T> make_slice(N n) { int64_t k = idx64(n); return Slice<T>::make(k, k); }
+template <class T, class N, class C> inline Slice<T> make_slice(N n, C c) { return Slice<T>::make(idx64(n), idx64(c)); }
+template <class T> inline T* New() { T* p = (T*)alloc_zero(sizeof(T)); return new (p) T(); }
+template <class V> inline std::decay_t<V>* New(V&& v) { using T = std::decay_t<V>; T* p = (T*)alloc_zero(sizeof(T)); return new (p) T(std::forward<V>(v)); }
+
+// append
+template <class T> inline Slice<T> grow(const Slice<T>& s, int64_t need) {
+    if (need <= s.c) return Slice<T>(s.p, s.n, s.c);
+    int64_t nc = std::max<int64_t>(need, s.c < 256 ? 2 * s.c : s.c + s.c / 4 + 192);   // (capacity growth is not observable through len / contents)
+    Slice<T> r = Slice<T>::make(s.n, nc);
+    for (int64_t i = 0; i < s.n; i++) r.p[i] = s.p[i];
+    return r;
+}
+template <class T> inline Slice<T> append(const Slice<T>& s) { return s; }
+template <class T, class... A> inline Slice<T> append(const Slice<T>& s, const A&... xs) {
+    Slice<T> r = grow(s, s.n + (int64_t)sizeof...(A));
+    ((r.p[r.n++] = T(xs)), ...);
+    return r;
+}
+template <class T> inline Slice<T> append_slice(const Slice<T>& s, const Slice<T>& t) {
+    Slice<T> r = grow(s, s.n + t.n);
+    if (t.n > 0) std::memmove((void*)(r.p + r.n), (const void*)t.p, (size_t)t.n * sizeof(T));
+    r.n += t.n;
+    return r;
+}
+inline Slice<Byte> append_slice(const Slice<Byte>& s, const String& t) {
+    Slice<Byte> r = grow(s, s.n + (int64_t)t.s.size());
+    std::memcpy((void*)(r.p + r.n), t.s.data(), t.s.size());
+    r.n += (int64_t)t.s.size();
+    return r;
+}
+
+// clear
+template <class T> inline void clear(const Slice<T>& s) { for (int64_t i = 0; i < s.n; i++) s.p[i] = T(); }
+
+// string <-> []byte
+inline Slice<Byte> bytes_of(const String& s) {
+    Slice<Byte> r = Slice<Byte>::make((int64_t)s.s.size(), (int64_t)s.s.size());
+    if (!s.s.empty()) std::memcpy((void*)r.p, s.s.data(), s.s.size());
+    return r;
+}
+inline String string_of(const Slice<Byte>& b) { return String((const char*)b.p, (size_t)b.n); }
+template <> inline Slice<Byte> conv<Slice<Byte>, String>(const String& s) { return bytes_of(s); }
+template <> inline String conv<String, Slice<Byte>>(const Slice<Byte>& b) { return string_of(b); }
+
+// range helpers: `for i := range x` over an integer, a slice, an array or a string (bytes; the translated files hold ASCII only there)
+constexpr int64_t range_len(U u) { return (int64_t)u.v; }
+template <class T, class G> constexpr int64_t range_len(I<T, G> i) { return (int64_t)i.v; }
+template <class T> inline int64_t range_len(const Slice<T>& s) { return s.n; }
+template <class T, size_t N> constexpr int64_t range_len(const Array<T, N>&) { return (int64_t)N; }
+template <class T> inline T& range_at(const Slice<T>& s, int64_t i) { return s.p[i]; }
+template <class T, size_t N> inline T& range_at(Array<T, N>& a, int64_t i) { return a.a[i]; }
+template <class T, size_t N> inline const T& range_at(const Array<T, N>& a, int64_t i) { return a.a[i]; }
+// (range over a pointer to an array: the Go idiom that avoids the copy)
+template <class T, size_t N> constexpr int64_t range_len(Array<T, N>*) { return (int64_t)N; }
+template <class T, size_t N> inline T& range_at(Array<T, N>* a, int64_t i) { return a->a[i]; }
+
+// min / max builtins
+template <class T> constexpr T min(T a) { return a; }
+template <class T> constexpr T max(T a) { return a; }
+template <class A, class B> constexpr auto min(A a, B b) {
+    if constexpr (std::is_same_v<A, U> && !std::is_same_v<B, U>) return B(a) < b ? B(a) : b;
+    else if constexpr (std::is_same_v<B, U> && !std::is_same_v<A, U>) return a < A(b) ? a : A(b);
+    else return a < b ? a : b;
+}
+template <class A, class B> constexpr auto max(A a, B b) {
+    if constexpr (std::is_same_v<A, U> && !std::is_same_v<B, U>) return B(a) > b ? B(a) : b;
+    else if constexpr (std::is_same_v<B, U> && !std::is_same_v<A, U>) return a > A(b) ? a : A(b);
+    else return a > b ? a : b;
+}
+template <class A, class B, class... R> constexpr auto min(A a, B b, R... r) { return min(min(a, b), r...); }
+template <class A, class B, class... R> constexpr auto max(A a, B b, R... r) { return max(max(a, b), r...); }
+
+// ---------------------------------------------------------------------------------------------------------------- error, any, map
+struct error_iface { virtual String Error() = 0; virtual ~error_iface() = default; };
+using error = error_iface*;
+struct errorString : error_iface { String msg; explicit errorString(String m) : msg(std::move(m)) {} String Error() override { return msg; } };
+
+template <class T> [[noreturn]] inline void panic(const T& v) {
+    if constexpr (std::is_convertible_v<T, error>) { error e = v; panic_str(e ? e->Error().s : std::string("nil error")); }
+    else if constexpr (std::is_same_v<T, String>) panic_str(v.s);
+    else panic_str("panic");
+}
+
+// `any`: holds one value of a type the ctx maps of the translated constructors use
+struct any {
+    const std::type_info* ti = nullptr;
+    std::shared_ptr<void> box;
+    any() = default;
+    any(nil_t) {}
+    any(U u) : any(Int(u)) {}            // an untyped constant stored in an interface takes its default type
+    template <class T, class = std::enable_if_t<!std::is_same_v<std::decay_t<T>, any> && !std::is_same_v<std::decay_t<T>, nil_t>>>
+    any(T&& v) : ti(&typeid(std::decay_t<T>)), box(std::make_shared<std::decay_t<T>>(std::forward<T>(v))) {}
+    friend bool operator==(const any& a, nil_t) { return a.ti == nullptr; }
+    friend bool operator!=(const any& a, nil_t) { return a.ti != nullptr; }
+};
+template <class T> inline std::tuple<T, bool> assert2(const any& a) {
+    if (a.ti && *a.ti == typeid(T)) return {*(T*)a.box.get(), true};
+    return {T(), false};
+}
+template <class T> inline T assert1(const any& a) {
+    if (a.ti && *a.ti == typeid(T)) return *(T*)a.box.get();
+    panic_str(std::string("interface conversion: interface {} is ") + (a.ti ? a.ti->name() : "nil") + ", not " + typeid(T).name());
+}
+
+// maps are references to shared storage, as in Go (a nil map reads as empty and panics on assignment)
+template <class K, class V> struct Map {
+    std::shared_ptr<std::map<K, V>> m;
+    Map() = default;
+    Map(nil_t) {}
+    V& operator[](const K& k) { if (!m) panic_str("assignment to entry in nil map"); return (*m)[k]; }
+    friend bool operator==(const Map& a, nil_t) { return !a.m; }
+    friend bool operator!=(const Map& a, nil_t) { return (bool)a.m; }
+};
+template <class K, class V> inline std::tuple<V, bool> map_get2(const Map<K, V>& m, const K& k) {
+    if (!m.m) return {V(), false};
+    auto it = m.m->find(k);
+    if (it == m.m->end()) return {V(), false};
+    return {it->second, true};
+}
+template <class K, class V> inline Int len(const Map<K, V>& m) { return Int::from_raw(m.m ? (int64_t)m.m->size() : 0); }
+template <class K, class V> inline Map<K, V> make_map() { Map<K, V> r; r.m = std::make_shared<std::map<K, V>>(); return r; }
+template <class K, class V> inline void map_delete(Map<K, V>& m, const K& k) { if (m.m) m.m->erase(k); }
+
+}  // namespace go
+
+// ---------------------------------------------------------------------------------------------------------------- std packages
+namespace go_errors {
+inline go::error New(const go::String& s) { return go::New<go::errorString>(go::errorString(s)); }
+}
+
+namespace go_fmt {
+inline void fmt_arg(std::string& out, const go::String& v) { out += v.s; }
+inline void fmt_arg(std::string& out, const char* v) { out += v; }
+inline void fmt_arg(std::string& out, go::U v) { out += std::to_string((long long)v.v); }
+inline void fmt_arg(std::string& out, bool v) { out += v ? "true" : "false"; }
+inline void fmt_arg(std::string& out, double v) { out += std::to_string(v); }
+inline void fmt_arg(std::string& out, go::error e) { out += e ? e->Error().s : "<nil>"; }
+template <class T, class G> inline void fmt_arg(std::string& out, go::I<T, G> v) {
+    if constexpr (std::is_signed_v<T>) out += std::to_string((long long)v.v); else out += std::to_string((unsigned long long)v.v);
+}
+template <class T> inline void fmt_arg(std::string& out, const T&) { out += "?"; }
+// verbs are replaced in order by the arguments' default renderings (messages are diagnostics: never compared)
+template <class... A> inline go::String Sprintf(const go::String& f, const A&... a) {
+    std::vector<std::string> args;
+    (([&] { std::string s; fmt_arg(s, a); args.push_back(s); })(), ...);
+    std::string out;
+    size_t k = 0;
+    for (size_t i = 0; i < f.s.size(); i++) {
+        if (f.s[i] != '%') { out += f.s[i]; continue; }
+        if (i + 1 < f.s.size() && f.s[i + 1] == '%') { out += '%'; i++; continue; }
+        size_t j = i + 1;
+        while (j < f.s.size() && !isalpha((unsigned char)f.s[j])) j++;
+        out += k < args.size() ? args[k++] : std::string("%!missing");
+        i = j;
+    }
+    return go::String(out);
+}
+template <class... A> inline go::error Errorf(const go::String& f, const A&... a) { return go_errors::New(Sprintf(f, a...)); }
+template <class... A> inline void Printf(const go::String& f, const A&... a) { std::fputs(Sprintf(f, a...).s.c_str(), stderr); }
+template <class... A> inline void Println(const A&... a) { std::string s; ((fmt_arg(s, a), s += ' '), ...); s += '\n'; std::fputs(s.c_str(), stderr); }
+template <class... A> inline go::String Sprint(const A&... a) { std::string s; (fmt_arg(s, a), ...); return go::String(s); }
+}  // namespace go_fmt
+
+namespace go_binary {
+struct BigEndian_t {
+    BigEndian_t* operator->() { return this; }
+    const BigEndian_t* operator->() const { return this; }
+    static void need(const go::Slice<go::Byte>& b, int64_t n) { if (b.n < n) go::oob(n - 1, b.n); }
+    go::Uint16 Uint16(const go::Slice<go::Byte>& b) const { need(b, 2); return go::Uint16::from_raw((uint16_t)((b.p[0].v << 8) | b.p[1].v)); }
+    go::Uint32 Uint32(const go::Slice<go::Byte>& b) const { need(b, 4); uint32_t x; std::memcpy(&x, b.p, 4); return go::Uint32::from_raw(__builtin_bswap32(x)); }
+    go::Uint64 Uint64(const go::Slice<go::Byte>& b) const { need(b, 8); uint64_t x; std::memcpy(&x, b.p, 8); return go::Uint64::from_raw(__builtin_bswap64(x)); }
+    void PutUint16(const go::Slice<go::Byte>& b, go::Uint16 v) const { need(b, 2); b.p[0].v = (uint8_t)(v.v >> 8); b.p[1].v = (uint8_t)v.v; }
+    void PutUint32(const go::Slice<go::Byte>& b, go::Uint32 v) const { need(b, 4); uint32_t x = __builtin_bswap32(v.v); std::memcpy(b.p, &x, 4); }
+    void PutUint64(const go::Slice<go::Byte>& b, go::Uint64 v) const { need(b, 8); uint64_t x = __builtin_bswap64(v.v); std::memcpy(b.p, &x, 8); }
+};
+struct LittleEndian_t {
+    LittleEndian_t* operator->() { return this; }
+    const LittleEndian_t* operator->() const { return this; }
+    static void need(const go::Slice<go::Byte>& b, int64_t n) { if (b.n < n) go::oob(n - 1, b.n); }
+    go::Uint16 Uint16(const go::Slice<go::Byte>& b) const { need(b, 2); uint16_t x; std::memcpy(&x, b.p, 2); return go::Uint16::from_raw(x); }
+    go::Uint32 Uint32(const go::Slice<go::Byte>& b) const { need(b, 4); uint32_t x; std::memcpy(&x, b.p, 4); return go::Uint32::from_raw(x); }
+    go::Uint64 Uint64(const go::Slice<go::Byte>& b) const { need(b, 8); uint64_t x; std::memcpy(&x, b.p, 8); return go::Uint64::from_raw(x); }
+    void PutUint16(const go::Slice<go::Byte>& b, go::Uint16 v) const { need(b, 2); std::memcpy(b.p, &v.v, 2); }
+    void PutUint32(const go::Slice<go::Byte>& b, go::Uint32 v) const { need(b, 4); std::memcpy(b.p, &v.v, 4); }
+    void PutUint64(const go::Slice<go::Byte>& b, go::Uint64 v) const { need(b, 8); std::memcpy(b.p, &v.v, 8); }
+};
+inline BigEndian_t BigEndian;
+inline LittleEndian_t LittleEndian;
+}  // namespace go_binary
+
+namespace go_bits {
+inline go::Int TrailingZeros64(go::Uint64 x) { return go::Int::from_raw(x.v ? __builtin_ctzll(x.v) : 64); }
+inline go::Int TrailingZeros32(go::Uint32 x) { return go::Int::from_raw(x.v ? __builtin_ctz(x.v) : 32); }
+inline go::Int LeadingZeros64(go::Uint64 x) { return go::Int::from_raw(x.v ? __builtin_clzll(x.v) : 64); }
+inline go::Int LeadingZeros32(go::Uint32 x) { return go::Int::from_raw(x.v ? __builtin_clz(x.v) : 32); }
+inline go::Int Len64(go::Uint64 x) { return go::Int::from_raw(x.v ? 64 - __builtin_clzll(x.v) : 0); }
+inline go::Int Len32(go::Uint32 x) { return go::Int::from_raw(x.v ? 32 - __builtin_clz(x.v) : 0); }
+inline go::Int OnesCount64(go::Uint64 x) { return go::Int::from_raw(__builtin_popcountll(x.v)); }
+inline go::Uint32 RotateLeft32(go::Uint32 x, go::Int k) { unsigned s = (unsigned)k.v & 31; return go::Uint32::from_raw(s ? (x.v << s) | (x.v >> (32 - s)) : x.v); }
+inline go::Uint64 RotateLeft64(go::Uint64 x, go::Int k) { unsigned s = (unsigned)k.v & 63; return go::Uint64::from_raw(s ? (x.v << s) | (x.v >> (64 - s)) : x.v); }
+inline go::Uint64 ReverseBytes64(go::Uint64 x) { return go::Uint64::from_raw(__builtin_bswap64(x.v)); }
+inline go::Uint32 ReverseBytes32(go::Uint32 x) { return go::Uint32::from_raw(__builtin_bswap32(x.v)); }
+}  // namespace go_bits
+
+namespace go_sort {
+inline void Ints(const go::Slice<go::Int>& s) { std::sort(s.p, s.p + s.n, [](go::Int a, go::Int b) { return a.v < b.v; }); }
+}
+namespace go_slices {
+template <class T, class F> inline void SortStableFunc(const go::Slice<T>& s, F cmp) {
+    std::stable_sort(s.p, s.p + s.n, [&](const T& a, const T& b) { return cmp(a, b) < go::Int(); });
+}
+template <class T, class F> inline void SortFunc(const go::Slice<T>& s, F cmp) {
+    std::sort(s.p, s.p + s.n, [&](const T& a, const T& b) { return cmp(a, b) < go::Int(); });
+}
+}
+namespace go_io {
+struct Reader { virtual std::tuple<go::Int, go::error> Read(go::Slice<go::Byte> b) = 0; virtual ~Reader() = default; };
+struct Writer { virtual std::tuple<go::Int, go::error> Write(go::Slice<go::Byte> b) = 0; virtual ~Writer() = default; };
+struct Closer { virtual go::error Close() = 0; virtual ~Closer() = default; };
+struct ReadCloser { virtual std::tuple<go::Int, go::error> Read(go::Slice<go::Byte> b) = 0; virtual go::error Close() = 0; virtual ~ReadCloser() = default; };
+struct WriteCloser { virtual std::tuple<go::Int, go::error> Write(go::Slice<go::Byte> b) = 0; virtual go::error Close() = 0; virtual ~WriteCloser() = default; };
+struct ReadWriteCloser {
+    virtual std::tuple<go::Int, go::error> Read(go::Slice<go::Byte> b) = 0; virtual std::tuple<go::Int, go::error> Write(go::Slice<go::Byte> b) = 0;
+    virtual go::error Close() = 0; virtual ~ReadWriteCloser() = default;
+};
+inline go::errorString EOF_value{go::String("EOF")};
+inline go::error EOF_ = &EOF_value;
+}  // namespace go_io
+namespace go_sync {
+// goroutines of the translated files run one after the other (`go f(x)` is emitted as the call): a WaitGroup has nothing to wait for
+struct WaitGroup {
+    WaitGroup* operator->() { return this; }
+    template <class T> void Add(T) {}
+    void Done() {}
+    void Wait() {}
+};
+struct Mutex { Mutex* operator->() { return this; } void Lock() {} void Unlock() {} };
+}  // namespace go_sync
+
+namespace go_strings {
+inline go::String ToUpper(const go::String& s) { std::string r = s.s; for (char& c : r) c = (char)toupper((unsigned char)c); return go::String(r); }
+inline go::String ToLower(const go::String& s) { std::string r = s.s; for (char& c : r) c = (char)tolower((unsigned char)c); return go::String(r); }
+inline go::Int IndexByte(const go::String& s, go::Byte c) { size_t k = s.s.find((char)c.v); return go::Int::from_raw(k == std::string::npos ? -1 : (int64_t)k); }
+inline bool Contains(const go::String& s, const go::String& sub) { return s.s.find(sub.s) != std::string::npos; }
+inline bool HasPrefix(const go::String& s, const go::String& pre) { return s.s.compare(0, pre.s.size(), pre.s) == 0; }
+inline go::Slice<go::String> Split(const go::String& s, const go::String& sep) {
+    std::vector<go::String> parts;
+    size_t a = 0;
+    while (true) {
+        size_t k = sep.s.empty() ? std::string::npos : s.s.find(sep.s, a);
+        if (k == std::string::npos) { parts.push_back(go::String(s.s.substr(a))); break; }
+        parts.push_back(go::String(s.s.substr(a, k - a)));
+        a = k + sep.s.size();
+    }
+    // (String is not trivially copyable: the slice's cells are constructed in place and never destroyed -- arena memory)
+    go::String* mem = (go::String*)go::alloc_zero(parts.size() * sizeof(go::String));
+    for (size_t i = 0; i < parts.size(); i++) new (mem + i) go::String(parts[i]);
+    return go::Slice<go::String>(mem, (int64_t)parts.size(), (int64_t)parts.size());
+}
+}  // namespace go_strings
+
+namespace go_bytes {
+// bytes.Buffer as internal.BufferStream uses it: append at the end, read from the front
+struct Buffer {
+    Buffer* operator->() { return this; }
+    std::string data;
+    size_t rd = 0;
+    std::tuple<go::Int, go::error> Write(go::Slice<go::Byte> b) { data.append((const char*)b.p, (size_t)b.n); return {go::Int::from_raw(b.n), nullptr}; }
+    std::tuple<go::Int, go::error> Read(go::Slice<go::Byte> b) {
+        size_t n = std::min<size_t>((size_t)b.n, data.size() - rd);
+        if (n == 0 && b.n > 0) return {go::Int(), go_io::EOF_};
+        std::memcpy((void*)b.p, data.data() + rd, n);
+        rd += n;
+        return {go::Int::from_raw((int64_t)n), nullptr};
+    }
+    go::Int Len() { return go::Int::from_raw((int64_t)(data.size() - rd)); }
+    go::Int Available() { return go::Int::from_raw((int64_t)(data.capacity() - data.size())); }
+};
+inline Buffer* NewBuffer(go::Slice<go::Byte> b) { Buffer* r = go::New<Buffer>(); r->data.assign((const char*)b.p, (size_t)b.n); return r; }
+}  // namespace go_bytes
