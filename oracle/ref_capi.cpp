@@ -231,6 +231,64 @@ int kref_bwt_inverse(const uint8_t* src, uint64_t n, uint8_t* dst, const uint64_
     KREF_CATCH
 }
 
+// == what app/BlockCompressor.go does with a file: io.NewWriterWithCtx(os, ctx); w.Write(data); w.Close()  (io/CompressedStream.go:232-620).
+// The goroutines of Writer.processBlock run one after the other (`go task.encode(..)` is emitted as the call; the tasks' lock-free hand-over of
+// the shared bit stream, :935-949, is satisfied in block order). file_size < 0: ctx["fileSize"] absent. Returns the .knz stream.
+int kref_compress(const uint8_t* src, uint64_t n, const char* transform, const char* entropy, uint32_t block_size, uint32_t checksum_bits, uint32_t jobs,
+                  int64_t file_size, int skip_blocks, uint8_t* dst, uint64_t cap, uint64_t* out_n) {
+    KREF_TRY
+    MemStream ms;
+    Ctx ctx = go::make_map<go::String, go::any>();
+    ctx[go::String("entropy")] = go::any(go::String(entropy));
+    ctx[go::String("transform")] = go::any(go::String(transform));
+    ctx[go::String("blockSize")] = go::any(go::Uint(go::U(block_size)));
+    ctx[go::String("jobs")] = go::any(go::Uint(go::U(jobs ? jobs : 1)));
+    ctx[go::String("checksum")] = go::any(go::Uint(go::U(checksum_bits)));
+    if (file_size >= 0) ctx[go::String("fileSize")] = go::any(go::Int64(go::U(file_size)));
+    ctx[go::String("headerless")] = go::any(false);
+    if (skip_blocks) ctx[go::String("skipBlocks")] = go::any(true);
+    auto [w, err] = kz_io::NewWriterWithCtx(&ms, ctx);
+    if (err != nullptr) return fail(err, 1);
+    // (the application hands the writer its read buffer piece by piece; one call with everything writes the same stream)
+    auto [wr, werr] = w->Write(copy_in(src, n));
+    if (werr != nullptr) return fail(werr, 2);
+    go::error cerr = w->Close();
+    if (cerr != nullptr) return fail(cerr, 3);
+    if (ms.data.size() > cap) { g_err = "output buffer too small"; return 4; }
+    memcpy(dst, ms.data.data(), ms.data.size());
+    *out_n = ms.data.size();
+    return 0;
+    KREF_CATCH
+}
+
+// == io.NewReader(is, jobs); r.Read(...) until EOF; r.Close()  (io/CompressedStream.go:1047-1760)
+int kref_decompress(const uint8_t* src, uint64_t n, uint32_t jobs, uint8_t* dst, uint64_t cap, uint64_t* out_n) {
+    KREF_TRY
+    MemStream ms;
+    ms.data.assign((const char*)src, (size_t)n);
+    auto [r, err] = kz_io::NewReader(&ms, go::Uint(go::U(jobs ? jobs : 1)));
+    if (err != nullptr) return fail(err, 1);
+    go::Slice<go::Byte> buf = go::Slice<go::Byte>::make(1 << 20, 1 << 20);
+    uint64_t total = 0;
+    while (true) {
+        auto [k, rerr] = r->Read(buf);
+        if (k.v > 0) {
+            if (total + (uint64_t)k.v > cap) { g_err = "output buffer too small"; return 4; }
+            memcpy(dst + total, buf.p, (size_t)k.v);
+            total += (uint64_t)k.v;
+        }
+        if (rerr != nullptr) {
+            if (rerr == go_io::EOF_) break;
+            return fail(rerr, 2);
+        }
+        if (k.v == 0) break;
+    }
+    r->Close();
+    *out_n = total;
+    return 0;
+    KREF_CATCH
+}
+
 uint32_t kref_xxhash32(const uint8_t* d, uint64_t n, uint32_t seed) {
     go::ArenaScope arena_;
     auto [h, err] = kz_hash::NewXXHash32(go::Uint32(go::U(seed)));

@@ -196,3 +196,28 @@ def transform_type(name):
 
 def entropy_type(name):
     return int(lib().kref_entropy_type(name.encode()))
+
+
+def compress(data, transform="NONE", entropy="NONE", block_size=4 << 20, checksum_bits=0, jobs=1, header_size=None, skip_blocks=False):
+    """the reference's own Writer (io/CompressedStream.go) over `data` -> the .knz stream; header_size: ctx["fileSize"] (default len(data), -1 = absent)"""
+    L = lib()
+    L.kref_compress.argtypes = [C.POINTER(C.c_uint8), C.c_uint64, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int64, C.c_int,
+                                C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint64)]
+    a, p, _k = _u8(data)
+    cap = len(a) + len(a) // 2 + (1 << 20)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_uint64()
+    fs = len(a) if header_size is None else header_size
+    _chk(L.kref_compress(p, len(a), transform.encode(), entropy.encode(), block_size, checksum_bits, jobs, fs, 1 if skip_blocks else 0,
+                         out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n)))
+    return out[: n.value].tobytes()
+
+
+def decompress(stream, cap, jobs=1):
+    L = lib()
+    L.kref_decompress.argtypes = [C.POINTER(C.c_uint8), C.c_uint64, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint64)]
+    a, p, _k = _u8(stream)
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = C.c_uint64()
+    _chk(L.kref_decompress(p, len(a), jobs, out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n)))
+    return out[: n.value].tobytes()

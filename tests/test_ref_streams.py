@@ -1,10 +1,11 @@
-"""Reference-generated parity pin: .knz streams written by flanglet/kanzi-go itself.
+"""Reference-generated parity pin: .knz streams written by flanglet/kanzi-go's own Writer.
 
-The build image has no Go toolchain, so the repository ships the recipe (tools/make_ref_vectors.sh + tools/refgen/main.go) and this
-test instead of the files. As soon as tests/golden/ref_streams/ holds streams (one command on any machine with Go), these tests
-REQUIRE, for every stream: oracle-encode == file and oracle-decode(file) == input (CPU suite), device-encode == file and
-device-decode(file) == input (GPU suite). Until then they say so loudly: every parity claim in this repository is against the
-in-repo restatement (oracle/), which no reference-generated byte pins yet.
+tests/golden/ref_streams/manifest.json holds, for 387 (input, configuration) cases, the length and sha256 of the stream the REFERENCE'S OWN CODE
+writes (io/CompressedStream.go and everything under it), and the stream itself for the small inputs. The image has no Go toolchain: the
+producer is oracle/_ref = the reference's .go files translated mechanically to C++ by tools/go2cpp (tools/make_ref_vectors_go2cpp.py, committed
+recipe, runs in the build container); tools/make_ref_vectors.sh is the same recipe for a machine with Go and writes the same manifest.
+These tests REQUIRE, for every case: oracle-encode == reference stream and oracle-decode(stream) == input (CPU suite), device-encode ==
+reference stream and device-decode(stream) == input (GPU suite: neither /root/reference nor oracle/_ref is needed there, only the fixtures).
 """
 import importlib.util
 import json
@@ -17,8 +18,8 @@ import oracle_lib as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_DIR = os.path.join(ROOT, "tests", "golden", "ref_streams")
-UNPINNED = ("PARITY UNPINNED: tests/golden/ref_streams/ holds no reference-generated streams (no Go toolchain in the build image). "
-            "Run tools/make_ref_vectors.sh /path/to/kanzi-go on a machine with Go and commit the result to pin the oracle and the device.")
+UNPINNED = ("PARITY UNPINNED: tests/golden/ref_streams/ holds no reference-generated streams. Run tools/make_ref_vectors_go2cpp.py (build container, "
+            "needs /root/reference) or tools/make_ref_vectors.sh /path/to/kanzi-go (a machine with Go) and commit the result.")
 
 
 def _gen():
@@ -29,16 +30,26 @@ def _gen():
 
 
 def _cases():
-    """[(case dict, stream bytes)] for every manifest entry whose stream file is present."""
+    """[(case dict, stream bytes or None)] for every manifest entry: the stream's sha256 is always there, its bytes for the small ones (or for all
+    of them when the Go recipe wrote the files)."""
     mpath = os.path.join(REF_DIR, "manifest.json")
     if not os.path.exists(mpath):
         return []
     out = []
     for c in json.load(open(mpath))["cases"]:
-        f = os.path.join(REF_DIR, c["name"] + ".knz")
-        if os.path.exists(f):
-            out.append((c, open(f, "rb").read()))
+        f = os.path.join(REF_DIR, c.get("file", c["name"] + ".knz"))
+        stream = open(f, "rb").read() if os.path.exists(f) else None
+        if stream is None and "sha256" not in c:
+            continue
+        out.append((c, stream))
     return out
+
+
+def _same(got, c, ref):
+    import hashlib
+    if ref is not None:
+        return got == ref
+    return len(got) == c["stream_bytes"] and hashlib.sha256(got).hexdigest() == c["sha256"]
 
 
 def _inputs():
@@ -55,6 +66,24 @@ def test_manifest_generator_is_deterministic(tmp_path):
     m = json.load(open(tmp_path / "manifest.json"))
     assert len(m["cases"]) >= 100
     assert {c["entropy"] for c in m["cases"]} >= {"HUFFMAN", "ANS0", "ANS1", "FPAQ", "NONE"}
+    committed = json.load(open(os.path.join(REF_DIR, "manifest.json")))
+    assert [c["name"] for c in committed["cases"]] == [c["name"] for c in m["cases"]], "the committed manifest is not the generator's case list"
+
+
+def test_committed_vectors_are_what_the_reference_writes_today():
+    """Where /root/reference is present (build container): regenerate every stream with oracle/_ref and compare with the committed manifest."""
+    import ref_lib as R
+    if not R.can_build():
+        pytest.skip("/root/reference is not here (GPU box): the committed fixtures stand on their own")
+    data = _inputs()
+    cases = _cases()
+    assert len(cases) >= 300
+    for c, ref in cases:
+        src = data[c["input"][:-4]]
+        for jobs in (1, 3):
+            got = R.compress(src, c["transform"], c["entropy"], c["block_size"], c["checksum"], jobs=jobs, skip_blocks=c["skip_blocks"])
+            assert _same(got, c, ref), (c["name"], jobs)
+        assert R.decompress(got, len(src) + 64, jobs=2) == src, c["name"]
 
 
 def test_oracle_against_reference_streams():
@@ -67,8 +96,8 @@ def test_oracle_against_reference_streams():
         src = data[c["input"][:-4]]
         assert len(src) == c["input_bytes"], c["name"]
         got = O.compress(src, c["transform"], c["entropy"], c["block_size"], c["checksum"], skip_blocks=c["skip_blocks"])
-        assert got == ref, f"{c['name']}: the oracle's stream differs from the reference's"
-        assert O.decompress(ref, len(src) + 64) == src, c["name"]
+        assert _same(got, c, ref), f"{c['name']}: the oracle's stream differs from the reference's"
+        assert O.decompress(got, len(src) + 64) == src, c["name"]          # (got IS the reference's stream at this point)
 
 
 @pytest.mark.gpu
@@ -90,9 +119,10 @@ def test_device_against_reference_streams():
         cap = 2 * n + 262144 * (n // c["block_size"] + 2)
         dst, kdst = be.empty(cap)
         nb = codec.dev_compress(sp, n, dst, cap)
-        assert be.to_host(kdst, nb) == ref, f"{c['name']}: the device's stream differs from the reference's"
-        rp, _k2 = be.to_dev(ref, 4)
+        got = be.to_host(kdst, nb)
+        assert _same(got, c, ref), f"{c['name']}: the device's stream differs from the reference's"
+        rp, _k2 = be.to_dev(got, 4)                                              # (byte for byte the reference's stream)
         out, kout = be.empty(n + 4096)
-        nd = codec.dev_decompress(rp, len(ref), out, n + 4096)
+        nd = codec.dev_decompress(rp, len(got), out, n + 4096)
         assert nd == n and be.to_host(kout, nd) == src, c["name"]
         codec.close()

@@ -44,8 +44,8 @@ STD_INTERFACES = {
     ("io", "ReadWriteCloser"): {"Read": RW_SIG, "Write": RW_SIG, "Close": ((), ("go::error",))},
     ("go", "error_iface"): {"Error": ((), ("go::String",))},
 }
-STD_VALUE_TYPES = {("sync", "WaitGroup"): "::go_sync::WaitGroup", ("sync", "Mutex"): "::go_sync::Mutex", ("bytes", "Buffer"): "::go_bytes::Buffer"}
-STD_PACKAGES = {"errors", "fmt", "encoding/binary", "math/bits", "sort", "slices", "io", "sync", "strings", "bytes"}
+STD_VALUE_TYPES = {("sync", "WaitGroup"): "::go_sync::WaitGroup", ("sync", "Mutex"): "::go_sync::Mutex", ("bytes", "Buffer"): "::go_bytes::Buffer", ("time", "Time"): "::go_time::Time"}
+STD_PACKAGES = {"errors", "fmt", "encoding/binary", "math/bits", "sort", "slices", "io", "sync", "strings", "bytes", "sync/atomic", "time", "runtime"}
 
 
 THIS_IS_RECEIVER = [False]     # Go's conventional receiver name `this` is C++'s `this` inside methods; elsewhere it is an ordinary local
@@ -112,11 +112,25 @@ def escaping_names(n, out):
             b = base_ident(n.x)
             if b is not None:
                 out.add(b)
+        elif n.kind == "Defer":
+            walk_idents(n.call, out)           # a deferred closure runs after the body's block is gone: everything it names gets heap storage
         for v in n.f.values():
             escaping_names(v, out)
     elif isinstance(n, (list, tuple)):
         for v in n:
             escaping_names(v, out)
+
+
+def has_defer(n):
+    if isinstance(n, Node):
+        if n.kind == "Defer":
+            return True
+        if n.kind == "FuncLit":
+            return False
+        return any(has_defer(v) for v in n.f.values())
+    if isinstance(n, (list, tuple)):
+        return any(has_defer(v) for v in n)
+    return False
 
 
 class Package:
@@ -417,7 +431,9 @@ class Translator:
         for p in sig.params:
             if p.name:
                 self.declare(p.name)
+        self.in_closure += 1
         body = self.func_body(x.body, sig)
+        self.in_closure -= 1
         self.cur_results, self.named_results = saved
         self.pop()
         return f"[&]({self.params_decl(sig)}) -> {self.result_ctype(sig)} {body}"
@@ -498,7 +514,11 @@ class Translator:
         if n == "new":
             t = self.resolve_type_expr(a[0])
             return f"go::New<{self.ctype(t)}>()"
-        if n in ("print", "println", "recover", "delete", "complex", "real", "imag", "close"):
+        if n == "recover":
+            return "go::recover()"
+        if n == "delete":
+            return f"go::map_delete({self.ex(a[0])}, {self.ex(a[1])})"
+        if n in ("print", "println", "complex", "real", "imag", "close"):
             self.err(x, f"builtin {n} is not supported")
         return None
 
@@ -605,7 +625,21 @@ class Translator:
         return f"{self.ex(s.call)};   // (go statement: run in place)"
 
     def st_Defer(self, s):
-        self.err(s, "defer is not supported")
+        if not self.defer_frame:
+            self.err(s, "defer inside a closure is not supported")
+        c = s.call
+        if c.kind != "Call":
+            self.err(s, "defer of a non-call")
+        if c.fun.kind == "FuncLit" and not c.args:
+            return f"_df.push({self.ex(c.fun)});"
+        # defer f(args): the arguments are evaluated now, the call runs at exit
+        tmps, pre = [], []
+        for a in c.args:
+            t = self.tmpname("da")
+            pre.append(f"auto& {t} = *go::New(go::def({self.ex(a)}));")
+            tmps.append(t)
+        fn = self.ex(c.fun)
+        return "\n".join(pre) + f"\n_df.push([&]() {{ {fn}({', '.join(tmps)}); }});"
 
     def st_Labeled(self, s):
         inner = s.stmt
@@ -631,6 +665,34 @@ class Translator:
         return f"goto {mangle(s.label)}_continue;"
 
     def st_Return(self, s):
+        if self.defer_frame and self.in_closure == 0:
+            return self.defer_return(s)
+        return self.plain_return(s)
+
+    def defer_return(self, s):
+        """inside a function that defers: results go to the frame's result variables, then control leaves the try block"""
+        rs = self.cur_results
+        if not rs:
+            return "goto _df_done;"
+        names = [mangle(n) for n in self.named_results] if self.named_results else [f"_ret{i}" for i in range(len(rs))]
+        if not s.values:
+            return "goto _df_done;"
+        if len(s.values) == len(rs):
+            tmps = []
+            out = ["{"]
+            for v in s.values:
+                t = self.tmpname()
+                tmps.append(t)
+                out.append(f"auto {t} = {self.ex(v)};")
+            out += [f"{n} = {t};" for n, t in zip(names, tmps)]
+            out.append("goto _df_done; }")
+            return " ".join(out)
+        if len(s.values) == 1:
+            t = self.tmpname()
+            return f"{{ auto {t} = {self.ex(s.values[0])}; " + " ".join(f"{n} = std::get<{i}>({t});" for i, n in enumerate(names)) + " goto _df_done; }"
+        self.err(s, "return arity")
+
+    def plain_return(self, s):
         rs = self.cur_results
         if not s.values:
             if not rs:
@@ -870,7 +932,7 @@ class Translator:
         label, self.loop_label = self.loop_label, None
         self.push()
         r, n, i = self.tmpname("r"), self.tmpname("n"), self.tmpname("i")
-        out = ["{", f"auto&& {r} = {self.ex(s.x)};", f"int64_t {n} = go::range_len({r});"]
+        out = ["{", f"auto&& {r}x = {self.ex(s.x)};", f"auto {r} = go::ranger({r}x);", f"int64_t {n} = {r}.n;"]
         head = []
         key = s.key if (s.key is not None and not (s.key.kind == "Ident" and s.key.name == "_")) else None
         val = s.value if (s.value is not None and not (s.value.kind == "Ident" and s.value.name == "_")) else None
@@ -878,15 +940,15 @@ class Translator:
         if key is not None:
             if s.define:
                 self.declare(key.name)
-                head.append(f"go::Int {mangle(key.name)} = go::Int::from_raw({i});")
+                head.append(f"auto {mangle(key.name)} = {r}.key({i});")
             else:
-                head.append(f"{self.ex(key)} = go::Int::from_raw({i});")
+                head.append(f"{self.ex(key)} = {r}.key({i});")
         if val is not None:
             if s.define:
                 self.declare(val.name)
-                head.append(f"auto {mangle(val.name)} = go::range_at({r}, {i});")
+                head.append(f"auto {mangle(val.name)} = {r}.val({i});")
             else:
-                head.append(f"{self.ex(val)} = go::range_at({r}, {i});")
+                head.append(f"{self.ex(val)} = {r}.val({i});")
         saved_fall = self.fall_var
         self.fall_var = None
         body, tail = self.loop_wrap(label, lambda: self.block(s.body))
@@ -949,8 +1011,102 @@ class Translator:
         self.pop()
         return "\n".join(out)
 
+    def st_TypeSwitch(self, s):
+        label, self.loop_label = self.loop_label, None
+        self.push()
+        out = ["{"]
+        if s.init is not None:
+            out.append(self.stmt(s.init))
+        ts = self.tmpname("ts")
+        out.append(f"go::any {ts} = {self.ex(s.x)};")
+        out.append("switch (0) { default:")
+        first = True
+        default = None
+        saved_fall = self.fall_var
+        self.fall_var = None
+        for c in s.clauses:
+            if c.types is None:
+                default = c
+                continue
+            conds = []
+            for t in c.types:
+                if t.kind == "NamedType" and t.pkg is None and t.name == "nil":
+                    conds.append(f"({ts} == go::nil)")
+                else:
+                    conds.append(f"go::type_is<{self.ctype(t)}>({ts})")
+            self.push()
+            bind = ""
+            if s.bind and s.bind != "_":
+                self.declare(s.bind)
+                if len(c.types) == 1:
+                    bind = f"auto {mangle(s.bind)} = go::assert1<{self.ctype(c.types[0])}>({ts}); (void){mangle(s.bind)};\n"
+                else:
+                    bind = f"auto& {mangle(s.bind)} = {ts}; (void){mangle(s.bind)};\n"
+            body = "\n".join(self.stmt(b) for b in c.body)
+            self.pop()
+            out.append(f"{'if' if first else 'else if'} ({' || '.join(conds)}) {{\n{bind}{body}\n}}")
+            first = False
+        if default is not None:
+            self.push()
+            bind = ""
+            if s.bind and s.bind != "_":
+                self.declare(s.bind)
+                bind = f"auto& {mangle(s.bind)} = {ts}; (void){mangle(s.bind)};\n"
+            body = "\n".join(self.stmt(b) for b in default.body)
+            self.pop()
+            out.append(f"{'else ' if not first else ''}{{\n{bind}{body}\n}}")
+        self.fall_var = saved_fall
+        out.append("}")
+        out.append("}")
+        self.pop()
+        return "\n".join(out)
+
     # ------------------------------------------------------------------------------------------------ functions
     def func_body(self, body, sig):
+        if self.defer_frame and self.in_closure == 0:
+            return self.func_body_deferring(body, sig)
+        return self.func_body_plain(body, sig)
+
+    def func_body_deferring(self, body, sig):
+        """Go's defer / recover: the body runs inside try; deferred closures run after it, last in first out, whether it returned or panicked;
+        recover() inside one of them stops the panic; results live outside the try block so that the closures can still change them."""
+        self.push()
+        rs = sig.results
+        lines = ["{"]
+        if rs and rs[0].name:
+            names = []
+            for r in rs:
+                self.declare(r.name)
+                lines.append(f"{self.ctype(r.typ)} {mangle(r.name)}{{}};")
+                names.append(mangle(r.name))
+        else:
+            names = [f"_ret{i}" for i in range(len(rs))]
+            for i, r in enumerate(rs):
+                lines.append(f"{self.ctype(r.typ)} _ret{i}{{}};")
+        lines.append("go::DeferFrame _df;")
+        lines.append("try {")
+        saved = (self.loop_label, self.fall_var, self.used_continue_labels)
+        self.loop_label, self.fall_var, self.used_continue_labels = None, None, set()
+        self.push()
+        for st in body.stmts:
+            lines.append(self.stmt(st))
+        self.pop()
+        self.loop_label, self.fall_var, self.used_continue_labels = saved
+        lines.append("goto _df_done;")
+        lines.append("} catch (go::PanicException& _e) { _df.set_panic(_e); }")
+        lines.append("_df_done:;")
+        lines.append("_df.run();")
+        if not rs:
+            lines.append("return;")
+        elif len(rs) == 1:
+            lines.append(f"return {names[0]};")
+        else:
+            lines.append("return std::tuple<" + ", ".join(self.ctype(r.typ) for r in rs) + ">(" + ", ".join(names) + ");")
+        lines.append("}")
+        self.pop()
+        return "\n".join(lines)
+
+    def func_body_plain(self, body, sig):
         """body block with the named results declared up front"""
         self.push()
         lines = ["{"]
@@ -978,6 +1134,8 @@ class Translator:
         self.loop_label = None
         self.fall_var = None
         self.used_continue_labels = set()
+        self.in_closure = 0
+        self.defer_frame = has_defer(d.body)
         for p in d.sig.params:
             if p.name:
                 self.declare(p.name)

@@ -665,12 +665,14 @@ class Parser:
                         self.err("switch tag")
                     tag = s2.x
             else:
+                if s.kind == "Define" and len(s.names) == 1 and len(s.values) == 1 and s.values[0].kind == "TypeAssert" and s.values[0].typ is None:
+                    return self.type_switch_body(pos, init, s.names[0], s.values[0].x, old)      # switch v := x.(type)
                 if s.kind != "ExprStmt":
-                    self.err("type switches are not supported")
+                    self.err("switch header")
                 tag = s.x
+                if tag.kind == "TypeAssert" and tag.typ is None:
+                    return self.type_switch_body(pos, init, None, tag.x, old)
         self.expr_lev = old
-        if tag is not None and tag.kind == "TypeAssert" and tag.typ is None:
-            self.err("type switches are not supported")
         self.expect_op("{")
         clauses = []
         while not self.is_op("}"):
@@ -686,6 +688,26 @@ class Parser:
             clauses.append(Node("Case", cpos, exprs=exprs, body=body))
         self.next()
         return Node("Switch", pos, init=init, tag=tag, clauses=clauses)
+
+    def type_switch_body(self, pos, init, bind, x, old_lev):
+        self.expr_lev = old_lev
+        self.expect_op("{")
+        clauses = []
+        while not self.is_op("}"):
+            cpos = self.pos()
+            if self.is_kw("default"):
+                self.next()
+                types = None
+            else:
+                self.expect_kw("case")
+                types = [self.parse_type()]
+                while self.accept_op(","):
+                    types.append(self.parse_type())
+            self.expect_op(":")
+            body = self.stmt_list()
+            clauses.append(Node("TypeCase", cpos, types=types, body=body))
+        self.next()
+        return Node("TypeSwitch", pos, init=init, bind=bind, x=x, clauses=clauses)
 
     # ---- expressions
     def expr_list(self):

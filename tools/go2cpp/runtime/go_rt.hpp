@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <functional>
 #include <map>
 #include <memory>
@@ -24,10 +25,13 @@
 namespace go {
 
 // ---------------------------------------------------------------------------------------------------------------- panics
+// a panic is a C++ exception. `is_error`: the panic value implements `error` (runtime errors do, as in Go: a recovered index-out-of-range
+// lands in the `case error:` arm of the reference's recover blocks); otherwise it is a string.
 struct PanicException : std::runtime_error {
-    explicit PanicException(const std::string& m) : std::runtime_error(m) {}
+    bool is_error;
+    explicit PanicException(const std::string& m, bool is_err = true) : std::runtime_error(m), is_error(is_err) {}
 };
-[[noreturn]] inline void panic_str(const std::string& m) { throw PanicException(m); }
+[[noreturn]] inline void panic_str(const std::string& m) { throw PanicException(m, true); }
 
 // ---------------------------------------------------------------------------------------------------------------- memory
 // Allocations of the translated code live until the C API call that made them returns (Go has a garbage collector; a test
@@ -384,9 +388,9 @@ using error = error_iface*;
 struct errorString : error_iface { String msg; explicit errorString(String m) : msg(std::move(m)) {} String Error() override { return msg; } };
 
 template <class T> [[noreturn]] inline void panic(const T& v) {
-    if constexpr (std::is_convertible_v<T, error>) { error e = v; panic_str(e ? e->Error().s : std::string("nil error")); }
-    else if constexpr (std::is_same_v<T, String>) panic_str(v.s);
-    else panic_str("panic");
+    if constexpr (std::is_convertible_v<T, error>) { error e = v; throw PanicException(e ? e->Error().s : std::string("nil error"), true); }
+    else if constexpr (std::is_same_v<T, String>) throw PanicException(v.s, false);
+    else throw PanicException("panic", false);
 }
 
 // `any`: holds one value of a type the ctx maps of the translated constructors use
@@ -396,17 +400,35 @@ struct any {
     any() = default;
     any(nil_t) {}
     any(U u) : any(Int(u)) {}            // an untyped constant stored in an interface takes its default type
-    template <class T, class = std::enable_if_t<!std::is_same_v<std::decay_t<T>, any> && !std::is_same_v<std::decay_t<T>, nil_t>>>
-    any(T&& v) : ti(&typeid(std::decay_t<T>)), box(std::make_shared<std::decay_t<T>>(std::forward<T>(v))) {}
+    template <class T, class = std::enable_if_t<!std::is_same_v<std::decay_t<T>, any> && !std::is_same_v<std::decay_t<T>, nil_t> && !std::is_same_v<std::decay_t<T>, U>>>
+    any(T&& v) {
+        using D = std::decay_t<T>;
+        if constexpr (std::is_convertible_v<D, error>) { ti = &typeid(error); box = std::make_shared<error>((error)v); }   // a value that implements `error` is kept as one
+        else { ti = &typeid(D); box = std::make_shared<D>(std::forward<T>(v)); }
+    }
     friend bool operator==(const any& a, nil_t) { return a.ti == nullptr; }
     friend bool operator!=(const any& a, nil_t) { return a.ti != nullptr; }
 };
+template <class T> inline bool type_is(const any& a) {
+    if (!a.ti) return false;
+    if (*a.ti == typeid(T)) return true;
+    if constexpr (std::is_pointer_v<T> && std::is_convertible_v<T, error> && !std::is_same_v<T, error>) {
+        if (*a.ti == typeid(error)) return dynamic_cast<T>(*(error*)a.box.get()) != nullptr;
+    }
+    return false;
+}
 template <class T> inline std::tuple<T, bool> assert2(const any& a) {
     if (a.ti && *a.ti == typeid(T)) return {*(T*)a.box.get(), true};
+    if constexpr (std::is_pointer_v<T> && std::is_convertible_v<T, error> && !std::is_same_v<T, error>) {
+        if (a.ti && *a.ti == typeid(error)) { T p = dynamic_cast<T>(*(error*)a.box.get()); if (p) return {p, true}; }
+    }
     return {T(), false};
 }
 template <class T> inline T assert1(const any& a) {
     if (a.ti && *a.ti == typeid(T)) return *(T*)a.box.get();
+    if constexpr (std::is_pointer_v<T> && std::is_convertible_v<T, error> && !std::is_same_v<T, error>) {
+        if (a.ti && *a.ti == typeid(error)) { T p = dynamic_cast<T>(*(error*)a.box.get()); if (p) return p; }
+    }
     panic_str(std::string("interface conversion: interface {} is ") + (a.ti ? a.ti->name() : "nil") + ", not " + typeid(T).name());
 }
 
@@ -428,6 +450,66 @@ template <class K, class V> inline std::tuple<V, bool> map_get2(const Map<K, V>&
 template <class K, class V> inline Int len(const Map<K, V>& m) { return Int::from_raw(m.m ? (int64_t)m.m->size() : 0); }
 template <class K, class V> inline Map<K, V> make_map() { Map<K, V> r; r.m = std::make_shared<std::map<K, V>>(); return r; }
 template <class K, class V> inline void map_delete(Map<K, V>& m, const K& k) { if (m.m) m.m->erase(k); }
+
+// ---------------------------------------------------------------------------------------------------------------- defer / recover
+struct DeferFrame {
+    std::vector<std::function<void()>> fns;
+    bool panicking = false, recovered = false, is_error = true;
+    std::string msg;
+    DeferFrame* prev = nullptr;
+    template <class F> void push(F&& f) { fns.emplace_back(std::forward<F>(f)); }
+    void set_panic(const PanicException& e) { panicking = true; recovered = false; msg = e.what(); is_error = e.is_error; }
+    void run();
+};
+inline thread_local DeferFrame* g_running_defers = nullptr;
+inline void DeferFrame::run() {
+    prev = g_running_defers;
+    g_running_defers = this;
+    while (!fns.empty()) {
+        std::function<void()> f = std::move(fns.back());
+        fns.pop_back();
+        try { f(); } catch (const PanicException& e) { set_panic(e); }        // a panic inside a deferred call replaces the current one
+    }
+    g_running_defers = prev;
+    if (panicking && !recovered) throw PanicException(msg, is_error);
+}
+// recover(): the value of the panic that is unwinding through the function whose deferred call this is, or nil
+inline any recover() {
+    DeferFrame* f = g_running_defers;
+    if (f == nullptr || !f->panicking || f->recovered) return any();
+    f->recovered = true;
+    if (f->is_error) return any((error)New<errorString>(errorString(String(f->msg))));
+    return any(String(f->msg));
+}
+
+// ---------------------------------------------------------------------------------------------------------------- for range
+template <class R> struct Ranger;
+template <class T> struct Ranger<Slice<T>> { const Slice<T>& s; int64_t n; Int key(int64_t i) const { return Int::from_raw(i); } T& val(int64_t i) const { return s.p[i]; } };
+template <class T, size_t N> struct Ranger<Array<T, N>> { const Array<T, N>& a; int64_t n; Int key(int64_t i) const { return Int::from_raw(i); } T val(int64_t i) const { return a.a[i]; } };
+template <class T, size_t N> struct Ranger<Array<T, N>*> { Array<T, N>* a; int64_t n; Int key(int64_t i) const { return Int::from_raw(i); } T& val(int64_t i) const { return a->a[i]; } };
+template <class K, class V> struct Ranger<Map<K, V>> {
+    std::vector<std::pair<K, V>> items; int64_t n;
+    K key(int64_t i) const { return items[(size_t)i].first; }
+    V val(int64_t i) const { return items[(size_t)i].second; }
+};
+struct IntRanger { int64_t n; Int key(int64_t i) const { return Int::from_raw(i); } };
+struct StringRanger {          // (bytes; the translated files range over ASCII strings only)
+    const String& s; int64_t n;
+    Int key(int64_t i) const { return Int::from_raw(i); }
+    Rune val(int64_t i) const { return Rune::from_raw((int32_t)(unsigned char)s.s[(size_t)i]); }
+};
+template <class T> inline Ranger<Slice<T>> ranger(const Slice<T>& s) { return {s, s.n}; }
+template <class T, size_t N> inline Ranger<Array<T, N>> ranger(const Array<T, N>& a) { return {a, (int64_t)N}; }
+template <class T, size_t N> inline Ranger<Array<T, N>*> ranger(Array<T, N>* a) { return {a, (int64_t)N}; }
+template <class K, class V> inline Ranger<Map<K, V>> ranger(const Map<K, V>& m) {
+    Ranger<Map<K, V>> r;
+    if (m.m) for (auto& kv : *m.m) r.items.emplace_back(kv.first, kv.second);
+    r.n = (int64_t)r.items.size();
+    return r;
+}
+inline IntRanger ranger(U u) { return {(int64_t)u.v}; }
+template <class T, class G> inline IntRanger ranger(I<T, G> i) { return {(int64_t)i.v}; }
+inline StringRanger ranger(const String& s) { return {s, (int64_t)s.s.size()}; }
 
 }  // namespace go
 
@@ -525,12 +607,10 @@ namespace go_io {
 struct Reader { virtual std::tuple<go::Int, go::error> Read(go::Slice<go::Byte> b) = 0; virtual ~Reader() = default; };
 struct Writer { virtual std::tuple<go::Int, go::error> Write(go::Slice<go::Byte> b) = 0; virtual ~Writer() = default; };
 struct Closer { virtual go::error Close() = 0; virtual ~Closer() = default; };
-struct ReadCloser { virtual std::tuple<go::Int, go::error> Read(go::Slice<go::Byte> b) = 0; virtual go::error Close() = 0; virtual ~ReadCloser() = default; };
-struct WriteCloser { virtual std::tuple<go::Int, go::error> Write(go::Slice<go::Byte> b) = 0; virtual go::error Close() = 0; virtual ~WriteCloser() = default; };
-struct ReadWriteCloser {
-    virtual std::tuple<go::Int, go::error> Read(go::Slice<go::Byte> b) = 0; virtual std::tuple<go::Int, go::error> Write(go::Slice<go::Byte> b) = 0;
-    virtual go::error Close() = 0; virtual ~ReadWriteCloser() = default;
-};
+// (an interface that embeds others converts to them: virtual bases)
+struct ReadCloser : virtual Reader, virtual Closer {};
+struct WriteCloser : virtual Writer, virtual Closer {};
+struct ReadWriteCloser : virtual ReadCloser, virtual WriteCloser {};
 inline go::errorString EOF_value{go::String("EOF")};
 inline go::error EOF_ = &EOF_value;
 }  // namespace go_io
@@ -568,21 +648,70 @@ inline go::Slice<go::String> Split(const go::String& s, const go::String& sep) {
 }  // namespace go_strings
 
 namespace go_bytes {
-// bytes.Buffer as internal.BufferStream uses it: append at the end, read from the front
+// bytes.Buffer as internal.BufferStream uses it. NewBuffer(b) takes OWNERSHIP of b's backing array: writes append in place while they fit into
+// cap(b) (the block task of io/CompressedStream.go relies on that: it reads the encoded bits back through its own slice of the same array),
+// then the buffer moves to a larger array; reads consume from the front.
 struct Buffer {
     Buffer* operator->() { return this; }
-    std::string data;
-    size_t rd = 0;
-    std::tuple<go::Int, go::error> Write(go::Slice<go::Byte> b) { data.append((const char*)b.p, (size_t)b.n); return {go::Int::from_raw(b.n), nullptr}; }
-    std::tuple<go::Int, go::error> Read(go::Slice<go::Byte> b) {
-        size_t n = std::min<size_t>((size_t)b.n, data.size() - rd);
-        if (n == 0 && b.n > 0) return {go::Int(), go_io::EOF_};
-        std::memcpy((void*)b.p, data.data() + rd, n);
-        rd += n;
-        return {go::Int::from_raw((int64_t)n), nullptr};
+    go::Slice<go::Byte> buf;
+    int64_t off = 0;
+    std::tuple<go::Int, go::error> Write(go::Slice<go::Byte> b) {
+        if (buf.n + b.n > buf.c) {
+            int64_t nc = std::max<int64_t>(2 * buf.c + b.n, 64);
+            go::Slice<go::Byte> nb = go::Slice<go::Byte>::make(buf.n, nc);
+            if (buf.n) std::memcpy((void*)nb.p, (const void*)buf.p, (size_t)buf.n);
+            buf = nb;
+        }
+        if (b.n) std::memmove((void*)(buf.p + buf.n), (const void*)b.p, (size_t)b.n);
+        buf.n += b.n;
+        return {go::Int::from_raw(b.n), nullptr};
     }
-    go::Int Len() { return go::Int::from_raw((int64_t)(data.size() - rd)); }
-    go::Int Available() { return go::Int::from_raw((int64_t)(data.capacity() - data.size())); }
+    std::tuple<go::Int, go::error> Read(go::Slice<go::Byte> b) {
+        int64_t n = std::min<int64_t>(b.n, buf.n - off);
+        if (n == 0 && b.n > 0) return {go::Int(), go_io::EOF_};
+        if (n) std::memmove((void*)b.p, (const void*)(buf.p + off), (size_t)n);
+        off += n;
+        return {go::Int::from_raw(n), nullptr};
+    }
+    go::Int Len() { return go::Int::from_raw(buf.n - off); }
+    go::Int Available() { return go::Int::from_raw(buf.c - buf.n); }
 };
-inline Buffer* NewBuffer(go::Slice<go::Byte> b) { Buffer* r = go::New<Buffer>(); r->data.assign((const char*)b.p, (size_t)b.n); return r; }
+inline Buffer* NewBuffer(go::Slice<go::Byte> b) { Buffer* r = go::New<Buffer>(); r->buf = b; return r; }
 }  // namespace go_bytes
+
+namespace go_atomic {
+// the goroutines of the translated files run one after the other: plain loads and stores
+template <class T> inline T LoadInt32(T* p) { return *p; }
+template <class T, class V> inline void StoreInt32(T* p, V v) { *p = T(v); }
+template <class T, class V> inline T SwapInt32(T* p, V v) { T o = *p; *p = T(v); return o; }
+template <class T, class V> inline T AddInt32(T* p, V v) { *p = *p + T(v); return *p; }
+template <class T, class A, class B> inline bool CompareAndSwapInt32(T* p, A o, B n) { if (*p == T(o)) { *p = T(n); return true; } return false; }
+template <class T> inline T LoadInt64(T* p) { return *p; }
+template <class T, class V> inline void StoreInt64(T* p, V v) { *p = T(v); }
+template <class T, class V> inline T AddInt64(T* p, V v) { *p = *p + T(v); return *p; }
+template <class T> inline T LoadUint64(T* p) { return *p; }
+template <class T, class V> inline void StoreUint64(T* p, V v) { *p = T(v); }
+template <class T, class V> inline T AddUint64(T* p, V v) { *p = *p + T(v); return *p; }
+}  // namespace go_atomic
+namespace go_time {
+struct Duration_tag {};
+using Duration = go::I<int64_t, Duration_tag>;
+struct Time {
+    Time* operator->() { return this; }
+    const Time* operator->() const { return this; }
+    int64_t ns = 0;
+    bool IsZero() const { return ns == 0; }
+    go::Int64 UnixNano() const { return go::Int64::from_raw(ns); }
+    go::Int64 UnixMilli() const { return go::Int64::from_raw(ns / 1000000); }
+    Duration Sub(const Time& o) const { return Duration::from_raw(ns - o.ns); }
+    bool Before(const Time& o) const { return ns < o.ns; }
+    bool After(const Time& o) const { return ns > o.ns; }
+};
+inline Time Now() { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); Time t; t.ns = (int64_t)ts.tv_sec * 1000000000 + ts.tv_nsec; return t; }
+inline Duration Since(const Time& t) { return Now().Sub(t); }
+constexpr Duration Nanosecond = Duration::from_raw(1), Microsecond = Duration::from_raw(1000), Millisecond = Duration::from_raw(1000000), Second = Duration::from_raw(1000000000);
+}  // namespace go_time
+namespace go_runtime {
+inline void Gosched() {}
+inline go::Int NumCPU() { return go::Int::from_raw(1); }
+}  // namespace go_runtime
