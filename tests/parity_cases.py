@@ -617,6 +617,63 @@ def check_reference_inputs(be):
         cs.close()
 
 
+def check_device_vs_ref(be, quick=False):
+    """The device against oracle/_ref DIRECTLY (the reference's own sources, translated and compiled: tests/ref_lib.py), no hand-written oracle in
+    between: entropy codec objects and transform objects in both directions, then whole streams written by the reference's Writer and read by
+    the device, and the device's streams read by the reference's Reader."""
+    import ref_lib as R
+    ent, trf = reference_test_inputs()
+    extra = [] if quick else [(n, d) for n, d in entropy_inputs()]           # (quick: the emulator build runs the reference's own test inputs only)
+    c = K.Codec("NONE", "NONE", 1 << 16, lib=be.lib)
+    for ename in ("HUFFMAN", "ANS0", "ANS1", "FPAQ", "NONE"):
+        et = R.entropy_type(ename)
+        enc, dec = K.EntropyEncoder(c, ename), K.EntropyDecoder(c, ename)
+        for name, data in ent + trf + extra:
+            if len(data) == 0 or (ename == "ANS1" and len(data) in (2, 3)):
+                continue
+            gb, gbits = enc.write(data)
+            rb, rbits = R.entropy_encode(et, data)
+            assert (gb, gbits) == (rb, rbits), (ename, name, "device encode != reference encode")
+            assert R.entropy_decode(et, gb, len(data))[0] == data, (ename, name, "device-encode -> reference-decode")
+            assert dec.read(rb, len(data))[0] == data, (ename, name, "reference-encode -> device-decode")
+    tin = [] if quick else [(n, d) for n, d in transform_inputs(max_len=1 << 16)] + list(utf_inputs()) + [(n, d) for n, d in text_inputs(50000)]
+    for tname in ("BWT", "RANK", "MTFT", "ZRLT", "LZ", "LZX", "LZP", "SRT", "TEXT", "UTF"):
+        t = K.ByteTransform(c, tname)
+        tid = _TID[tname]
+        for name, data in trf + ent + tin:
+            if len(data) == 0 or len(data) > (1 << 16):
+                continue
+            g = t.forward(data)
+            R.set_ctx(1 << 16, R.entropy_type("NONE"))                      # (TEXT reads ctx: the handle's block size and entropy stage)
+            r = R.transform_forward(tid, data)
+            assert (g is None) == (r is None), (tname, name, "one declines, the other does not")
+            if r is None:
+                continue
+            assert g == r, (tname, name, "device forward != reference forward")
+            assert R.transform_inverse(tid, g, len(data) + 1024) == data, (tname, name, "device-forward -> reference-inverse")
+            assert t.inverse(r, len(data) + max(512, len(data) >> 4)) == data, (tname, name, "reference-forward -> device-inverse")
+    c.close()
+    for transform, entropy, ck in (("NONE", "HUFFMAN", 0), ("BWT+RANK+ZRLT", "ANS1", 64), ("LZ", "ANS0", 32), ("BWT+RANK+ZRLT", "FPAQ", 0),
+                                   ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0", 0)):
+        cs = K.Codec(transform, entropy, 1 << 16, ck, lib=be.lib)
+        for name, data in (trf[:6] + ent[:6] if quick else trf + ent + [("corpus", corpus(200001))]):
+            if len(data) == 0:
+                continue
+            src, ks = be.to_dev(data)
+            cap = 2 * len(data) + (1 << 18)
+            dst, kd = be.empty(cap)
+            nb = cs.dev_compress(src, len(data), dst, cap)
+            got = be.to_host(kd, nb)
+            exp = R.compress(data, transform, entropy, 1 << 16, ck)
+            assert got == exp, (transform, entropy, name, "device stream != the reference Writer's stream")
+            assert R.decompress(got, len(data) + 64) == data, (transform, entropy, name, "device stream -> reference Reader")
+            s2, k2 = be.to_dev(exp)
+            out, ko = be.empty(len(data) + 64)
+            assert cs.dev_decompress(s2, len(exp), out, len(data) + 64) == len(data)
+            assert be.to_host(ko, len(data)) == data, (transform, entropy, name, "reference stream -> device reader")
+        cs.close()
+
+
 def _huffman_header_with_wrapped_delta(payload, nbits):
     """Re-encodes one negative code-length delta (-2..-11) of a Huffman chunk header with the 16-bit Exp-Golomb form whose
     magnitude wraps as int8 (ExpGolombCodec.go:159-190, readLengths casts to int8): a stream no kanzi encoder writes but

@@ -102,6 +102,14 @@ def test_reference_test_inputs_both_directions(be):
     P.check_reference_inputs(be)
 
 
+def test_device_vs_ref_directly(be):
+    """the reference's own code (oracle/_ref = kanzi-go's sources translated by tools/go2cpp) as the checker, nothing hand-written in between"""
+    import ref_lib as R
+    if not R.available():
+        pytest.skip("oracle/_ref is not built")
+    P.check_device_vs_ref(be, quick=True)
+
+
 def test_short_block_inside_stream(be):
     P.check_short_inner_block(be)
 
