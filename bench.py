@@ -694,7 +694,8 @@ def main():
             exp = O.compress(tiled(0, size), transform, entropy, bs, 0, jobs=os.cpu_count() or 1)
             got = (d_seg if not multi else d_stream)[:C_bytes].cpu().numpy().tobytes()
             out["bit_exact_vs_oracle"] = bool(got == exp)
-            out["parity_note"] = "oracle = in-repo C++ restatement of kanzi-go; no Go toolchain in the image, so no reference-generated stream pins it (DESIGN.md section 2)"
+            out["parity_note"] = ("oracle = in-repo C++ restatement of kanzi-go, pinned by oracle/_ref (the reference's own .go sources translated mechanically to C++ and compiled: "
+                                  "tests/test_ref_build.py, tests/test_ref_streams.py; DESIGN.md section 2)")
         if not multi and not emu and not args.no_host_hook:
             try:
                 out["host_hook_MBps"] = host_hook_rate(K, (transform, entropy, bs, 0, local_rank), base[:size], bs)

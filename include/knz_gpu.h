@@ -1,9 +1,10 @@
 /*
  * knz_gpu.h — C ABI of the MI355X-native Kanzi block-compression hot path.
  *
- * Drop-in boundary for flanglet/kanzi-go (bitstream v6) AGAINST AN UNPINNED RESTATEMENT: bit-exactness is established against the
- * in-repo C++ restatement of the reference (oracle/); no stream written by the Go binary pins it yet (no Go toolchain in the build
- * image; tools/make_ref_vectors.sh + tests/test_ref_streams.py close that on any machine with Go). Every entry point names the reference
+ * Drop-in boundary for flanglet/kanzi-go (bitstream v6). Bit-exactness is established against the reference's own code: its .go sources
+ * translated mechanically to C++ and compiled (oracle/_ref, tools/go2cpp; the image has no Go toolchain), compared with the device
+ * directly and through 387 reference-written stream vectors (tests/test_ref_streams.py), and against the hand-written restatement
+ * (oracle/) that _ref pins. A stream from a Go-compiled build would be one more witness (tools/make_ref_vectors.sh). Every entry point names the reference
  * interface it replaces; the cgo stubs a kanzi-go maintainer would add are in INTEGRATION.md.
  * Plain pointers and sizes only; the library never keeps a caller pointer after a call returns.
  * Return value: 0 on success, otherwise a kanzi error code (v2/Definitions.go:25-46), except

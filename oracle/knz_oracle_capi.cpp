@@ -3,11 +3,11 @@
 // directory for the reference file:line each function follows). Loaded through ctypes by tests/,
 // by __graft_entry__.smoke() and by bench.py's cpu_baseline leg — never by the product library.
 //
-// PARITY PIN STATUS: the Go reference cannot be built here (no Go toolchain) and its tests are
-// round-trip only, so codec output bytes are "parity unpinned" by reference-generated vectors.
-// What IS pinned (tests/test_oracle_units.py): BWT("mississippi")="ipssmpissii"/5 (BWT.go:48-62),
-// the signed Exp-Golomb table (ExpGolombCodec.go:45-62), varint lengths (Entropy_test.go:84-96),
-// stream header layout/constants (CompressedStream.go:442-516), XXH32 known answers.
+// PARITY PIN STATUS (round 5): pinned by the reference's own code. oracle/_ref = kanzi-go's .go sources translated mechanically to C++
+// (tools/go2cpp) and compiled; tests/test_ref_build.py requires _ref == this oracle on every codec, transform, sequence, hash and whole
+// stream, and the 387 stream vectors under tests/golden/ref_streams/ were written by the reference's own Writer (tests/test_ref_streams.py).
+// Also pinned (tests/test_oracle_units.py): BWT("mississippi")="ipssmpissii"/5 (BWT.go:48-62), the signed Exp-Golomb table
+// (ExpGolombCodec.go:45-62), varint lengths (Entropy_test.go:84-96), stream header layout/constants (CompressedStream.go:442-516), XXH32 known answers.
 #include "stream.hpp"
 
 using namespace knzo;

@@ -2,7 +2,7 @@
 // word-replacement stage in front of UTF / BWT in the `-l 5..9` presets. Two stream formats live behind one transform id: "codec 1" (escape
 // tokens 0x0F / 0x0E + a 1..3 byte index; used in front of the bit-wise entropy coders) and "codec 2" (indexes as bytes >= 0x80; picked by
 // Factory.go:100-120 when the entropy stage is NONE / ANS0 / HUFFMAN / RANGE). Both build the same dynamic dictionary while they scan.
-// Parity unpinned like the rest of the oracle (no Go toolchain in the image); the static dictionary and every constant come from the fixture
+// Pinned like the rest of the oracle by oracle/_ref (the reference's own TextCodec.go, translated mechanically: tests/test_ref_build.py); the static dictionary and every constant come from the fixture
 // tests/golden/reference_constants.json (extracted from the reference source by tests/golden/make_golden.py).
 #pragma once
 #include <cstdint>
