@@ -154,6 +154,7 @@ enum { KNZ_COUNTER_HUF_SERIAL_CHUNKS = 0, KNZ_COUNTER_POST_TRANSFORM_BYTES = 1 /
        KNZ_COUNTER_LZ_FWD_SERIAL_BLOCKS = 4 /* blocks of the last LZ / LZX forward stage whose segment-parallel parse did not settle (or that need a
                                                decision the parallel layout leaves to the one-wave kernel): parsed by the one-wave kernel */,
        KNZ_COUNTER_LZ_FWD_ROUNDS = 5 /* rounds the fixed point of the last segment-parallel LZ forward stage took */,
+       KNZ_COUNTER_RANK_PIPE_BLOCKS = 6 /* blocks of the last decode batch whose ZRLT / RANK inverses ran as one chain under the order-1 rANS decoder */,
        KNZ_COUNTER_STAGE_BYTES0 = 8 /* 8 + i: bytes that entered transform stage i (0..7) of the last encode batch, summed over its blocks */ };
 int knz_last_counter(void* handle, int id, uint64_t* value);
 

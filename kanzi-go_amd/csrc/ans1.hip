@@ -531,6 +531,7 @@ struct Ans1DecArgs {
     uint64_t* paybit;              // [nslots]
     int32_t* blk_status;
     uint32_t plain_loop;           // (KNZ_ANS1_PLAIN: the compiler's schedule of the LDS decoder's loop instead of the hand-written block; A/B and cross-check)
+    uint64_t* progress;            // [nslots] or null: steps whose bytes are stored (first-quarter bytes of the chunk), ~0 = chunk complete: read by the fused ZRLT / RANK inverse (rank_pipe.hip)
 };
 
 // One context of a chunk header (decodeHeader :605-710: alphabet, then the frequencies in groups of 6 / 8 behind their bit width).
@@ -1001,11 +1002,19 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
             const uint8_t* ob = (const uint8_t*)s_ob[g];
             for (uint32_t i = l; i < tn; i += 16) qdst[t0 + i] = ob[i];
         }
+        if (a.progress != nullptr && ((t0 >> 8) & 3u) == 3u) {              // every fourth tile (1024 steps, ~0.2 ms): what is stored so far is handed on
+            agent_fence_release();
+            if (lane == 0) knz_publish64(a.progress + slotId, (uint64_t)(t0 + tn));
+        }
         wave_sync();
     }
     if (lane == 0) {
         for (uint32_t i = end4; i < n; i++)
             dst[i] = (uint8_t)(knz_fetch32(a.stream, (int64_t)(paybit + 16ull * cnt + 8ull * (i - end4)), (int64_t)limit) >> 24);
+    }
+    if (a.progress != nullptr) {
+        agent_fence_release();
+        if (lane == 0) knz_publish64(a.progress + slotId, ~0ull);
     }
 }
 

@@ -9,6 +9,7 @@
 #include "fpaq.hip"
 #include "transforms.hip"
 #include "rank_inv.hip"
+#include "rank_pipe.hip"
 #include "bwt.hip"
 #include "lz.hip"
 #include "lz_par.hip"
@@ -186,6 +187,8 @@ extern "C" int knz_open(const knz_cfg* cfg, void** handle) {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamDefault) == hipSuccess) h->own_stream = true;
     else h->stream = nullptr;
     for (int i = 0; i <= KNZ_STAGE_COUNT; i++) hipEventCreate(&h->ev[i]);
+    h->pipe_ready = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&h->ev_pipe[i], hipEventDisableTiming) != hipSuccess) h->pipe_ready = false;
     for (int i = 0; i < KNZ_STAGE_COUNT; i++) h->stage_ms[i] = 0.f;
     *handle = h;
     return KNZ_OK;
@@ -200,6 +203,8 @@ extern "C" int knz_close(void* handle) {
     if (h->pinned_status) hipHostFree(h->pinned_status);
     if (h->pinned_len) hipHostFree(h->pinned_len);
     for (int i = 0; i <= KNZ_STAGE_COUNT; i++) hipEventDestroy(h->ev[i]);
+    if (h->pipe_ready) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); h->stream2 = nullptr; }
+    for (int i = 0; i < 2; i++) if (h->ev_pipe[i]) { hipEventDestroy(h->ev_pipe[i]); h->ev_pipe[i] = nullptr; }
     for (int i = 0; i < KNZ_MAX_PROBES; i++) if (h->probes[i].a) { hipEventDestroy(h->probes[i].a); hipEventDestroy(h->probes[i].b); }
     delete h;
     return KNZ_OK;
@@ -238,7 +243,7 @@ extern "C" int knz_last_kernel_times(void* handle, char* names, int names_cap, f
 
 extern "C" int knz_last_counter(void* handle, int id, uint64_t* value) {
     Handle* h = (Handle*)handle;
-    if (!h || !value || id < KNZ_COUNTER_HUF_SERIAL_CHUNKS || id > KNZ_COUNTER_STAGE_BYTES0 + 7 || (id > KNZ_COUNTER_LZ_FWD_ROUNDS && id < KNZ_COUNTER_STAGE_BYTES0)) return KNZ_ERR_INVALID_PARAM;
+    if (!h || !value || id < KNZ_COUNTER_HUF_SERIAL_CHUNKS || id > KNZ_COUNTER_STAGE_BYTES0 + 7 || (id > KNZ_COUNTER_RANK_PIPE_BLOCKS && id < KNZ_COUNTER_STAGE_BYTES0)) return KNZ_ERR_INVALID_PARAM;
     DeviceGuard dg(h);
     *value = 0;
     if (id == KNZ_COUNTER_POST_TRANSFORM_BYTES) { *value = h->post_bytes; return KNZ_OK; }
@@ -250,6 +255,15 @@ extern "C" int knz_last_counter(void* handle, int id, uint64_t* value) {
         return KNZ_OK;
     }
     if (id == KNZ_COUNTER_LZ_FWD_ROUNDS) { *value = h->lzs_rounds; return KNZ_OK; }
+    if (id == KNZ_COUNTER_RANK_PIPE_BLOCKS) {
+        if (h->pipe_n == 0) return KNZ_OK;
+        std::vector<uint8_t> f(h->pipe_n);
+        if (hipMemcpy(f.data(), h->pipe_flag.p, f.size(), hipMemcpyDeviceToHost) != hipSuccess) return KNZ_ERR_UNKNOWN;
+        uint64_t n = 0;
+        for (uint8_t v : f) n += v;
+        *value = n;
+        return KNZ_OK;
+    }
     if (id == KNZ_COUNTER_LZ_FWD_SERIAL_BLOCKS) {
         if (h->lzs_n == 0) return KNZ_OK;
         std::vector<uint8_t> f(h->lzs_n);

@@ -740,9 +740,10 @@ __global__ void knz_xf_none_kernel(uint32_t nblocks, const uint8_t* active, uint
     if (b < nblocks && active[b]) skip[b] &= (uint8_t)~(1u << (7 - stage));
 }
 // inverse sequence: a stage runs for live blocks whose skip bit is clear; `live` (take) is the decode-side block liveness
-__global__ void knz_xf_inv_select_kernel(uint32_t nblocks, const uint8_t* skip, const uint8_t* live, uint8_t* active, uint32_t stage, const int32_t* blk_status) {
+// piped: blocks whose stage the fused ZRLT / RANK inverse already ran (rank_pipe.hip), or null
+__global__ void knz_xf_inv_select_kernel(uint32_t nblocks, const uint8_t* skip, const uint8_t* live, uint8_t* active, uint32_t stage, const int32_t* blk_status, const uint8_t* piped) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nblocks) active[b] = (live[b] && blk_status[b] == 0 && !(skip[b] & (1u << (7 - stage)))) ? 1 : 0;
+    if (b < nblocks) active[b] = (live[b] && blk_status[b] == 0 && !(skip[b] & (1u << (7 - stage))) && !(piped != nullptr && piped[b])) ? 1 : 0;
 }
 // gather of per-block byte ranges (final copy of decoded blocks / staging)
 __global__ __launch_bounds__(256) void knz_copy_blocks_kernel(uint32_t nblocks, const uint64_t* src_ptr, const uint32_t* len, const uint64_t* dst_ptr, const uint8_t* live) {

@@ -150,6 +150,12 @@ __device__ __forceinline__ void wave_sync_lds() {
 // polling loops between waves of one workgroup (LDS flags): give the issue slot away for a few cycles
 __device__ __forceinline__ void wave_spin_pause() { __builtin_amdgcn_s_sleep(1); }
 __device__ __forceinline__ void wg_fence_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// hand-over between workgroups of DIFFERENT kernels (rank_pipe.hip): the producer's stores are written back past its XCD's L2 before the flag,
+// the consumer drops what its own caches hold before it reads behind the flag; and the scalar cache of a wave that reads back what its
+// vector unit has just stored
+__device__ __forceinline__ void agent_fence_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+__device__ __forceinline__ void agent_fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ void knz_scalar_cache_inv() { __builtin_amdgcn_s_dcache_inv(); }
 __device__ __forceinline__ void wg_fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 // 64-bit words that are their own ready flag between workgroups of one launch (device-scope relaxed atomics: the store goes
 // to L2, the load bypasses the non-coherent caches); a longer sleep for polls that wait on another workgroup
@@ -185,6 +191,9 @@ __device__ __forceinline__ uint32_t knz_byte_perm(uint32_t hi, uint32_t lo, uint
 // ------------------------------------------------------------------ emulator (tests only)
 inline void wave_spin_pause() { hipemu::spin_pause(); }
 inline void wg_fence_release() {}
+inline void agent_fence_release() {}
+inline void agent_fence_acquire() {}
+inline void knz_scalar_cache_inv() {}
 inline void wg_fence_acquire() {}
 inline void knz_publish64(uint64_t* p, uint64_t v) { *(volatile uint64_t*)p = v; }
 inline uint64_t knz_poll64(const uint64_t* p) { return *(const volatile uint64_t*)p; }

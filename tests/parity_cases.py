@@ -617,6 +617,51 @@ def check_reference_inputs(be):
         cs.close()
 
 
+def check_rank_pipe(be, monkeypatch, sizes=((50000, 1 << 14), (300000, 1 << 16), (1000, 1024), (200001, 1 << 17)), seeds=(5, 6)):
+    """Decode of ...RANK+ZRLT / ANS1: the two inverses run as one chain under the rANS decoder (rank_pipe.hip). Same bytes as the regular stage kernels
+    (KNZ_NO_RANK_PIPE), every coded block taken by the chain (knz_last_counter 6), the three-register form and a moved packed / unpacked cut included;
+    inputs with long zero runs (digits across lane and piece boundaries), escapes (0xFE / 0xFF ranks) and blocks a stage skips."""
+    def shapes(n, seed):
+        r = np.random.default_rng(seed)
+        yield "corpus", corpus(n, seed)
+        yield "zeros", bytes(n)
+        yield "sparse", np.where(r.random(n) < 0.002, r.integers(1, 256, n), 0).astype(np.uint8).tobytes()
+        yield "random", r.integers(0, 256, n, dtype=np.uint8).tobytes()                     # (ranks up to 255: escapes in the ZRLT stream; ZRLT may be skipped)
+        yield "runs", b"".join(bytes([int(r.integers(0, 256))]) * int(r.integers(1, 5000)) for _ in range(max(n // 2000, 2)))[:n] or b"x"
+        a = np.zeros(n, dtype=np.uint8)
+        a[:: max(n // 300, 1)] = r.integers(1, 256, len(a[:: max(n // 300, 1)]))
+        yield "steps", a.tobytes()
+    for seq in ("BWT+RANK+ZRLT", "RANK+ZRLT"):
+        for n, bs in sizes:
+            for seed in seeds:
+                for name, data in shapes(n, seed):
+                    n2 = len(data)
+                    stream = O.compress(data, seq, "ANS1", bs)
+                    sp, k1 = be.to_dev(stream)
+                    res = {}
+                    for form in ("pipe", "regular", "unpacked", "cut"):
+                        for v in ("KNZ_NO_RANK_PIPE", "KNZ_RANK_UNPACKED", "KNZ_RANK_CUT"):
+                            monkeypatch.delenv(v, raising=False)
+                        if form == "regular":
+                            monkeypatch.setenv("KNZ_NO_RANK_PIPE", "1")
+                        elif form == "unpacked":
+                            monkeypatch.setenv("KNZ_RANK_UNPACKED", "1")
+                        elif form == "cut":
+                            monkeypatch.setenv("KNZ_RANK_CUT", "512")
+                        c = K.Codec(seq, "ANS1", bs, lib=be.lib)
+                        out, ko = be.empty(n2 + 4096)
+                        nd = c.dev_decompress(sp, len(stream), out, n2 + 4096)
+                        assert nd == n2 and be.to_host(ko, nd) == data, (seq, n, bs, seed, name, form)
+                        res[form] = c.last_counter(6)
+                        c.close()
+                    assert res["regular"] == 0
+                    assert res["pipe"] == res["unpacked"] == res["cut"]
+                    if name in ("corpus", "sparse", "steps"):
+                        assert res["pipe"] >= 1, (seq, n, bs, seed, name, "no block took the fused chain")
+    for v in ("KNZ_NO_RANK_PIPE", "KNZ_RANK_UNPACKED", "KNZ_RANK_CUT"):
+        monkeypatch.delenv(v, raising=False)
+
+
 def check_device_vs_ref(be, quick=False):
     """The device against oracle/_ref DIRECTLY (the reference's own sources, translated and compiled: tests/ref_lib.py), no hand-written oracle in
     between: entropy codec objects and transform objects in both directions, then whole streams written by the reference's Writer and read by

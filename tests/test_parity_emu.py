@@ -132,6 +132,10 @@ def test_bwt_suffix_sort_fuzz(be, monkeypatch):
     P.check_bwt_sort_fuzz(be, monkeypatch)
 
 
+def test_rank_pipe_under_ans1_decoder(be, monkeypatch):
+    P.check_rank_pipe(be, monkeypatch, sizes=((50000, 1 << 14), (1000, 1024), (70001, 1 << 16)), seeds=(5,))
+
+
 def test_rank_chain_variants(be, monkeypatch):
     P.check_rank_chain_variants(be, monkeypatch, max_len=4100, bwt_len=12000)
 

@@ -288,6 +288,12 @@ def test_bwt_suffix_sort_fuzz(be, monkeypatch):
     P.check_bwt_sort_fuzz(be, monkeypatch, cases=120, seed=8, max_n=3000000, segs=("",))
 
 
+def test_rank_pipe_under_ans1_decoder(be, monkeypatch):
+    # (blocks of 6 MiB: two rANS chunks per block, the chain waits on the first quarter of the first and on the whole second)
+    P.check_rank_pipe(be, monkeypatch, sizes=((50000, 1 << 14), (3000000, 1 << 20), (13000001, 6 << 20)), seeds=(5,))
+    P.check_corrupt_streams(be, trials=6)
+
+
 def test_rank_chain_variants(be, monkeypatch):
     P.check_rank_chain_variants(be, monkeypatch)
 
