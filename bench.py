@@ -74,6 +74,8 @@ PUBLISHED = {
 # coder input), c = compressed bytes (every stage reads its input once and writes its output once)
 KERNEL_BYTES = {
     "knz_rank_inverse_chain_kernel": lambda n, m, c: 2 * n, "knz_sbrt_inverse_kernel": lambda n, m, c: 2 * n,
+    # the fused ZRLT / RANK inverse does both stages' algorithmic work: ZRLT stream m in, n ranks out, n ranks in, n symbols out ("ZRLT/RANK N + N'")
+    "knz_zrlti_rank_pipe_kernel": lambda n, m, c: m + 3 * n,
     "knz_sbrt_apply_kernel": lambda n, m, c: 2 * n, "knz_bwt_inv_chains_kernel": lambda n, m, c: 2 * n,
     "knz_bwt_inv_walk_kernel": lambda n, m, c: 2 * n, "knz_bwt_inv_emit_kernel": lambda n, m, c: 2 * n,
     "knz_ans1_decode_lds_kernel": lambda n, m, c: c + m, "knz_ans1_decode_kernel": lambda n, m, c: c + m,
@@ -105,7 +107,9 @@ KERNEL_BYTES = {
 # (vector loads of 16 B per lane). Kernels that read their input through the SCALAR cache fetch 64-byte lines that are tallied in full: calibrated on
 # knz_rank_inverse_chain_kernel, which reads its n input bytes exactly once with s_load_dwordx4 and stores n bytes: raw FETCH_SIZE = 1.001 n, raw
 # WRITE_SIZE = 1.000 n (profiles/r03_final_config4_bench.json). With the factor 2 that kernel showed "1.50x algorithmic" in round 2: an artefact.
-FETCH_FACTOR = {"knz_rank_inverse_chain_kernel": 1.0}
+FETCH_FACTOR = {"knz_rank_inverse_chain_kernel": 1.0,
+                "knz_zrlti_rank_pipe_kernel": 1.0}   # (its chain wave reads the ranks through the scalar cache like the kernel above; the expander wave's 16-byte vector reads of the
+                                                     #  ZRLT stream - m of the m + 3 n bytes - are tallied at half: at most m / 2 under-counted)
 
 
 def kernel_key(name):
@@ -267,6 +271,83 @@ def host_hook_rate(K, codec_args, data, bs):
             "what": "knz_encode_blocks + knz_decode_blocks, all blocks of the stream in pageable host memory (H2D and D2H inside the timed call)"}
 
 
+def multi_handle_curve(K, codec_args, data, bs, ks, per_handle_blocks=51, rounds=2):
+    """The boundary the Go host has: every io.Writer / io.Reader owns one handle and hands it at most `jobs` <= 64 blocks per call
+    (io/CompressedStream.go:52,285,621-710). k host threads, one handle each, each calling knz_encode_blocks / knz_decode_blocks on its own batch of
+    `per_handle_blocks` blocks in pageable host memory, all at the same time: aggregate MB/s against the number of handles (= blocks in flight)."""
+    import threading
+    from kanzi_go_amd import api as A
+    nb_total = (len(data) + bs - 1) // bs
+    out = []
+    for k in ks:
+        codecs = [K.Codec(*codec_args) for _ in range(k)]
+        batches = []
+        for t in range(k):                                   # handle t takes blocks [t * per, (t + 1) * per) of the corpus, wrapping around
+            blks = []
+            for j in range(per_handle_blocks):
+                b = (t * per_handle_blocks + j) % nb_total
+                a = np.ascontiguousarray(data[b * bs:(b + 1) * bs])
+                if len(a) < bs:                               # (a short block may only be the last of a batch: take a full one instead)
+                    a = np.ascontiguousarray(data[:bs])
+                blks.append(a)
+            batches.append(blks)
+        cap = int(codecs[0].L.knz_max_encoded_len(codecs[0].cfg.transform, bs)) * 2 + 262144
+        enc_arr, keep = [], []
+        for t in range(k):
+            arr = (A._Block * per_handle_blocks)()
+            outs = [np.zeros(cap, dtype=np.uint8) for _ in range(per_handle_blocks)]
+            for i, a in enumerate(batches[t]):
+                arr[i].src = a.ctypes.data; arr[i].src_len = len(a); arr[i].dst = outs[i].ctypes.data; arr[i].dst_cap = cap
+            enc_arr.append(arr); keep.append(outs)
+
+        def run(fn_name, arrs):
+            errs = []
+            barrier = threading.Barrier(k + 1)
+
+            def work(t):
+                c = codecs[t]
+                fn = getattr(c.L, fn_name)
+                barrier.wait()
+                rc = fn(c.h, arrs[t], per_handle_blocks)
+                if rc:
+                    errs.append(rc)
+            ths = [threading.Thread(target=work, args=(t,)) for t in range(k)]
+            for th in ths:
+                th.start()
+            barrier.wait()
+            t0 = time.perf_counter()
+            for th in ths:
+                th.join()
+            dt = time.perf_counter() - t0
+            assert not errs, errs
+            return dt
+        te = td = None
+        dec_arr, keep2 = [], []
+        for r in range(rounds + 1):                           # (round 0 grows the workspaces: untimed)
+            dt = run("knz_encode_blocks", enc_arr)
+            te = dt if r else None if te is None else te
+            if r == 0:
+                for t in range(k):
+                    arr = (A._Block * per_handle_blocks)()
+                    pays = [keep[t][i][: (enc_arr[t][i].out_bits + 7) // 8].copy() for i in range(per_handle_blocks)]
+                    outs = [np.zeros(bs + max(512, bs >> 4), dtype=np.uint8) for _ in range(per_handle_blocks)]
+                    for i in range(per_handle_blocks):
+                        arr[i].src = pays[i].ctypes.data; arr[i].src_len = len(pays[i]); arr[i].dst = outs[i].ctypes.data; arr[i].dst_cap = len(outs[i])
+                    dec_arr.append(arr); keep2.append((pays, outs))
+            elif te is None or dt < te:
+                te = dt
+            dt = run("knz_decode_blocks", dec_arr)
+            if r and (td is None or dt < td):
+                td = dt
+        ok = all(bytes(keep2[t][1][i][: dec_arr[t][i].out_bits]) == batches[t][i].tobytes() for t in range(k) for i in range(per_handle_blocks))
+        n = k * per_handle_blocks * bs
+        out.append({"handles": k, "blocks_in_flight": k * per_handle_blocks, "encode_MBps": round(n / 1e6 / te, 1), "decode_MBps": round(n / 1e6 / td, 1),
+                    "round_trip_MBps": round(n / 1e6 / (te + td), 1), "ok": ok})
+        for c in codecs:
+            c.close()
+    return out
+
+
 def pmc_traffic(argv_child, timeout_s=900):
     """HBM bytes per launch for every knz_ kernel: two rocprofv3 passes of THIS command (--kernel-trace --pmc FETCH_SIZE, then
     WRITE_SIZE: separate passes as MI355X_MICROARCH.md prescribes), rocpd databases read with tools/pmc_traffic.py.
@@ -329,6 +410,7 @@ def main():
     ap.add_argument("--copies", type=int, default=1, help="corpus copies in the one stream (single-GPU saturation curve: MB/s against blocks in flight)")
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, sharded encode, gather, assembly, collectives) at world size 1: "
                                                               "puts RCCL under bench.py on a one-GPU box (debug / pre-flight of the driver's multi-GPU run)")
+    ap.add_argument("--handles", default="", help="e.g. 1,2,4,8: instead of the step, the multi-handle curve of the host-pointer boundary (k threads x one handle x 51 blocks per call), one JSON object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes (roofline.traffic = null)")
@@ -403,6 +485,13 @@ def main():
         t = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
         return t[(-t.data_ptr()) % 16:][:n]
 
+    if args.handles:
+        ks = [int(x) for x in args.handles.split(",") if x]
+        per = 51 if bs <= (4 << 20) else 26                   # one Writer's batch: jobs <= 64 blocks (the default job's block count per call)
+        curve = multi_handle_curve(K, (transform, entropy, bs, 0, local_rank), base, bs, ks, per_handle_blocks=per)
+        print(json.dumps({"what": "knz_encode_blocks / knz_decode_blocks from k host threads, one handle each, pageable host memory, all calls at the same time",
+                          "config": f"-t {transform} -e {entropy} -b {bs >> 20}m", "blocks_per_call": per, "curve": curve}), file=json_out, flush=True)
+        return
     codec = K.Codec(transform, entropy, bs, device=local_rank, lib=lib)
 
     def make_job(strong_):
@@ -580,7 +669,7 @@ def main():
                     stage_in[tok] = n_local
 
         def n_for(kernel):
-            for prefixes, toks in ((("knz_bwt_", "knz_ss_", "knz_sg_", "knz_sl_"), ("BWT",)), (("knz_rank_", "knz_sbrt_", "knz_mtft_"), ("RANK", "MTFT", "SRT")),
+            for prefixes, toks in ((("knz_bwt_", "knz_ss_", "knz_sg_", "knz_sl_"), ("BWT",)), (("knz_rank_", "knz_sbrt_", "knz_mtft_", "knz_zrlti_rank_pipe"), ("RANK", "MTFT", "SRT")),
                                    (("knz_zrlt",), ("ZRLT",)), (("knz_lzp_",), ("LZP",)), (("knz_lz",), ("LZ", "LZX")), (("knz_text_",), ("TEXT",)),
                                    (("knz_utf_",), ("UTF",)), (("knz_srt_",), ("SRT",))):
                 if kernel.startswith(prefixes):

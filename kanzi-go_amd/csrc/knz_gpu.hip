@@ -69,16 +69,44 @@ int knz_set_error(Handle* h, int code, const char* msg) {
     return code;
 }
 
+// Workspace growth is refused while it would leave the device with less than 1/16 of its memory (4 GiB at least): a device driven to its
+// last byte takes the HIP runtime down with it (queue creation aborts the process), and several handles share one device. A refused
+// growth comes back as KNZ_ERR_CREATE_COMPRESSOR / _DECOMPRESSOR; the host-pointer entry points then release the workspace and take the
+// batch in halves (knz_host_api.inc). KNZ_TEST_ALLOC_LIMIT (tests): bytes one buffer may hold.
+static thread_local std::vector<DevBuf*>* g_buf_registry = nullptr;
+static thread_local bool g_alloc_refused = false;
+DevBuf::DevBuf() { if (g_buf_registry) g_buf_registry->push_back(this); }
 int DevBuf::reserve(size_t n) {
     if (n <= cap) return 0;
     if (p) hipFree(p);
     p = nullptr; cap = 0;
     size_t want = n + n / 8 + 256;
-    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+    if (const char* lim = knz_test_switch("KNZ_TEST_ALLOC_LIMIT")) { if (want > (size_t)strtoull(lim, nullptr, 10)) { g_alloc_refused = true; return -1; } }
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB != 0) {
+        const size_t keep = std::max<size_t>(totalB / 16, (size_t)4 << 30);
+        if (want > freeB || freeB - want < std::min(keep, totalB / 2)) { g_alloc_refused = true; return -1; }
+    }
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; (void)hipGetLastError(); g_alloc_refused = true; return -1; }
     cap = want;
     return 0;
 }
 void DevBuf::release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+static void knz_release_workspace(Handle* h) {
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->pipe_ready) hipStreamSynchronize(h->stream2);
+    for (DevBuf* b : h->all_bufs) b->release();
+    h->text_stat_ready = false;                      // (the static TEXT dictionary lives in one of them: uploaded again on demand)
+    h->huf_fallback_n = 0; h->lzs_n = 0; h->lzi_serial_n = 0; h->pipe_n = 0;
+}
+
+// The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and kernels of streams that share
+// a queue run one after the other. A Go host keeps one handle per io.Writer / io.Reader (two streams each: the caller's and the fused ZRLT / RANK
+// chain's), so four queues serialise everything beyond two handles (measured: profiles/r05_multi_handle.json). The variable is read when the
+// runtime initialises: set here, when the library is loaded, unless the host has chosen a value (no effect if HIP is already up).
+#ifndef KNZ_HIP_EMU
+__attribute__((constructor)) static void knz_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "32", 0); }
+#endif
 
 // ---- stream header, v2/io/CompressedStream.go:429-519 -----------------------------------------------------------
 static void hdr_put(uint32_t* words, uint32_t& pos, uint64_t value, uint32_t count) {
@@ -167,7 +195,11 @@ extern "C" int knz_open(const knz_cfg* cfg, void** handle) {
     if (cfg->block_size < 1024 || cfg->block_size > (1u << 30) || (cfg->block_size & 15)) { g_open_error = "invalid block size"; return KNZ_ERR_BLOCK_SIZE; }
     if (cfg->checksum_bits != 0 && cfg->checksum_bits != 32 && cfg->checksum_bits != 64) { g_open_error = "invalid checksum size"; return KNZ_ERR_INVALID_PARAM; }
     if (cfg->bs_version != 0 && cfg->bs_version != 6) { g_open_error = "only bitstream version 6"; return KNZ_ERR_STREAM_VERSION; }
+    std::vector<DevBuf*> bufs;
+    g_buf_registry = &bufs;
     Handle* h = new Handle();
+    g_buf_registry = nullptr;
+    h->all_bufs = bufs;
     h->cfg = *cfg;
     h->cfg.bs_version = 6;
     int dev = cfg->device;

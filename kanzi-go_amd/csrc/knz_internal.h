@@ -20,7 +20,7 @@ static inline const char* knz_measure_switch(const char*) { return nullptr; }
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    DevBuf() = default;
+    DevBuf();                         // (registers itself with the Handle under construction: knz_release_workspace walks the list)
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }          // every workspace buffer of a Handle goes with it (knz_close)
@@ -90,6 +90,7 @@ struct Handle {
         pinned_tables_cap = want;
         return 0;
     }
+    std::vector<DevBuf*> all_bufs;    // every workspace buffer of this handle (filled while the handle is constructed)
     hipEvent_t ev[KNZ_STAGE_COUNT + 1];
     bool ev_valid = false;
     float stage_ms[KNZ_STAGE_COUNT];

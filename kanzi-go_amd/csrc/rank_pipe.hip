@@ -181,7 +181,7 @@ __global__ __launch_bounds__(128) void knz_zrlti_rank_pipe_kernel(RankPipeArgs a
                 moved = true;
             }
             if (moved) {
-                wg_fence_release();                                                        // the literals have landed before the chain is told
+                agent_fence_release();                                                     // the literals have landed in L2 before the chain (which reads them back through the scalar cache) is told
                 if (lane == 0) s_ready = outPos;
                 idle = 0;
             } else {
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(128) void knz_zrlti_rank_pipe_kernel(RankPipeArgs a
                 if (++idle > (1u << 24)) { if (lane == 0) s_state = KNZ_PIPE_DECLINED; return; }   // (~ seconds: a producer that does not move)
             }
         }
-        wg_fence_release();
+        agent_fence_release();
         if (lane == 0) { s_ready = outPos; s_state = KNZ_PIPE_END; }
         KNZ_PIPE_T(if (lane == 0 && b < 1024u) { unsigned long long* t = g_knz_pipe_ticks[b]; t[1] = KNZ_RANK_NOW() - tStart; t[4] = tFirst; t[5] = tDone; t[6] = m; t[7] = outPos; })
         return;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(128) void knz_zrlti_rank_pipe_kernel(RankPipeArgs a
         const uint32_t ready = state == KNZ_PIPE_END ? total : (total & ~63u);
         if (ready > chainPos) {
             KNZ_PIPE_T({ const unsigned long long now = KNZ_RANK_NOW(); tW += now - tMark; tMark = now; })
-            wg_fence_acquire();
+            agent_fence_acquire();
             knz_scalar_cache_inv();                                                        // the rows come back through the scalar cache
             uint32_t end = min(ready, chainPos + (1u << 17));
             if (!unpacked) {

@@ -155,7 +155,7 @@ __device__ __forceinline__ void wg_fence_release() { __builtin_amdgcn_fence(__AT
 // vector unit has just stored
 __device__ __forceinline__ void agent_fence_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
 __device__ __forceinline__ void agent_fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-__device__ __forceinline__ void knz_scalar_cache_inv() { __builtin_amdgcn_s_dcache_inv(); }
+__device__ __forceinline__ void knz_scalar_cache_inv() { asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); }   // (the loads behind it must not overtake the invalidate)
 __device__ __forceinline__ void wg_fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 // 64-bit words that are their own ready flag between workgroups of one launch (device-scope relaxed atomics: the store goes
 // to L2, the load bypasses the non-coherent caches); a longer sleep for polls that wait on another workgroup

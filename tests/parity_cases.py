@@ -167,6 +167,41 @@ def check_block_batch(be, transform, entropy, block_size, nblocks, last_len):
     c.close()
 
 
+def check_alloc_split(be, monkeypatch):
+    """A batch whose workspace the device refuses (KNZ_TEST_ALLOC_LIMIT: bytes one workspace buffer may hold) is taken in halves by
+    knz_encode_blocks / knz_decode_blocks after the handle has given its workspace back: same bytes as the unrestricted batch, and an
+    error (not a crash) when even a single block does not fit."""
+    for transform, entropy, limit in (("NONE", "HUFFMAN", 1200000), ("LZ", "ANS0", 1500000)):
+        monkeypatch.delenv("KNZ_TEST_ALLOC_LIMIT", raising=False)
+        bs, nblocks = 1 << 16, 12
+        blocks = [corpus(bs, 20 + i) for i in range(nblocks - 1)] + [corpus(4321, 77)]
+        c = K.Codec(transform, entropy, bs, lib=be.lib)
+        want = K.BlockBatch(c).encode(blocks)
+        c.close()
+        monkeypatch.setenv("KNZ_TEST_ALLOC_LIMIT", str(limit))       # the stage buffers of 12 x 64 KiB blocks do not fit, those of 3-6 blocks do
+        c = K.Codec(transform, entropy, bs, lib=be.lib)
+        bb = K.BlockBatch(c)
+        got = bb.encode(blocks)
+        assert got == want, (transform, entropy, "split batch encodes differently")
+        assert bb.decode([r[0] for r in got]) == blocks
+        c.close()
+        monkeypatch.setenv("KNZ_TEST_ALLOC_LIMIT", "1000")            # nothing fits: the call comes back with an error
+        c = K.Codec(transform, entropy, bs, lib=be.lib)
+        with pytest_raises_knz_any():
+            K.BlockBatch(c).encode(blocks)
+        c.close()
+    monkeypatch.delenv("KNZ_TEST_ALLOC_LIMIT", raising=False)
+
+
+class pytest_raises_knz_any:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        assert et is not None and issubclass(et, K.KnzError), "the call succeeded although no workspace buffer may exist"
+        return True
+
+
 def check_assemble(be, entropy, block_size, n, ranks):
     """Multi-GPU sharding: each 'rank' encodes a contiguous range of blocks, rank 0 assembles."""
     data = corpus(n, 5)

@@ -265,6 +265,10 @@ def test_device_vs_ref_directly(be):
     P.check_device_vs_ref(be)
 
 
+def test_batch_split_when_workspace_is_refused(be, monkeypatch):
+    P.check_alloc_split(be, monkeypatch)
+
+
 def test_short_block_inside_stream(be):
     P.check_short_inner_block(be)
 
