@@ -1,0 +1,277 @@
+// gpu_stream.go — goes into github.com/flanglet/kanzi-go/v2/io next to CompressedStream.go and gpu_batch.go.
+//
+// The two batch hooks themselves: Writer.processBlockGPU / Reader.processBlockGPU do what Writer.processBlock
+// (CompressedStream.go:621-710) and Reader.processBlock (:1614-1744) do, with the goroutine fan-out replaced by ONE call
+// into the GPU batch scheduler (gpu_batch.go). The reference's structs stay as they are: which Writer / Reader owns a
+// batch scheduler is kept in a side table. The only lines that change in CompressedStream.go are the first statement of
+// each processBlock (INTEGRATION.md, "the patch"):
+//
+//	func (this *Writer) processBlock() error {
+//		if gb := gpuBatchOfWriter(this); gb != nil { return this.processBlockGPU(gb) }
+//	func (this *Reader) processBlock() (int64, error) {
+//		if gb := gpuBatchOfReader(this); gb != nil { return this.processBlockGPU(gb) }
+//
+// No Go toolchain exists in the image this library is built in. This file, gpu_batch.go and the patched
+// CompressedStream.go ARE executed there all the same: tools/go2cpp translates them to C++ together with the rest of the
+// reference (`make -C oracle _ref_gpu`), the result is linked against libknz_gpu.so and the GPU suite requires that the
+// reference's own Writer / Reader, driving the device through this shim, write and read the same streams as without it
+// (tests/test_go_shim_gpu.py).
+package io
+
+import (
+	"sync"
+	"sync/atomic"
+
+	kanzi "github.com/flanglet/kanzi-go/v2"
+)
+
+var gpuLock sync.Mutex
+var gpuWriters = make(map[*Writer]*gpuBatch)
+var gpuReaders = make(map[*Reader]*gpuBatch)
+
+func gpuBatchOfWriter(w *Writer) *gpuBatch {
+	gpuLock.Lock()
+	gb := gpuWriters[w]
+	gpuLock.Unlock()
+	return gb
+}
+
+func gpuBatchOfReader(r *Reader) *gpuBatch {
+	gpuLock.Lock()
+	gb := gpuReaders[r]
+	gpuLock.Unlock()
+	return gb
+}
+
+// EnableGPU re-points the block batches of this Writer at the GPU batch scheduler. To be called right after
+// NewWriterWithCtx. Returns an error (and leaves the goroutine path in place) when the stream's transform sequence or
+// entropy codec has no device implementation or no GPU can be opened: the library has no CPU fallback.
+func (this *Writer) EnableGPU() error {
+	if gpuSupports(this.transformType, this.entropyType) == false {
+		return &IOError{msg: "No device implementation for this transform / entropy combination", code: kanzi.ERR_INVALID_CODEC}
+	}
+
+	checksum := 0
+
+	if this.hasher32 != nil {
+		checksum = 32
+	} else if this.hasher64 != nil {
+		checksum = 64
+	}
+
+	skipBlocks := false
+
+	if v, hasKey := this.ctx["skipBlocks"]; hasKey {
+		skipBlocks, _ = v.(bool)
+	}
+
+	gb, err := newGPUBatch(this.transformType, this.entropyType, this.blockSize, checksum, skipBlocks)
+
+	if err != nil {
+		return err
+	}
+
+	gpuLock.Lock()
+	gpuWriters[this] = gb
+	gpuLock.Unlock()
+	return nil
+}
+
+// DisableGPU gives the batch scheduler back (to be called after Close).
+func (this *Writer) DisableGPU() {
+	gpuLock.Lock()
+	gb := gpuWriters[this]
+	delete(gpuWriters, this)
+	gpuLock.Unlock()
+
+	if gb != nil {
+		gb.close()
+	}
+}
+
+// processBlockGPU = Writer.processBlock with the per-block goroutines replaced by one device batch.
+func (this *Writer) processBlockGPU(gb *gpuBatch) error {
+	if err := this.writeHeader(); err != nil {
+		return err
+	}
+
+	if this.available == 0 {
+		return nil
+	}
+
+	data := make([][]byte, 0, this.jobs)
+	out := make([][]byte, 0, this.jobs)
+	lengths := make([]int, 0, this.jobs)
+	// an encodingTask's output buffer: room for a block the transforms and the entropy coder expanded (:857-864)
+	bufSize := max(this.blockSize+(this.blockSize>>3), 256*1024)
+
+	for taskID := 0; taskID < this.jobs; taskID++ {
+		dataLength := this.available
+
+		if dataLength > this.blockSize {
+			dataLength = this.blockSize
+		}
+
+		if dataLength == 0 {
+			break
+		}
+
+		this.available -= dataLength
+
+		if len(this.buffers[this.jobs+taskID].Buf) < bufSize {
+			this.buffers[this.jobs+taskID].Buf = make([]byte, bufSize)
+		}
+
+		data = append(data, this.buffers[taskID].Buf)
+		out = append(out, this.buffers[this.jobs+taskID].Buf)
+		lengths = append(lengths, dataLength)
+	}
+
+	res, err := gb.encodeBlocks(data, lengths, out)
+
+	if err != nil {
+		return err
+	}
+
+	// ordered emission into the shared bitstream, as the tasks do it one after the other (:934-976)
+	emitBlocks(this.obs, out, res)
+	atomic.AddInt32(&this.blockID, int32(len(lengths)))
+	return nil
+}
+
+// EnableGPU re-points the block batches of this Reader at the GPU batch scheduler. The stream header is read first:
+// the codecs, the block size and the checksum size come from it.
+func (this *Reader) EnableGPU() error {
+	if err := this.readHeader(); err != nil {
+		return err
+	}
+
+	if _, hasKey := this.ctx["from"]; hasKey {
+		return &IOError{msg: "Block ranges are not supported on the device path", code: kanzi.ERR_INVALID_PARAM}
+	}
+
+	if _, hasKey := this.ctx["to"]; hasKey {
+		return &IOError{msg: "Block ranges are not supported on the device path", code: kanzi.ERR_INVALID_PARAM}
+	}
+
+	if gpuSupports(this.transformType, this.entropyType) == false {
+		return &IOError{msg: "No device implementation for this transform / entropy combination", code: kanzi.ERR_INVALID_CODEC}
+	}
+
+	checksum := 0
+
+	if this.hasher32 != nil {
+		checksum = 32
+	} else if this.hasher64 != nil {
+		checksum = 64
+	}
+
+	gb, err := newGPUBatch(this.transformType, this.entropyType, this.blockSize, checksum, false)
+
+	if err != nil {
+		return err
+	}
+
+	gpuLock.Lock()
+	gpuReaders[this] = gb
+	gpuLock.Unlock()
+	return nil
+}
+
+// DisableGPU gives the batch scheduler back (to be called after Close).
+func (this *Reader) DisableGPU() {
+	gpuLock.Lock()
+	gb := gpuReaders[this]
+	delete(gpuReaders, this)
+	gpuLock.Unlock()
+
+	if gb != nil {
+		gb.close()
+	}
+}
+
+// processBlockGPU = Reader.processBlock: the payloads are read from the shared bitstream one after the other as the
+// decoding tasks do (:1816-1852), then ONE device batch replaces the concurrent part of the tasks (:1875-2011).
+// Block b of the batch is decoded into this.buffers[b].Buf, where Reader.Read picks it up.
+func (this *Reader) processBlockGPU(gb *gpuBatch) (int64, error) {
+	if atomic.LoadInt32(&this.blockID) == _CANCEL_TASKS_ID {
+		return 0, nil
+	}
+
+	bufSize := this.blockSize + _EXTRA_BUFFER_SIZE
+
+	if bufSize < this.blockSize+(this.blockSize>>4) {
+		bufSize = this.blockSize + (this.blockSize >> 4)
+	}
+
+	payload := make([][]byte, 0, this.jobs)
+	out := make([][]byte, 0, this.jobs)
+
+	for taskID := 0; taskID < this.jobs; taskID++ {
+		lr := uint(this.ibs.ReadBits(5)) + 3
+		read := this.ibs.ReadBits(lr)
+
+		if read == 0 {
+			// end of stream: nothing is decoded from here on (what the first task that reads an empty block does, :1781-1793)
+			atomic.StoreInt32(&this.blockID, _CANCEL_TASKS_ID)
+			break
+		}
+
+		if read > uint64(1)<<34 {
+			return 0, &IOError{msg: "Invalid block size", code: kanzi.ERR_BLOCK_SIZE}
+		}
+
+		r := int((read + 7) >> 3)
+
+		if len(this.buffers[this.jobs+taskID].Buf) < r {
+			this.buffers[this.jobs+taskID].Buf = make([]byte, r)
+		}
+
+		if len(this.buffers[taskID].Buf) < bufSize {
+			this.buffers[taskID].Buf = make([]byte, bufSize)
+		}
+
+		data := this.buffers[this.jobs+taskID].Buf
+
+		// Read data from shared bitstream
+		for n := uint(0); read > 0; {
+			chkSize := uint(1 << 30)
+
+			if read < 1<<30 {
+				chkSize = uint(read)
+			}
+
+			this.ibs.ReadArray(data[n:], chkSize)
+			n += ((chkSize + 7) >> 3)
+			read -= uint64(chkSize)
+		}
+
+		atomic.AddInt32(&this.blockID, 1)
+		payload = append(payload, data[0:r])
+		out = append(out, this.buffers[taskID].Buf)
+	}
+
+	if len(payload) == 0 {
+		this.consumed = 0
+		return 0, nil
+	}
+
+	sizes, err := gb.decodeBlocks(payload, out)
+
+	if err != nil {
+		return 0, err
+	}
+
+	decoded := int64(0)
+
+	for i := range sizes {
+		if sizes[i] > this.blockSize {
+			return decoded, &IOError{msg: "Block incorrectly decompressed", code: kanzi.ERR_PROCESS_BLOCK}
+		}
+
+		decoded += int64(sizes[i])
+	}
+
+	this.consumed = 0
+	return decoded, nil
+}

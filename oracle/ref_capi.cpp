@@ -8,7 +8,13 @@
 //
 // What it is for: pinning the hand-written oracle (oracle/*.hpp) and the device against the reference's OWN code:
 // tests/test_ref_build.py (CPU) and tests/test_parity_gpu.py::test_device_vs_ref_* (GPU).
+#ifdef KREF_WITH_CGO
+// oracle/_ref/libknz_ref_gpu.so: the same translation PLUS the cgo shim of go/ (gpu_batch.go, gpu_stream.go, gpu_transform.go, gpu_entropy.go) and the
+// two-line patch of INTEGRATION.md in CompressedStream.go, linked against libknz_gpu.so: the reference's Writer / Reader drive the device.
+#include "kanzi_ref_gpu.gen.hpp"
+#else
 #include "kanzi_ref.gen.hpp"
+#endif
 
 #include <string>
 
@@ -288,6 +294,122 @@ int kref_decompress(const uint8_t* src, uint64_t n, uint32_t jobs, uint8_t* dst,
     return 0;
     KREF_CATCH
 }
+
+#ifdef KREF_WITH_CGO
+// The Go host with its block batches re-pointed at the GPU batch scheduler: io.NewWriterWithCtx + Writer.EnableGPU (go/gpu_stream.go), `jobs` blocks per
+// device batch. Same arguments and result as kref_compress.
+int kref_gpu_compress(const uint8_t* src, uint64_t n, const char* transform, const char* entropy, uint32_t block_size, uint32_t checksum_bits, uint32_t jobs,
+                      int64_t file_size, int skip_blocks, uint8_t* dst, uint64_t cap, uint64_t* out_n) {
+    KREF_TRY
+    MemStream ms;
+    Ctx ctx = go::make_map<go::String, go::any>();
+    ctx[go::String("entropy")] = go::any(go::String(entropy));
+    ctx[go::String("transform")] = go::any(go::String(transform));
+    ctx[go::String("blockSize")] = go::any(go::Uint(go::U(block_size)));
+    ctx[go::String("jobs")] = go::any(go::Uint(go::U(jobs ? jobs : 1)));
+    ctx[go::String("checksum")] = go::any(go::Uint(go::U(checksum_bits)));
+    if (file_size >= 0) ctx[go::String("fileSize")] = go::any(go::Int64(go::U(file_size)));
+    ctx[go::String("headerless")] = go::any(false);
+    if (skip_blocks) ctx[go::String("skipBlocks")] = go::any(true);
+    auto [w, err] = kz_io::NewWriterWithCtx(&ms, ctx);
+    if (err != nullptr) return fail(err, 1);
+    go::error gerr = w->EnableGPU();
+    if (gerr != nullptr) return fail(gerr, 5);
+    auto [wr, werr] = w->Write(copy_in(src, n));
+    go::error cerr = werr != nullptr ? werr : w->Close();
+    w->DisableGPU();
+    if (cerr != nullptr) return fail(cerr, 3);
+    if (ms.data.size() > cap) { g_err = "output buffer too small"; return 4; }
+    memcpy(dst, ms.data.data(), ms.data.size());
+    *out_n = ms.data.size();
+    return 0;
+    KREF_CATCH
+}
+
+// io.NewReader + Reader.EnableGPU: the payloads are read from the stream by the Go code, decoded by the device batch
+int kref_gpu_decompress(const uint8_t* src, uint64_t n, uint32_t jobs, uint8_t* dst, uint64_t cap, uint64_t* out_n) {
+    KREF_TRY
+    MemStream ms;
+    ms.data.assign((const char*)src, (size_t)n);
+    auto [r, err] = kz_io::NewReader(&ms, go::Uint(go::U(jobs ? jobs : 1)));
+    if (err != nullptr) return fail(err, 1);
+    go::error gerr = r->EnableGPU();
+    if (gerr != nullptr) return fail(gerr, 5);
+    go::Slice<go::Byte> buf = go::Slice<go::Byte>::make(1 << 20, 1 << 20);
+    uint64_t total = 0;
+    int rc = 0;
+    while (true) {
+        auto [k, rerr] = r->Read(buf);
+        if (k.v > 0) {
+            if (total + (uint64_t)k.v > cap) { g_err = "output buffer too small"; rc = 4; break; }
+            memcpy(dst + total, buf.p, (size_t)k.v);
+            total += (uint64_t)k.v;
+        }
+        if (rerr != nullptr) {
+            if (rerr == go_io::EOF_) break;
+            rc = fail(rerr, 2);
+            break;
+        }
+        if (k.v == 0) break;
+    }
+    r->Close();
+    r->DisableGPU();
+    if (rc) return rc;
+    *out_n = total;
+    return 0;
+    KREF_CATCH
+}
+
+// kanzi.ByteTransform / kanzi.EntropyEncoder / kanzi.EntropyDecoder objects of go/gpu_transform.go and go/gpu_entropy.go over a handle of knz_open
+static void* open_handle(uint32_t block_size) {
+    ::knz_cfg cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.block_size = block_size; cfg.bs_version = 6; cfg.device = -1;
+    void* h = nullptr;
+    return ::knz_open(&cfg, &h) == 0 ? h : nullptr;
+}
+int kref_gpu_transform(int inverse, uint64_t t, const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap, uint64_t* out_n) {
+    KREF_TRY
+    void* h = open_handle(1u << 20);
+    if (!h) { g_err = "knz_open failed"; return 5; }
+    auto [tr, err] = kz_transform::NewGPUTransform(go_unsafe::Pointer(h), go::Uint64(go::U(t)));
+    int rc = 0;
+    if (err != nullptr) rc = fail(err, 2);
+    else {
+        go::Slice<go::Byte> in = copy_in(src, n);
+        go::Slice<go::Byte> outb = go::Slice<go::Byte>::make((int64_t)cap, (int64_t)cap);
+        auto [rd, wr, ferr] = inverse ? tr->Inverse(in, outb) : tr->Forward(in, outb);
+        if (ferr != nullptr) { fail(ferr, -1); rc = inverse ? 3 : -1; }
+        else { if (wr.v) memcpy(dst, outb.p, wr.v); *out_n = wr.v; }
+    }
+    ::knz_close(h);
+    return rc;
+    KREF_CATCH
+}
+int kref_gpu_entropy_encode(uint32_t type, const uint8_t* src, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_bits) {
+    KREF_TRY
+    void* h = open_handle(1u << 20);
+    if (!h) { g_err = "knz_open failed"; return 5; }
+    MemStream ms;
+    auto [obs, err0] = kz_bitstream::NewDefaultOutputBitStream(&ms, go::Uint(go::U(16384)));
+    auto [ee, err] = kz_entropy::NewGPUEntropyEncoder(go_unsafe::Pointer(h), obs, go::Uint32(go::U(type)));
+    int rc = 0;
+    if (err != nullptr) rc = fail(err, 2);
+    else {
+        auto [wr, werr] = ee->Write(copy_in(src, n));
+        if (werr != nullptr) rc = fail(werr, 3);
+        else {
+            ee->Dispose();
+            obs->Close();
+            if (ms.data.size() > cap) { g_err = "output buffer too small"; rc = 4; }
+            else { memcpy(out, ms.data.data(), ms.data.size()); *out_bits = obs->Written().v; }
+        }
+    }
+    ::knz_close(h);
+    return rc;
+    KREF_CATCH
+}
+#endif
 
 uint32_t kref_xxhash32(const uint8_t* d, uint64_t n, uint32_t seed) {
     go::ArenaScope arena_;

@@ -1,0 +1,122 @@
+"""The Go host driving the device, executed: the cgo shim of go/ (gpu_batch.go, gpu_stream.go, gpu_transform.go, gpu_entropy.go) and the two-line
+patch of INTEGRATION.md in the reference's CompressedStream.go, translated to C++ by tools/go2cpp together with the rest of the reference and linked
+against libknz_gpu.so (`make -C oracle _ref_gpu`, built in the build container; the library travels to the GPU box). The reference's own Writer /
+Reader then hand their block batches to the GPU batch scheduler through the shim's Go code, and the stream they write must be the stream they write
+WITHOUT the device (oracle/_ref, the same translation without shim and patch) and the stream the committed reference vectors describe."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import parity_cases as P
+import ref_lib as R
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "oracle", "_ref", "libknz_ref_gpu.so")
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not os.path.exists(SO):
+        pytest.skip("oracle/_ref/libknz_ref_gpu.so is not built (make -C oracle _ref_gpu in the build container)")
+    L = C.CDLL(SO)
+    u8p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)
+    L.kref_last_error.restype = C.c_char_p
+    L.kref_gpu_compress.argtypes = [u8p, C.c_uint64, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int64, C.c_int, u8p, C.c_uint64, u64p]
+    L.kref_gpu_decompress.argtypes = [u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, u64p]
+    L.kref_gpu_transform.argtypes = [C.c_int, C.c_uint64, u8p, C.c_uint64, u8p, C.c_uint64, u64p]
+    L.kref_gpu_entropy_encode.argtypes = [C.c_uint32, u8p, C.c_uint64, u8p, C.c_uint64, u64p]
+    return L
+
+
+def _buf(data):
+    a = np.frombuffer(bytes(data), dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def gpu_compress(L, data, transform, entropy, bs, ck=0, jobs=16, skip=False):
+    a, p = _buf(data)
+    cap = len(data) + len(data) // 2 + (1 << 20)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_uint64()
+    rc = L.kref_gpu_compress(p, len(data), transform.encode(), entropy.encode(), bs, ck, jobs, len(data), 1 if skip else 0,
+                             out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n))
+    assert rc == 0, (rc, L.kref_last_error())
+    return out[: n.value].tobytes()
+
+
+def gpu_decompress(L, stream, cap, jobs=16):
+    a, p = _buf(stream)
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = C.c_uint64()
+    rc = L.kref_gpu_decompress(p, len(stream), jobs, out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n))
+    assert rc == 0, (rc, L.kref_last_error())
+    return out[: n.value].tobytes()
+
+
+@pytest.mark.parametrize("cfg", [("NONE", "HUFFMAN", 1 << 16, 0), ("BWT+RANK+ZRLT", "ANS1", 1 << 16, 64), ("LZ", "ANS0", 1 << 16, 32),
+                                 ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0", 1 << 17, 0), ("BWT+RANK+ZRLT", "FPAQ", 1 << 16, 0), ("NONE", "NONE", 1 << 16, 0)])
+def test_reference_writer_and_reader_through_the_go_shim(G, cfg):
+    transform, entropy, bs, ck = cfg
+    for n in (0, 1, 15, 16, 70000, 5 * bs + 4321, 40 * bs + 17):           # (40 blocks with jobs 16: three device batches per stream)
+        data = P.corpus(n, seed=n % 97)
+        via_gpu = gpu_compress(G, data, transform, entropy, bs, ck)
+        host_only = R.compress(data, transform, entropy, bs, ck) if R.available() else O.compress(data, transform, entropy, bs, ck)
+        assert via_gpu == host_only, (cfg, n, "the reference Writer writes another stream when its batches go through the device")
+        assert gpu_decompress(G, host_only, n + 64) == data, (cfg, n, "reference Reader over the device")
+        for jobs in (1, 3):
+            assert gpu_compress(G, data, transform, entropy, bs, ck, jobs=jobs) == host_only, (cfg, n, jobs)
+            assert gpu_decompress(G, via_gpu, n + 64, jobs=jobs) == data
+
+
+def test_go_shim_against_the_committed_reference_vectors(G):
+    import test_ref_streams as T
+    data = T._inputs()
+    cases = [(c, s) for c, s in T._cases() if c["block_size"] <= (4 << 20) and not c["name"].startswith("cfg5")]
+    assert len(cases) > 200
+    for c, ref in cases[::3]:
+        src = data[c["input"][:-4]]
+        got = gpu_compress(G, src, c["transform"], c["entropy"], c["block_size"], c["checksum"], skip=c["skip_blocks"])
+        assert len(got) == c["stream_bytes"] and hashlib.sha256(got).hexdigest() == c["sha256"], c["name"]
+        assert gpu_decompress(G, got, len(src) + 64) == src, c["name"]
+
+
+def test_plugin_objects_of_the_go_shim(G):
+    """kanzi.ByteTransform (go/gpu_transform.go) and kanzi.EntropyEncoder (go/gpu_entropy.go) objects over a device handle == the oracle's objects"""
+    u8p = C.POINTER(C.c_uint8)
+    for tname in ("RANK", "ZRLT", "LZ", "BWT", "SRT"):
+        tid = P._TID[tname]
+        for name, data in list(P.transform_inputs(max_len=1 << 16))[:14]:
+            a, p = _buf(data)
+            cap = 2 * len(data) + 65536
+            out = np.zeros(cap, dtype=np.uint8)
+            n = C.c_uint64()
+            rc = G.kref_gpu_transform(0, tid, p, len(data), out.ctypes.data_as(u8p), cap, C.byref(n))
+            o = O.transform_forward(tid, data)
+            assert (rc == -1) == (o is None), (tname, name, rc, G.kref_last_error())
+            if o is None:
+                continue
+            assert rc == 0 and out[: n.value].tobytes() == o, (tname, name)
+            back = np.zeros(len(data) + 1024, dtype=np.uint8)
+            fa, fp = _buf(o)
+            rc = G.kref_gpu_transform(1, tid, fp, len(o), back.ctypes.data_as(u8p), len(back), C.byref(n))
+            assert rc == 0 and back[: n.value].tobytes() == data, (tname, name, "inverse")
+    for ename in ("HUFFMAN", "ANS0", "ANS1", "FPAQ"):
+        et = O.entropy_type(ename)
+        for name, data in list(P.entropy_inputs())[:16]:
+            if ename == "ANS1" and len(data) in (2, 3):
+                continue
+            a, p = _buf(data)
+            cap = 2 * len(data) + 262144
+            out = np.zeros(cap, dtype=np.uint8)
+            bits = C.c_uint64()
+            rc = G.kref_gpu_entropy_encode(et, p, len(data), out.ctypes.data_as(u8p), cap, C.byref(bits))
+            assert rc == 0, (ename, name, G.kref_last_error())
+            ob, obits = O.entropy_encode(et, data)
+            assert bits.value == obits and out[: (obits + 7) // 8].tobytes() == ob, (ename, name)

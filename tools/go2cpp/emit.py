@@ -44,8 +44,10 @@ STD_INTERFACES = {
     ("io", "ReadWriteCloser"): {"Read": RW_SIG, "Write": RW_SIG, "Close": ((), ("go::error",))},
     ("go", "error_iface"): {"Error": ((), ("go::String",))},
 }
-STD_VALUE_TYPES = {("sync", "WaitGroup"): "::go_sync::WaitGroup", ("sync", "Mutex"): "::go_sync::Mutex", ("bytes", "Buffer"): "::go_bytes::Buffer", ("time", "Time"): "::go_time::Time"}
-STD_PACKAGES = {"errors", "fmt", "encoding/binary", "math/bits", "sort", "slices", "io", "sync", "strings", "bytes", "sync/atomic", "time", "runtime"}
+STD_VALUE_TYPES = {("sync", "WaitGroup"): "::go_sync::WaitGroup", ("sync", "Mutex"): "::go_sync::Mutex", ("bytes", "Buffer"): "::go_bytes::Buffer", ("time", "Time"): "::go_time::Time", ("unsafe", "Pointer"): "::go_unsafe::Pointer", ("runtime", "Pinner"): "::go_runtime::Pinner"}
+# cgo: the C types the shim files name (include/knz_gpu.h and <stdint.h> through tools/go2cpp/runtime/cgo_shim.hpp)
+CGO_TYPES = {"uint8_t", "uint16_t", "uint32_t", "uint64_t", "int8_t", "int16_t", "int32_t", "int64_t", "int", "uint", "size_t", "char", "float", "knz_cfg", "knz_block"}
+STD_PACKAGES = {"errors", "fmt", "encoding/binary", "math/bits", "sort", "slices", "io", "sync", "strings", "bytes", "sync/atomic", "time", "runtime", "C", "unsafe"}
 
 
 THIS_IS_RECEIVER = [False]     # Go's conventional receiver name `this` is C++'s `this` inside methods; elsewhere it is an ordinary local
@@ -252,6 +254,10 @@ class Translator:
                 if t.name not in r[1].types:
                     self.err(t, f"unknown type {t.pkg}.{t.name}")
                 return self.named_ctype(r[1], t.name)
+            if r[1] == "C":
+                if t.name not in CGO_TYPES:
+                    self.err(t, f"C type {t.name} is not in the cgo shim")
+                return f"::go_C::{mangle(t.name)}"
             if (r[1], t.name) in STD_INTERFACES:
                 return f"::go_{r[1]}::{t.name}*"
             if (r[1], t.name) in STD_VALUE_TYPES:
@@ -322,7 +328,7 @@ class Translator:
                 return None
             if r[0] == "kz" and x.sel in r[1].types:
                 return Node("NamedType", x.pos, pkg=x.x.name, name=x.sel)
-            if r[0] == "std" and ((r[1], x.sel) in STD_INTERFACES or (r[1], x.sel) in STD_VALUE_TYPES):
+            if r[0] == "std" and ((r[1], x.sel) in STD_INTERFACES or (r[1], x.sel) in STD_VALUE_TYPES or (r[1] == "C" and x.sel in CGO_TYPES)):
                 return Node("NamedType", x.pos, pkg=x.x.name, name=x.sel)
             return None
         if x.kind == "Unary" and x.op == "*":

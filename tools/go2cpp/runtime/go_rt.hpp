@@ -198,6 +198,7 @@ template <class To, class From> constexpr To conv(const From& x) {
     if constexpr (std::is_same_v<To, From>) return x;
     else if constexpr (std::is_floating_point_v<To> && std::is_same_v<From, U>) return (To)(double)x.v;
     else if constexpr (std::is_floating_point_v<To> && is_goint<From>::value) return (To)x.v;
+    else if constexpr (std::is_pointer_v<To> && std::is_class_v<From> && !std::is_same_v<From, nil_t>) return (To)x.p;     // (*T)(unsafe.Pointer)
     else return To(x);
 }
 // array length / index from any integer
@@ -713,5 +714,7 @@ constexpr Duration Nanosecond = Duration::from_raw(1), Microsecond = Duration::f
 }  // namespace go_time
 namespace go_runtime {
 inline void Gosched() {}
+struct Pinner { Pinner* operator->() { return this; } template <class T> void Pin(T*) {} void Unpin() {} };   // (memory does not move here)
+template <class T, class F> inline void SetFinalizer(T*, F) {}
 inline go::Int NumCPU() { return go::Int::from_raw(1); }
 }  // namespace go_runtime
