@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void knz_bwt_inv_keys_kernel(BwtInvArgs a, uin
     vals[i] = i;
 }
 
+#ifndef KNZ_BWT_SPLIT
 #define KNZ_BWT_SPLIT 128u
+#endif
 
 // LF links (BWT.go:228-247): slot p of the stably sorted order holds symbol v from payload index i; the link is
 // i-1 for 1 <= i < pIdx, i for i >= pIdx (the entry of i = 0 ends the text and is never followed).

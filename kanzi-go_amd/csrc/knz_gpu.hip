@@ -94,7 +94,7 @@ int DevBuf::reserve(size_t n) {
 void DevBuf::release() { if (p) hipFree(p); p = nullptr; cap = 0; }
 static void knz_release_workspace(Handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->pipe_ready) hipStreamSynchronize(h->stream2);
+    if (h->pipe_ready) { hipStreamSynchronize(h->stream2); hipStreamSynchronize(h->stream3); }
     for (DevBuf* b : h->all_bufs) b->release();
     h->text_stat_ready = false;                      // (the static TEXT dictionary lives in one of them: uploaded again on demand)
     h->huf_fallback_n = 0; h->lzs_n = 0; h->lzi_serial_n = 0; h->pipe_n = 0;
@@ -219,8 +219,8 @@ extern "C" int knz_open(const knz_cfg* cfg, void** handle) {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamDefault) == hipSuccess) h->own_stream = true;
     else h->stream = nullptr;
     for (int i = 0; i <= KNZ_STAGE_COUNT; i++) hipEventCreate(&h->ev[i]);
-    h->pipe_ready = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&h->ev_pipe[i], hipEventDisableTiming) != hipSuccess) h->pipe_ready = false;
+    h->pipe_ready = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 3; i++) if (hipEventCreateWithFlags(&h->ev_pipe[i], hipEventDisableTiming) != hipSuccess) h->pipe_ready = false;
     for (int i = 0; i < KNZ_STAGE_COUNT; i++) h->stage_ms[i] = 0.f;
     *handle = h;
     return KNZ_OK;
@@ -235,8 +235,8 @@ extern "C" int knz_close(void* handle) {
     if (h->pinned_status) hipHostFree(h->pinned_status);
     if (h->pinned_len) hipHostFree(h->pinned_len);
     for (int i = 0; i <= KNZ_STAGE_COUNT; i++) hipEventDestroy(h->ev[i]);
-    if (h->pipe_ready) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); h->stream2 = nullptr; }
-    for (int i = 0; i < 2; i++) if (h->ev_pipe[i]) { hipEventDestroy(h->ev_pipe[i]); h->ev_pipe[i] = nullptr; }
+    if (h->pipe_ready) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); h->stream2 = nullptr; hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); h->stream3 = nullptr; }
+    for (int i = 0; i < 3; i++) if (h->ev_pipe[i]) { hipEventDestroy(h->ev_pipe[i]); h->ev_pipe[i] = nullptr; }
     for (int i = 0; i < KNZ_MAX_PROBES; i++) if (h->probes[i].a) { hipEventDestroy(h->probes[i].a); hipEventDestroy(h->probes[i].b); }
     delete h;
     return KNZ_OK;

@@ -60,11 +60,12 @@ struct Handle {
     size_t huf_fallback_n = 0;        // chunks covered by huf_fallback in the last decode batch
     DevBuf huf_fallback;              // [chunks] 1 = the parallel Huffman decoder handed the chunk to the serial one
     // transform pipeline (knz_transforms.inc)
-    DevBuf xf_r3, pipe_prog, pipe_flag;                              // fused ZRLT / RANK inverse under the rANS-1 decoder (rank_pipe.hip): rank region, progress words, per-block done flags
+    DevBuf xf_r3, pipe_prog, pipe_flag, pipe_group;                              // fused ZRLT / RANK inverse under the rANS-1 decoder (rank_pipe.hip): rank region, progress words, per-block done flags
     hipStream_t stream2 = nullptr;                                  // its stream (non-blocking) and the two events that tie it to the caller's
     bool pipe_ready = false;
     size_t pipe_n = 0;                // blocks covered by pipe_flag in the last decode batch (0: the fused path was not taken)
-    hipEvent_t ev_pipe[2] = {nullptr, nullptr};
+    hipStream_t stream3 = nullptr;                                  // ... and the stream of the launch that holds the long chains
+    hipEvent_t ev_pipe[3] = {nullptr, nullptr, nullptr};
     DevBuf xf_r1, xf_r2, xf_outptr, xf_outlen, xf_ok, xf_side, xf_active, xf_take, xf_sega, xf_segb, xf_gstart, xf_misc;
     DevBuf lz_hash, lz_tk, lz_mb, lz_ml;
     DevBuf lz_k0, lz_k1, lz_v0, lz_v1, lz_cand, lz_cp, lz_holes, lz_gstart;     // second form of the LZ forward (lz_par.hip): sort buffers, candidates, common prefixes, hole bitmaps

@@ -30,6 +30,8 @@ struct RankPipeArgs {
     uint32_t out_cap;
     uint32_t zrlt_stage, rank_stage;  // positions of the two transforms in the sequence (their skip bits)
     uint32_t mode;                    // bit 8: force the three-register chain; bits 12..: packed/unpacked cut in rows (tests)
+    const uint8_t* group;             // [nblocks] or null: which of the two launches takes the block (the long chains go in a launch of their own, see decode_batch)
+    uint32_t group_sel;
 };
 #define KNZ_PIPE_DONE 0xFFFFFFFFFFFFFFFFull
 #define KNZ_PIPE_PIECE 2048u          // input bytes per expansion step: 32 per lane
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(128) void knz_zrlti_rank_pipe_kernel(RankPipeArgs a
     __shared__ uint32_t s_state;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x;
+    if (a.group != nullptr && a.group[b] != a.group_sel) return;
     // --- does this block take the fused path at all?
     const uint32_t m = a.cur_len[b];
     const uint32_t K = a.chunks_per_block;

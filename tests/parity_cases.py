@@ -674,8 +674,8 @@ def check_rank_pipe(be, monkeypatch, sizes=((50000, 1 << 14), (300000, 1 << 16),
                     stream = O.compress(data, seq, "ANS1", bs)
                     sp, k1 = be.to_dev(stream)
                     res = {}
-                    for form in ("pipe", "regular", "unpacked", "cut"):
-                        for v in ("KNZ_NO_RANK_PIPE", "KNZ_RANK_UNPACKED", "KNZ_RANK_CUT"):
+                    for form in ("pipe", "regular", "unpacked", "cut", "two_groups"):
+                        for v in ("KNZ_NO_RANK_PIPE", "KNZ_RANK_UNPACKED", "KNZ_RANK_CUT", "KNZ_RANK_PIPE_TWO_GROUPS"):
                             monkeypatch.delenv(v, raising=False)
                         if form == "regular":
                             monkeypatch.setenv("KNZ_NO_RANK_PIPE", "1")
@@ -683,6 +683,8 @@ def check_rank_pipe(be, monkeypatch, sizes=((50000, 1 << 14), (300000, 1 << 16),
                             monkeypatch.setenv("KNZ_RANK_UNPACKED", "1")
                         elif form == "cut":
                             monkeypatch.setenv("KNZ_RANK_CUT", "512")
+                        elif form == "two_groups":                                         # (the long chains in a launch of their own, the stages behind the chain in two passes)
+                            monkeypatch.setenv("KNZ_RANK_PIPE_TWO_GROUPS", "1")
                         c = K.Codec(seq, "ANS1", bs, lib=be.lib)
                         out, ko = be.empty(n2 + 4096)
                         nd = c.dev_decompress(sp, len(stream), out, n2 + 4096)
@@ -690,10 +692,10 @@ def check_rank_pipe(be, monkeypatch, sizes=((50000, 1 << 14), (300000, 1 << 16),
                         res[form] = c.last_counter(6)
                         c.close()
                     assert res["regular"] == 0
-                    assert res["pipe"] == res["unpacked"] == res["cut"]
+                    assert res["pipe"] == res["unpacked"] == res["cut"] == res["two_groups"]
                     if name in ("corpus", "sparse", "steps"):
                         assert res["pipe"] >= 1, (seq, n, bs, seed, name, "no block took the fused chain")
-    for v in ("KNZ_NO_RANK_PIPE", "KNZ_RANK_UNPACKED", "KNZ_RANK_CUT"):
+    for v in ("KNZ_NO_RANK_PIPE", "KNZ_RANK_UNPACKED", "KNZ_RANK_CUT", "KNZ_RANK_PIPE_TWO_GROUPS"):
         monkeypatch.delenv(v, raising=False)
 
 
