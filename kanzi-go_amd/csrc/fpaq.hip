@@ -6,6 +6,9 @@
 //   * input tiles are staged cooperatively by the wave, the 8 probability reads of a byte are issued up front
 //     (the encoder knows the tree path in advance), the 32-bit flush words go to the scratch slot with plain stores;
 //   * per 4 MiB sub-chunk the kernel leaves 3 units: varint(bytes) | bytes | (low | 0xFFFFFF):56 (:162-168,:195).
+// STATUS (closed in round 5): this is a format limit, not open work. One lane per block is ~19x slower per chain than a host thread (bench.py --config fpaq,
+// `fpaq_stage`); the context-parallel probability pass was costed (19 -> 13 s per 10^9 bytes) and would not change that. Config 5 is served at
+// blocks-in-flight scale only: hundreds of blocks side by side (many streams / handles), not a faster block.
 #include "bits.h"
 
 #define KNZ_FPAQ_CHUNK (4u << 20)

@@ -25,6 +25,11 @@ SO = os.path.join(ROOT, "oracle", "_ref", "libknz_ref_gpu.so")
 def G():
     if not os.path.exists(SO):
         pytest.skip("oracle/_ref/libknz_ref_gpu.so is not built (make -C oracle _ref_gpu in the build container)")
+    # torch first: it carries its own copy of the HIP runtime, and whichever copy comes up first owns the device for the process (the rest of the
+    # GPU suite holds its device memory in torch tensors)
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    torch.zeros(1, device="cuda:0")
     L = C.CDLL(SO)
     u8p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)
     L.kref_last_error.restype = C.c_char_p
