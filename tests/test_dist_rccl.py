@@ -63,3 +63,28 @@ def test_rccl_world_size_one(tmp_path):
     p = subprocess.run([sys.executable, str(script), HERE, port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=580)
     assert p.returncode == 0, p.stdout[-3000:]
     assert "rccl ok" in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_distributed_code_path_on_rccl():
+    """bench.py --force-dist: the N > 1 code path of the bench itself (process group on RCCL, sharded encode, gather, bit-granular assembly, per-rank
+    decode, the max-over-ranks collectives) at world size 1, on the full configs[3] job: the JSON contract and the assembled stream against the oracle.
+    (Config 5 at its stated 10^9 bytes is not in the suite for time: one 32 MiB block and a ragged one are, test_config5_block_size_32m_fpaq; the full
+    size is a builder-run line, profiles/r04_final_config_fpaq_bench.json.)"""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_PORT=str(29600 + (os.getpid() % 300)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "1", "--warmup", "1", "--no-pmc", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=850, cwd=root, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 1 and out["scaling"] == "strong" and out["dtype"] == "u8"
+    assert "configs[3]" in out["config"]["workload"] and out["config"]["blocks"] == 26
+    assert out["roundtrip_ok"] is True and out["bit_exact_vs_oracle"] is True
+    assert out["roofline"]["kernel"] is not None and out["roofline"]["encode_MBps"] > 0 and out["roofline"]["decode_MBps"] > 0
+    assert out["value"] > 100                                   # (MB/s: the default job's round trip is ~340 on one MI355X)
