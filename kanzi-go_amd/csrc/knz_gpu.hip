@@ -475,12 +475,19 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
             const uint32_t slotsPerGroup = (uint32_t)std::max<size_t>(cpb, std::min<size_t>((size_t)nblocks * cpb, ((size_t)64 << 30) / perSlot));
             uint32_t GB = std::max<uint32_t>(1, slotsPerGroup / cpb);                   // whole blocks per group
             if (const char* e = knz_test_switch("KNZ_ANS1_GROUP_BLOCKS")) GB = std::max(1, atoi(e));   // (tests: several groups on small inputs)
-            const uint32_t gs = GB * cpb;
             const bool ans1EncPlain = knz_test_switch("KNZ_ANS1_ENC_PLAIN") != nullptr;   // (A/B and cross-check: the compiler's loop instead of the hand-written one)
-            if (h->a1_freqs.reserve((size_t)gs * 65536 * 4) || h->a1_tab.reserve((size_t)gs * 65536 * 8) ||
-                h->a1_ctxhdr.reserve((size_t)gs * 256 * KNZ_ANS1_CTXHDR_BYTES + 64) || h->a1_ctxbits.reserve((size_t)gs * 256 * 4) ||
-                h->a1_ent.reserve((size_t)gs * KNZ_ANS1_ENT_STRIDE * 16))
-                return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
+            // a group the device has no room for (other handles, a smaller device) is halved until it fits: fewer chains side by side, same bytes
+            uint32_t gs = GB * cpb;
+            for (;;) {
+                gs = GB * cpb;
+                if (!(h->a1_freqs.reserve((size_t)gs * 65536 * 4) || h->a1_tab.reserve((size_t)gs * 65536 * 8) ||
+                      h->a1_ctxhdr.reserve((size_t)gs * 256 * KNZ_ANS1_CTXHDR_BYTES + 64) || h->a1_ctxbits.reserve((size_t)gs * 256 * 4) ||
+                      h->a1_ent.reserve((size_t)gs * KNZ_ANS1_ENT_STRIDE * 16)))
+                    break;
+                if (GB == 1) return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "device workspace allocation failed");
+                h->a1_freqs.release(); h->a1_tab.release(); h->a1_ctxhdr.release(); h->a1_ctxbits.release(); h->a1_ent.release();
+                GB = (GB + 1) / 2;
+            }
             for (uint32_t b0 = 0; b0 < nblocks; b0 += GB) {
                 const uint32_t gb = std::min<uint32_t>(GB, nblocks - b0), ns = gb * cpb;
                 const size_t s0 = (size_t)b0 * cpb;

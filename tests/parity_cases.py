@@ -190,6 +190,9 @@ def check_alloc_split(be, monkeypatch):
         with pytest_raises_knz_any():
             K.BlockBatch(c).encode(blocks)
         c.close()
+    # the order-1 rANS encoder's expanded-step workspace (64 MiB per chunk slot) is halved until the device takes it: 6 slots -> 3 -> 2
+    monkeypatch.setenv("KNZ_TEST_ALLOC_LIMIT", "200000000")
+    check_stream(be, "NONE", "ANS1", 1 << 16, 6 * (1 << 16) - 77, seed=11)
     monkeypatch.delenv("KNZ_TEST_ALLOC_LIMIT", raising=False)
 
 
