@@ -655,7 +655,8 @@ def check_reference_inputs(be):
         cs.close()
 
 
-def check_rank_pipe(be, monkeypatch, sizes=((50000, 1 << 14), (300000, 1 << 16), (1000, 1024), (200001, 1 << 17)), seeds=(5, 6)):
+def check_rank_pipe(be, monkeypatch, sizes=((50000, 1 << 14), (300000, 1 << 16), (1000, 1024), (200001, 1 << 17)), seeds=(5, 6), seqs=("BWT+RANK+ZRLT", "RANK+ZRLT"),
+                    forms=("pipe", "regular", "unpacked", "cut", "two_groups")):
     """Decode of ...RANK+ZRLT / ANS1: the two inverses run as one chain under the rANS decoder (rank_pipe.hip). Same bytes as the regular stage kernels
     (KNZ_NO_RANK_PIPE), every coded block taken by the chain (knz_last_counter 6), the three-register form and a moved packed / unpacked cut included;
     inputs with long zero runs (digits across lane and piece boundaries), escapes (0xFE / 0xFF ranks) and blocks a stage skips."""
@@ -669,7 +670,7 @@ def check_rank_pipe(be, monkeypatch, sizes=((50000, 1 << 14), (300000, 1 << 16),
         a = np.zeros(n, dtype=np.uint8)
         a[:: max(n // 300, 1)] = r.integers(1, 256, len(a[:: max(n // 300, 1)]))
         yield "steps", a.tobytes()
-    for seq in ("BWT+RANK+ZRLT", "RANK+ZRLT"):
+    for seq in seqs:
         for n, bs in sizes:
             for seed in seeds:
                 for name, data in shapes(n, seed):
@@ -677,7 +678,7 @@ def check_rank_pipe(be, monkeypatch, sizes=((50000, 1 << 14), (300000, 1 << 16),
                     stream = O.compress(data, seq, "ANS1", bs)
                     sp, k1 = be.to_dev(stream)
                     res = {}
-                    for form in ("pipe", "regular", "unpacked", "cut", "two_groups"):
+                    for form in forms:
                         for v in ("KNZ_NO_RANK_PIPE", "KNZ_RANK_UNPACKED", "KNZ_RANK_CUT", "KNZ_RANK_PIPE_TWO_GROUPS"):
                             monkeypatch.delenv(v, raising=False)
                         if form == "regular":
@@ -695,7 +696,7 @@ def check_rank_pipe(be, monkeypatch, sizes=((50000, 1 << 14), (300000, 1 << 16),
                         res[form] = c.last_counter(6)
                         c.close()
                     assert res["regular"] == 0
-                    assert res["pipe"] == res["unpacked"] == res["cut"] == res["two_groups"]
+                    assert len({v for k, v in res.items() if k != "regular"}) == 1, res
                     if name in ("corpus", "sparse", "steps"):
                         assert res["pipe"] >= 1, (seq, n, bs, seed, name, "no block took the fused chain")
     for v in ("KNZ_NO_RANK_PIPE", "KNZ_RANK_UNPACKED", "KNZ_RANK_CUT", "KNZ_RANK_PIPE_TWO_GROUPS"):

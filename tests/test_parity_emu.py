@@ -137,7 +137,9 @@ def test_bwt_suffix_sort_fuzz(be, monkeypatch):
 
 
 def test_rank_pipe_under_ans1_decoder(be, monkeypatch):
-    P.check_rank_pipe(be, monkeypatch, sizes=((50000, 1 << 14), (1000, 1024), (70001, 1 << 16)), seeds=(5,))
+    # (the emulator runs a small matrix: every form once on the pipeline of the bench, the bare RANK+ZRLT sequence through the fused chain and the fall-back; the MI355X suite runs all of it)
+    P.check_rank_pipe(be, monkeypatch, sizes=((30000, 1 << 14), (1000, 1024)), seeds=(5,), seqs=("BWT+RANK+ZRLT",))
+    P.check_rank_pipe(be, monkeypatch, sizes=((20000, 1 << 13),), seeds=(6,), seqs=("RANK+ZRLT",), forms=("pipe", "regular", "two_groups"))
 
 
 def test_rank_chain_variants(be, monkeypatch):

@@ -123,6 +123,24 @@ def escaping_names(n, out):
             escaping_names(v, out)
 
 
+def closures_naming(n, names, out):
+    """function literals inside n whose bodies name one of `names` (loop variables: Go >= 1.22 gives every iteration its own copy, a C++ reference
+    capture does not: refused rather than translated wrongly)"""
+    if isinstance(n, Node):
+        if n.kind == "FuncLit":
+            ids = set()
+            walk_idents(n.body, ids)
+            declared = {p.name for p in n.sig.params if p.name}
+            if (ids - declared) & names:
+                out.append(n)
+            return
+        for v in n.f.values():
+            closures_naming(v, names, out)
+    elif isinstance(n, (list, tuple)):
+        for v in n:
+            closures_naming(v, names, out)
+
+
 def has_defer(n):
     if isinstance(n, Node):
         if n.kind == "Defer":
@@ -763,7 +781,9 @@ class Translator:
                     ct = self.ctype(spec.typ)
                     out.append(f"{ct}& {mangle(nm)} = *go::New<{ct}>({ct}({v}));" if self.heap(nm) else f"{ct} {mangle(nm)} = {v};")
                 else:
-                    out.append(f"auto& {mangle(nm)} = *go::New(go::def({v}));" if self.heap(nm) else f"auto {mangle(nm)} = go::def({v});")
+                    t = self.tmpname()
+                    out.append(f"auto {t} = go::def({v});")           # (the initialiser may name an outer variable of the same name)
+                    out.append(f"auto& {mangle(nm)} = *go::New({t});" if self.heap(nm) else f"auto {mangle(nm)} = {t};")
             for nm in spec.names:
                 self.declare(nm)
             return "\n".join(out)
@@ -821,7 +841,13 @@ class Translator:
                 return f"(void)({exprs[0]});"
             if nm in self.scopes[-1]:
                 return f"{mangle(nm)} = {exprs[0]};"
+            used = set()
+            walk_idents(vals[0], used)
             self.declare(nm)
+            if nm in used:                                   # x := f(x) in a nested scope: the right side still means the OUTER x
+                t = self.tmpname()
+                pre = f"auto {t} = go::def({exprs[0]});\n"
+                return pre + (f"auto& {mangle(nm)} = *go::New({t});" if self.heap(nm) else f"auto {mangle(nm)} = {t};")
             if self.heap(nm):
                 return f"auto& {mangle(nm)} = *go::New(go::def({exprs[0]}));"
             return f"auto {mangle(nm)} = go::def({exprs[0]});"
@@ -914,6 +940,11 @@ class Translator:
         self.push()
         out = ["{"]
         if s.init is not None:
+            if s.init.kind == "Define":
+                bad = []
+                closures_naming(s.body, set(s.init.names), bad)
+                if bad:
+                    self.err(bad[0], "a closure captures a loop variable (per-iteration copies of Go >= 1.22 are not translated)")
             out.append(self.stmt(s.init))
         cond = self.ex(s.cond) if s.cond is not None else ""
         post = ""
@@ -936,12 +967,17 @@ class Translator:
 
     def st_RangeFor(self, s):
         label, self.loop_label = self.loop_label, None
+        if s.define:
+            bad = []
+            closures_naming(s.body, {x.name for x in (s.key, s.value) if x is not None and x.kind == "Ident"}, bad)
+            if bad:
+                self.err(bad[0], "a closure captures a loop variable (per-iteration copies of Go >= 1.22 are not translated)")
         self.push()
         r, n, i = self.tmpname("r"), self.tmpname("n"), self.tmpname("i")
-        out = ["{", f"auto&& {r}x = {self.ex(s.x)};", f"auto {r} = go::ranger({r}x);", f"int64_t {n} = {r}.n;"]
-        head = []
         key = s.key if (s.key is not None and not (s.key.kind == "Ident" and s.key.name == "_")) else None
         val = s.value if (s.value is not None and not (s.value.kind == "Ident" and s.value.name == "_")) else None
+        out = ["{", f"auto&& {r}x = {self.ex(s.x)};", f"auto {r} = go::{'ranger' if val is not None else 'ranger_keys'}({r}x);", f"int64_t {n} = {r}.n;"]
+        head = []
         self.push()
         if key is not None:
             if s.define:
@@ -1149,12 +1185,14 @@ class Translator:
         escaping_names(d.body, self.escaping)
 
     def func_def(self, d, owner=None):
-        THIS_IS_RECEIVER[0] = d.recv is not None and d.recv.name == "this"
+        by_value = d.recv is not None and d.recv.typ.kind != "PointerType"       # a value receiver works on a COPY of the object
+        THIS_IS_RECEIVER[0] = d.recv is not None and d.recv.name == "this" and not by_value
         self.begin_func(d)
         pre = ""
-        if d.recv is not None and d.recv.name and d.recv.name not in ("this", "_"):
+        if d.recv is not None and d.recv.name and d.recv.name != "_" and (by_value or d.recv.name != "this"):
             self.declare(d.recv.name)
-            pre = f"auto* {mangle(d.recv.name)} = this;\n"
+            nm = mangle(d.recv.name)
+            pre = f"auto {nm}_copy = *this;\nauto* {nm} = &{nm}_copy;\n" if by_value else f"auto* {nm} = this;\n"
         elif d.recv is not None and d.recv.name == "this":
             self.declare("this")
         heap_params = [p.name for p in d.sig.params if p.name and p.name != "_" and p.name in self.escaping and p.typ.kind not in ("SliceType", "PointerType")]

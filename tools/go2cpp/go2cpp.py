@@ -17,13 +17,17 @@ import emit  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--root", required=True)
+    ap.add_argument("--root", default=".")
+    ap.add_argument("--module", default="", help="module path (default: read from ROOT/go.mod)")
     ap.add_argument("--out", required=True)
     ap.add_argument("--cgo", action="store_true", help="the file set holds cgo files: include the cgo shim (tools/go2cpp/runtime/cgo_shim.hpp)")
     ap.add_argument("files", nargs="+")
     a = ap.parse_args()
-    with open(os.path.join(a.root, "go.mod")) as f:
-        module = re.search(r"^module\s+(\S+)", f.read(), re.M).group(1)
+    if a.module:
+        module = a.module
+    else:
+        with open(os.path.join(a.root, "go.mod")) as f:
+            module = re.search(r"^module\s+(\S+)", f.read(), re.M).group(1)
     tr = emit.Translator(module)
     for rel in a.files:
         if "=" in rel:                                   # PKGDIR=FILE: a file from somewhere else (the cgo shim, a patched copy) that belongs to package directory PKGDIR

@@ -434,14 +434,30 @@ template <class T> inline T assert1(const any& a) {
 }
 
 // maps are references to shared storage, as in Go (a nil map reads as empty and panics on assignment)
+template <class K, class V> struct Map;
+// m[k] as a value reads WITHOUT inserting (a missing key is the zero value), m[k] = v inserts: a proxy tells the two apart
+template <class K, class V> struct MapRef {
+    Map<K, V>* owner; K key;
+    operator V() const;
+    MapRef& operator=(const V& v);
+    MapRef& operator=(const MapRef& o) { return *this = (V)o; }
+    template <class X, class = std::enable_if_t<std::is_convertible_v<X, V> && !std::is_same_v<std::decay_t<X>, V> && !std::is_same_v<std::decay_t<X>, MapRef>>>
+    MapRef& operator=(X&& x) { return *this = V(std::forward<X>(x)); }
+    auto operator->() const { return (V) * this; }
+    friend bool operator==(const MapRef& r, nil_t) { return (V)r == nil; }
+    friend bool operator!=(const MapRef& r, nil_t) { return (V)r != nil; }
+};
 template <class K, class V> struct Map {
     std::shared_ptr<std::map<K, V>> m;
     Map() = default;
     Map(nil_t) {}
-    V& operator[](const K& k) { if (!m) panic_str("assignment to entry in nil map"); return (*m)[k]; }
+    MapRef<K, V> operator[](const K& k) { return MapRef<K, V>{this, k}; }
     friend bool operator==(const Map& a, nil_t) { return !a.m; }
     friend bool operator!=(const Map& a, nil_t) { return (bool)a.m; }
 };
+template <class K, class V> MapRef<K, V>::operator V() const { if (!owner->m) return V(); auto it = owner->m->find(key); return it == owner->m->end() ? V() : it->second; }
+template <class K, class V> MapRef<K, V>& MapRef<K, V>::operator=(const V& v) { if (!owner->m) panic_str("assignment to entry in nil map"); (*owner->m)[key] = v; return *this; }
+template <class K, class V> inline V def(MapRef<K, V> r) { return (V)r; }
 template <class K, class V> inline std::tuple<V, bool> map_get2(const Map<K, V>& m, const K& k) {
     if (!m.m) return {V(), false};
     auto it = m.m->find(k);
@@ -486,7 +502,7 @@ inline any recover() {
 // ---------------------------------------------------------------------------------------------------------------- for range
 template <class R> struct Ranger;
 template <class T> struct Ranger<Slice<T>> { const Slice<T>& s; int64_t n; Int key(int64_t i) const { return Int::from_raw(i); } T& val(int64_t i) const { return s.p[i]; } };
-template <class T, size_t N> struct Ranger<Array<T, N>> { const Array<T, N>& a; int64_t n; Int key(int64_t i) const { return Int::from_raw(i); } T val(int64_t i) const { return a.a[i]; } };
+template <class T, size_t N> struct Ranger<Array<T, N>> { Array<T, N> a; int64_t n; Int key(int64_t i) const { return Int::from_raw(i); } T val(int64_t i) const { return a.a[i]; } };   // (range over an array VALUE iterates a copy)
 template <class T, size_t N> struct Ranger<Array<T, N>*> { Array<T, N>* a; int64_t n; Int key(int64_t i) const { return Int::from_raw(i); } T& val(int64_t i) const { return a->a[i]; } };
 template <class K, class V> struct Ranger<Map<K, V>> {
     std::vector<std::pair<K, V>> items; int64_t n;
@@ -497,7 +513,7 @@ struct IntRanger { int64_t n; Int key(int64_t i) const { return Int::from_raw(i)
 struct StringRanger {          // (bytes; the translated files range over ASCII strings only)
     const String& s; int64_t n;
     Int key(int64_t i) const { return Int::from_raw(i); }
-    Rune val(int64_t i) const { return Rune::from_raw((int32_t)(unsigned char)s.s[(size_t)i]); }
+    Rune val(int64_t i) const { const unsigned char c = (unsigned char)s.s[(size_t)i]; if (c >= 0x80) panic_str("go2cpp: range over a non-ASCII string is not translated"); return Rune::from_raw((int32_t)c); }
 };
 template <class T> inline Ranger<Slice<T>> ranger(const Slice<T>& s) { return {s, s.n}; }
 template <class T, size_t N> inline Ranger<Array<T, N>> ranger(const Array<T, N>& a) { return {a, (int64_t)N}; }
@@ -508,9 +524,13 @@ template <class K, class V> inline Ranger<Map<K, V>> ranger(const Map<K, V>& m) 
     r.n = (int64_t)r.items.size();
     return r;
 }
+// `for i := range x` (no value variable): the range expression is only measured, never copied
+template <class X> inline auto ranger_keys(const X& x) { return ranger(x); }
+template <class T, size_t N> inline auto ranger_keys(const Array<T, N>&);
 inline IntRanger ranger(U u) { return {(int64_t)u.v}; }
 template <class T, class G> inline IntRanger ranger(I<T, G> i) { return {(int64_t)i.v}; }
 inline StringRanger ranger(const String& s) { return {s, (int64_t)s.s.size()}; }
+template <class T, size_t N> inline auto ranger_keys(const Array<T, N>&) { return IntRanger{(int64_t)N}; }
 
 }  // namespace go
 
