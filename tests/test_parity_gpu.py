@@ -412,3 +412,47 @@ def test_differential_fuzz(be):
 @pytest.mark.timeout(300)
 def test_corrupt_streams_come_back(be):
     P.check_corrupt_streams(be)
+
+
+def test_hardware_order_assumptions_under_load(be):
+    """The two places that lean on gfx950 ordering the HIP memory model does not promise (wave.h wave_order_lanes: the LZ parse's hole bits set by atomicOr and read
+    back by the same wave without a fence; prims.hip / bwt_sort.hip: LDS atomics of different lanes returning in program order) against forms that do not:
+    the segment-parallel LZ parse vs the one-wave parse (KNZ_LZ_CHAIN) and the device suffix sort vs the oracle's, repeated under uneven load from a second
+    stream (tools/gpu/lz_order_check.py is the 1000-iteration form of the first)."""
+    import os
+    import numpy as np
+    import bench_corpus
+    torch = be.torch
+    K = P.K
+    bs = 1 << 20
+    data = np.concatenate([bench_corpus._segment("exe", 5 * bs, 2), bench_corpus._segment("img16", bs, 3), bench_corpus._segment("records", 2 * bs, 4)])
+    n = len(data)
+    src = torch.from_numpy(data).to(be.dev)
+    dst = torch.zeros(n + n // 2, dtype=torch.uint8, device=be.dev)
+    os.environ["KNZ_LZ_CHAIN"] = "1"
+    try:
+        c = K.Codec("LZ", "NONE", bs, lib=be.lib)
+        nb = c.dev_compress(src.data_ptr(), n, dst.data_ptr(), dst.numel())
+        ref_lz = dst[:nb].clone()
+        c.close()
+    finally:
+        del os.environ["KNZ_LZ_CHAIN"]
+    ref_bwt = P.O.compress(data.tobytes(), "BWT", "NONE", bs)
+    noise = torch.cuda.Stream()
+    a = torch.empty(64 << 20, dtype=torch.uint8, device=be.dev)
+    b = torch.empty_like(a)
+    c_lz = K.Codec("LZ", "NONE", bs, lib=be.lib)
+    c_bwt = K.Codec("BWT", "NONE", bs, lib=be.lib)
+    for it in range(60):
+        if it % 3:                                       # uneven load: copies on another stream during two of three iterations
+            with torch.cuda.stream(noise):
+                for _ in range(1 + it % 5):
+                    b.copy_(a, non_blocking=True)
+        m = c_lz.dev_compress(src.data_ptr(), n, dst.data_ptr(), dst.numel())
+        assert m == nb and torch.equal(dst[:m], ref_lz), ("LZ parse", it)
+        if it % 4 == 0:
+            m = c_bwt.dev_compress(src.data_ptr(), n, dst.data_ptr(), dst.numel())
+            assert dst[:m].cpu().numpy().tobytes() == ref_bwt, ("suffix sort", it)
+    torch.cuda.synchronize()
+    c_lz.close()
+    c_bwt.close()
