@@ -240,3 +240,43 @@ func Values(n uint) (int, int, int, int, int, int, uint32, int) {
 	k := 1 << n             // an int: 2^40
 	return r1, r2, c.n + c.hist[0]*100 + c.hist[1], d.hist[1], a[0]*10 + a[3], len(b)*100 + b[2], m, k
 }
+
+type tape struct {
+	log  int
+	data []int
+}
+
+func (t *tape) next(v int) int { // leaves a trace of the order it was called in
+	t.log = t.log*10 + v
+	return v
+}
+
+func (t *tape) slot(v int) *int {
+	t.log = t.log*10 + v
+	return &t.data[v]
+}
+
+func three(a, b, c int) int { return a*100 + b*10 + c }
+
+// Go runs the calls inside one expression in lexical left-to-right order, whatever the operator or the position: operands of | and +, arguments,
+// several returned values, slice bounds, an index on the left of an assignment before the right side. C++ leaves most of these open.
+func CallOrder() (int, int, int, int, int, int, int) {
+	t := &tape{data: make([]int, 8)}
+	a := t.next(1)<<2 | t.next(2)<<1 | t.next(3) // 1,2,3
+	l1 := t.log
+	t.log = 0
+	b := three(t.next(4), t.next(5), t.next(6)) + t.next(7) // 4,5,6,7
+	l2 := t.log
+	t.log = 0
+	t.data[t.next(1)] = t.next(2) // index first, then the value: 1,2
+	*t.slot(3) += t.next(4)       // 3,4
+	s := t.data[t.next(0):t.next(5)]
+	l3 := t.log // 123405
+	t.log = 0
+	x, y := pairOf(t)
+	return a, l1, b, l2, l3*10 + len(s), x*10 + y, t.log
+}
+
+func pairOf(t *tape) (int, int) {
+	return t.next(8), t.next(9) // 8,9
+}

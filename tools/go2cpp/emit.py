@@ -12,6 +12,9 @@ TEST INFRASTRUCTURE (oracle/_ref). The emitter carries Go's semantics mechanical
     with labels become gotos, `go f(x)` runs f(x) in place (the one goroutine fan-out of BWT.go is serialised).
 Anything outside the subset raises: the translator never guesses.
 """
+import os
+import sys
+
 from goparse import Node
 
 
@@ -139,6 +142,28 @@ def closures_naming(n, names, out):
     elif isinstance(n, (list, tuple)):
         for v in n:
             closures_naming(v, names, out)
+
+
+PURE_BUILTINS = ("len", "cap", "min", "max", "new", "make")
+
+
+def has_call(tr, n):
+    """does evaluating expression n run a function or method call (conversions and the side-effect-free builtins do not count; a function literal's
+    body is not evaluated where it stands)"""
+    if isinstance(n, Node):
+        if n.kind == "FuncLit":
+            return False
+        if n.kind == "Call":
+            if tr.resolve_type_expr(n.fun) is not None:
+                return has_call(tr, n.args)
+            f = n.fun
+            if f.kind == "Ident" and not tr.is_local(f.name) and f.name not in tr.pk.funcs and f.name in PURE_BUILTINS:
+                return has_call(tr, n.args)
+            return True
+        return any(has_call(tr, v) for v in n.f.values())
+    if isinstance(n, (list, tuple)):
+        return any(has_call(tr, v) for v in n)
+    return False
 
 
 def has_defer(n):
@@ -410,11 +435,30 @@ class Translator:
         cop = {"-": "-", "+": "+", "!": "!", "^": "~"}[op]
         return f"({cop}({self.ex(x.x)}))"
 
+    def ordered(self, operands, strs, build, node=None):
+        """Go runs the calls among the operands of one expression in lexical left-to-right order; C++ leaves the order of the operands of most
+        operators and of the arguments of a call open. Where two or more operands run calls, each such operand is evaluated into a temporary, in
+        order, before the expression itself. operands: AST nodes (None = not an expression), strs: their C++ text, build: strs -> C++ text."""
+        calling = [i for i, o in enumerate(operands) if o is not None and has_call(self, o)]
+        if len(calling) < 2:
+            return build(strs)
+        if os.environ.get("GO2CPP_REPORT_ORDER") and node is not None and node.pos:
+            sys.stderr.write(f"ordered: {node.pos[0]}:{node.pos[1]} ({len(calling)} operands with calls)\n")
+        pre, out = [], list(strs)
+        for i in calling:
+            t = self.tmpname("o")
+            pre.append(f"auto {t} = {strs[i]};")
+            out[i] = t
+        cap = "&" if getattr(self, "in_func", False) else ""
+        return f"([{cap}]{{ {' '.join(pre)} return {build(out)}; }}())"
+
     def ex_Binary(self, x):
         a, b = self.ex(x.x), self.ex(x.y)
+        if x.op in ("&&", "||"):
+            return f"({a} {x.op} {b})"
         if x.op == "&^":
-            return f"andnot({a}, {b})"
-        return f"({a} {x.op} {b})"
+            return self.ordered([x.x, x.y], [a, b], lambda v: f"andnot({v[0]}, {v[1]})", x)
+        return self.ordered([x.x, x.y], [a, b], lambda v: f"({v[0]} {x.op} {v[1]})", x)
 
     def ex_Selector(self, x):
         if x.x.kind == "Ident" and not self.is_local(x.x.name) and x.x.name in self.imports:
@@ -437,8 +481,8 @@ class Translator:
         lo = self.ex(x.lo) if x.lo is not None else "go::none"
         hi = self.ex(x.hi) if x.hi is not None else "go::none"
         if x.three:
-            return f"go::slice3({self.ex(x.x)}, {lo}, {hi}, {self.ex(x.max)})"
-        return f"go::slice({self.ex(x.x)}, {lo}, {hi})"
+            return self.ordered([x.x, x.lo, x.hi, x.max], [self.ex(x.x), lo, hi, self.ex(x.max)], lambda v: f"go::slice3({', '.join(v)})", x)
+        return self.ordered([x.x, x.lo, x.hi], [self.ex(x.x), lo, hi], lambda v: f"go::slice({', '.join(v)})", x)
 
     def ex_TypeAssert(self, x):
         return f"go::assert1<{self.ctype(x.typ)}>({self.ex(x.x)})"
@@ -484,15 +528,19 @@ class Translator:
             b = self.builtin_call(x)
             if b is not None:
                 return b
-        args = [self.ex(a) for a in x.args]
         callee = self.find_callee(fun)
-        if callee is not None and callee.sig.params and callee.sig.params[-1].variadic and not x.spread:
-            nfix = len(callee.sig.params) - 1
-            et = self.ctype_in_pkg(callee)
-            rest = args[nfix:]
-            packed = f"go::Slice<{et}>::lit({{{', '.join(rest)}}})" if rest else f"go::Slice<{et}>()"
-            args = args[:nfix] + [packed]
-        return f"{self.ex(fun)}({', '.join(args)})"
+        fn = self.ex(fun)
+
+        def build(args):
+            if callee is not None and callee.sig.params and callee.sig.params[-1].variadic and not x.spread:
+                nfix = len(callee.sig.params) - 1
+                et = self.ctype_in_pkg(callee)
+                rest = args[nfix:]
+                packed = f"go::Slice<{et}>::lit({{{', '.join(rest)}}})" if rest else f"go::Slice<{et}>()"
+                args = args[:nfix] + [packed]
+            return f"{fn}({', '.join(args)})"
+        # (the function value / receiver expression is sequenced before the arguments by C++17; the arguments among themselves are not)
+        return self.ordered(list(x.args), [self.ex(a) for a in x.args], build, x)
 
     def ctype_in_pkg(self, callee):
         """element type of the variadic parameter of `callee` (types resolved in the callee's own package / imports)"""
@@ -513,9 +561,9 @@ class Translator:
         if n in ("len", "cap"):
             return f"go::{n}({self.ex(a[0])})"
         if n == "copy":
-            return f"go::copy({self.ex(a[0])}, {self.ex(a[1])})"
+            return self.ordered(a[:2], [self.ex(a[0]), self.ex(a[1])], lambda v: f"go::copy({v[0]}, {v[1]})", x)
         if n in ("min", "max"):
-            return f"go::{n}({', '.join(self.ex(v) for v in a)})"
+            return self.ordered(list(a), [self.ex(v) for v in a], lambda v: f"go::{n}({', '.join(v)})", x)
         if n == "clear":
             return f"go::clear({self.ex(a[0])})"
         if n == "panic":
@@ -524,14 +572,15 @@ class Translator:
             if x.spread:
                 if len(a) != 2:
                     self.err(x, "append with spread and several values")
-                return f"go::append_slice({self.ex(a[0])}, {self.ex(a[1])})"
-            return f"go::append({', '.join(self.ex(v) for v in a)})"
+                return self.ordered(a[:2], [self.ex(a[0]), self.ex(a[1])], lambda v: f"go::append_slice({v[0]}, {v[1]})", x)
+            return self.ordered(list(a), [self.ex(v) for v in a], lambda v: f"go::append({', '.join(v)})", x)
         if n == "make":
             t = self.resolve_type_expr(a[0])
             if t is None:
                 self.err(x, "make of a non-type")
             if t.kind == "SliceType":
-                return f"go::make_slice<{self.ctype(t.elem)}>({', '.join(self.ex(v) for v in a[1:])})"
+                et = self.ctype(t.elem)
+                return self.ordered(list(a[1:]), [self.ex(v) for v in a[1:]], lambda v: f"go::make_slice<{et}>({', '.join(v)})", x)
             if t.kind == "MapType":
                 return f"go::make_map<{self.ctype(t.key)}, {self.ctype(t.elem)}>()"
             self.err(x, "make of this type is not supported")
@@ -541,7 +590,7 @@ class Translator:
         if n == "recover":
             return "go::recover()"
         if n == "delete":
-            return f"go::map_delete({self.ex(a[0])}, {self.ex(a[1])})"
+            return self.ordered(a[:2], [self.ex(a[0]), self.ex(a[1])], lambda v: f"go::map_delete({v[0]}, {v[1]})", x)
         if n in ("print", "println", "complex", "real", "imag", "close"):
             self.err(x, f"builtin {n} is not supported")
         return None
@@ -734,7 +783,8 @@ class Translator:
             return f"return {self.ex(s.values[0])};"          # return f() with the same result list
         if len(s.values) != len(rs):
             self.err(s, "return arity")
-        return f"return {self.result_tuple()}({', '.join(self.ex(v) for v in s.values)});"
+        rt = self.result_tuple()
+        return "return " + self.ordered(list(s.values), [self.ex(v) for v in s.values], lambda v: f"{rt}({', '.join(v)})", s) + ";"
 
     def result_tuple(self):
         return "std::tuple<" + ", ".join(self.ctype(r.typ) for r in self.cur_results) + ">"
@@ -884,12 +934,20 @@ class Translator:
             if len(s.lhs) != 1 or len(s.rhs) != 1:
                 self.err(s, "compound assignment arity")
             l, r = self.ex(s.lhs[0]), self.ex(s.rhs[0])
+            if has_call(self, s.lhs[0]) and has_call(self, s.rhs[0]):
+                # Go: the index operands on the left first, then the right side; C++17: the right side of an assignment first
+                tl, trr = self.tmpname("o"), self.tmpname("o")
+                body = f"{tl} = andnot({tl}, {trr});" if op == "&^=" else f"{tl} {op} {trr};"
+                return f"{{ auto&& {tl} = {l}; auto {trr} = {r}; {body} }}"
             if op == "&^=":
                 return f"{l} = andnot({l}, {r});"
             return f"{l} {op} {r};"
         if len(s.lhs) == 1 and len(s.rhs) == 1:
             l = self.lhs(s.lhs[0])
             r = self.ex(s.rhs[0])
+            if l is not None and has_call(self, s.lhs[0]) and has_call(self, s.rhs[0]):
+                tl, trr = self.tmpname("o"), self.tmpname("o")
+                return f"{{ auto&& {tl} = {l}; auto {trr} = {r}; {tl} = {trr}; }}"
             return f"(void)({r});" if l is None else f"{l} = {r};"
         if len(s.rhs) == 1:
             t = self.tmpname()
@@ -1169,6 +1227,7 @@ class Translator:
         return "\n".join(lines)
 
     def begin_func(self, d):
+        self.in_func = True
         self.scopes = [set()]
         self.cur_results = d.sig.results
         self.named_results = [r.name for r in d.sig.results] if d.sig.results and d.sig.results[0].name else None
@@ -1284,6 +1343,7 @@ class Translator:
         for nm in items:
             visit(nm)
         consts_out, vars_out = [], []
+        self.in_func = False
         for nm in ordered:
             kind, spec, i = items[nm]
             if nm == "_":
