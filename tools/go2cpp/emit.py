@@ -47,10 +47,11 @@ STD_INTERFACES = {
     ("io", "ReadWriteCloser"): {"Read": RW_SIG, "Write": RW_SIG, "Close": ((), ("go::error",))},
     ("go", "error_iface"): {"Error": ((), ("go::String",))},
 }
-STD_VALUE_TYPES = {("sync", "WaitGroup"): "::go_sync::WaitGroup", ("sync", "Mutex"): "::go_sync::Mutex", ("bytes", "Buffer"): "::go_bytes::Buffer", ("time", "Time"): "::go_time::Time", ("unsafe", "Pointer"): "::go_unsafe::Pointer", ("runtime", "Pinner"): "::go_runtime::Pinner"}
+STD_VALUE_TYPES = {("sync", "WaitGroup"): "::go_sync::WaitGroup", ("sync", "Mutex"): "::go_sync::Mutex", ("bytes", "Buffer"): "::go_bytes::Buffer", ("time", "Time"): "::go_time::Time", ("unsafe", "Pointer"): "::go_unsafe::Pointer", ("runtime", "Pinner"): "::go_runtime::Pinner",
+                   ("testing", "T"): "::go_testing::T", ("testing", "B"): "::go_testing::T", ("rand", "Rand"): "::go_rand::Rand", ("bytes", "Reader"): "::go_bytes::Reader", ("os", "File"): "::go_os::File"}
 # cgo: the C types the shim files name (include/knz_gpu.h and <stdint.h> through tools/go2cpp/runtime/cgo_shim.hpp)
 CGO_TYPES = {"uint8_t", "uint16_t", "uint32_t", "uint64_t", "int8_t", "int16_t", "int32_t", "int64_t", "int", "uint", "size_t", "char", "float", "knz_cfg", "knz_block"}
-STD_PACKAGES = {"errors", "fmt", "encoding/binary", "math/bits", "sort", "slices", "io", "sync", "strings", "bytes", "sync/atomic", "time", "runtime", "C", "unsafe"}
+STD_PACKAGES = {"errors", "fmt", "encoding/binary", "math/bits", "sort", "slices", "io", "sync", "strings", "bytes", "sync/atomic", "time", "runtime", "C", "unsafe", "testing", "math/rand", "os"}
 
 
 THIS_IS_RECEIVER = [False]     # Go's conventional receiver name `this` is C++'s `this` inside methods; elsewhere it is an ordinary local
@@ -197,6 +198,9 @@ class Translator:
         self.pkgs = {}                      # import path -> Package
         self.order = []
         self.tmp = 0
+        self.ltypes = [{}]
+        self.hoisted = []
+        self.hoisted_names = {}
         self.iface_sigs = {}                # C++ interface type -> {method: (params, results)}
         for (p, n), sig in STD_INTERFACES.items():
             self.iface_sigs[("::go_%s::%s" % (p, n)) if p != "go" else "::go::error_iface"] = sig
@@ -263,9 +267,35 @@ class Translator:
     # ------------------------------------------------------------------------------------------------ scopes
     def push(self):
         self.scopes.append(set())
+        self.ltypes.append({})
 
     def pop(self):
         self.scopes.pop()
+        self.ltypes.pop()
+
+    def local_type(self, name):
+        """(hoisted C++ name, type node) of a type declared inside the current function, innermost scope first"""
+        for sc in reversed(getattr(self, "ltypes", [])):
+            if name in sc:
+                return sc[name]
+        return None
+
+    def hoist_struct(self, t, stem):
+        """a struct type that has no package-level name (a local `type X struct`, an anonymous `struct{...}`): defined at namespace scope just before the
+        function that uses it"""
+        key = id(t)
+        if key in self.hoisted_names:
+            return self.hoisted_names[key]
+        self.tmp += 1
+        cn = f"{stem}_{self.tmp}"
+        self.hoisted_names[key] = cn
+        lines = [f"struct {cn} {{", f"  {cn}* operator->() {{ return this; }}", f"  const {cn}* operator->() const {{ return this; }}"]
+        for f in t.fields:
+            if f.name != "_":
+                lines.append(f"  {self.ctype(f.typ)} {mangle(f.name)}{{}};")
+        lines.append("};")
+        self.hoisted.append("\n".join(lines))
+        return cn
 
     def declare(self, name):
         self.scopes[-1].add(name)
@@ -283,8 +313,13 @@ class Translator:
 
     def ctype(self, t):
         k = t.kind
+        if k == "StructType":
+            return self.hoist_struct(t, "Anon")
         if k == "NamedType":
             if t.pkg is None:
+                lt = self.local_type(t.name)
+                if lt is not None:
+                    return lt[0]
                 if t.name in self.pk.types and not self.is_local_type_shadow(t.name):
                     return self.named_ctype(self.pk, t.name)
                 if t.name in BUILTIN_TYPES:
@@ -360,6 +395,8 @@ class Translator:
         if x.kind == "Paren":
             return self.resolve_type_expr(x.x)
         if x.kind == "Ident":
+            if self.local_type(x.name) is not None and not self.is_local(x.name):
+                return Node("NamedType", x.pos, pkg=None, name=x.name)
             if self.is_local(x.name):
                 return None
             if x.name in self.pk.types or (x.name in BUILTIN_TYPES and x.name not in self.pk.funcs):
@@ -591,7 +628,9 @@ class Translator:
             return "go::recover()"
         if n == "delete":
             return self.ordered(a[:2], [self.ex(a[0]), self.ex(a[1])], lambda v: f"go::map_delete({v[0]}, {v[1]})", x)
-        if n in ("print", "println", "complex", "real", "imag", "close"):
+        if n == "println":
+            return f"go_fmt::Println({', '.join(self.ex(v) for v in a)})"
+        if n in ("print", "complex", "real", "imag", "close"):
             self.err(x, f"builtin {n} is not supported")
         return None
 
@@ -629,23 +668,29 @@ class Translator:
             if not x.elems:
                 return f"go::Array<{et}, {n}>{{}}"
             return f"go::Array<{et}, {n}>{{{{{', '.join(self.typed_elem(e.value, t.elem, et) for e in x.elems)}}}}}"
-        if k == "NamedType":
-            pk = self.pk if t.pkg is None else self.pkg_of_alias(t.pkg)[1]
-            if isinstance(pk, str):
-                if not x.elems:
-                    return f"{self.ctype(t)}{{}}"
-                self.err(x, "composite literal of a standard type")
-            ts = pk.types.get(t.name)
-            if ts is None or ts.typ.kind != "StructType":
-                if ts is not None and ts.typ.kind in ("SliceType", "ArrayType"):
-                    return self.composite(x, ts.typ)
-                self.err(x, f"composite literal of non-struct {t.name}")
+        if k == "NamedType" or k == "StructType":
+            lt = self.local_type(t.name) if (k == "NamedType" and t.pkg is None) else None
+            if k == "StructType":
+                fields = t.fields
+            elif lt is not None:
+                fields = lt[1].fields
+            else:
+                pk = self.pk if t.pkg is None else self.pkg_of_alias(t.pkg)[1]
+                if isinstance(pk, str):
+                    if not x.elems:
+                        return f"{self.ctype(t)}{{}}"
+                    self.err(x, "composite literal of a standard type")
+                ts = pk.types.get(t.name)
+                if ts is None or ts.typ.kind != "StructType":
+                    if ts is not None and ts.typ.kind in ("SliceType", "ArrayType"):
+                        return self.composite(x, ts.typ)
+                    self.err(x, f"composite literal of non-struct {t.name}")
+                fields = ts.typ.fields
             ct = self.ctype(t)
             if not x.elems:
                 return f"{ct}{{}}"
             v = self.tmpname("v")
             parts = []
-            fields = ts.typ.fields
             saved = (self.pk, self.imports)
             for i, e in enumerate(x.elems):
                 if e.key is not None:
@@ -658,9 +703,19 @@ class Translator:
                 parts.append(f"{v}.{mangle(fname)} = {self.elem_value(e.value, ftyp)};")
             return f"[&]{{ {ct} {v}{{}}; {' '.join(parts)} return {v}; }}()"
         if k == "MapType":
-            if x.elems:
-                self.err(x, "non-empty map literal")
-            return f"go::make_map<{self.ctype(t.key)}, {self.ctype(t.elem)}>()"
+            mk = f"go::make_map<{self.ctype(t.key)}, {self.ctype(t.elem)}>()"
+            if not x.elems:
+                return mk
+            v = self.tmpname("m")
+            to_any = t.elem.kind == "InterfaceType"
+            parts = []
+            for e in x.elems:
+                if e.key is None:
+                    self.err(x, "map literal element without a key")
+                val = self.elem_value(e.value, t.elem)
+                parts.append(f"{v}[{self.elem_value(e.key, t.key)}] = {('go::def(' + val + ')') if to_any else val};")
+            cap = "&" if getattr(self, "in_func", False) else ""
+            return f"[{cap}]{{ auto {v} = {mk}; {' '.join(parts)} return {v}; }}()"
         self.err(x, f"composite literal of {k}")
 
     def typed_elem(self, v, elem_type, et):
@@ -806,8 +861,10 @@ class Translator:
                         out.append(f"constexpr auto {mangle(nm)} = {val};")
                     self.declare(nm)
                 self.iota = None
+            elif spec.kind == "TypeSpec" and spec.typ.kind == "StructType":
+                self.ltypes[-1][spec.name] = (self.hoist_struct(spec.typ, "L_" + mangle(spec.name)), spec.typ)
             else:
-                self.err(s, "local type declarations are not supported")
+                self.err(s, "local type declarations other than structs are not supported")
         return "\n".join(out)
 
     def local_var(self, spec):
@@ -1025,11 +1082,15 @@ class Translator:
 
     def st_RangeFor(self, s):
         label, self.loop_label = self.loop_label, None
+        captured = set()
         if s.define:
-            bad = []
-            closures_naming(s.body, {x.name for x in (s.key, s.value) if x is not None and x.kind == "Ident"}, bad)
-            if bad:
-                self.err(bad[0], "a closure captures a loop variable (per-iteration copies of Go >= 1.22 are not translated)")
+            # Go >= 1.22: every iteration has its own copy of the range variables. They are declared inside the loop body here, so that already holds;
+            # one that a closure names gets heap (arena) storage per iteration, so that a closure that outlives the iteration keeps ITS copy.
+            for nm in {x.name for x in (s.key, s.value) if x is not None and x.kind == "Ident"}:
+                bad = []
+                closures_naming(s.body, {nm}, bad)
+                if bad:
+                    captured.add(nm)
         self.push()
         r, n, i = self.tmpname("r"), self.tmpname("n"), self.tmpname("i")
         key = s.key if (s.key is not None and not (s.key.kind == "Ident" and s.key.name == "_")) else None
@@ -1040,13 +1101,13 @@ class Translator:
         if key is not None:
             if s.define:
                 self.declare(key.name)
-                head.append(f"auto {mangle(key.name)} = {r}.key({i});")
+                head.append(f"auto& {mangle(key.name)} = *go::New({r}.key({i}));" if key.name in captured else f"auto {mangle(key.name)} = {r}.key({i});")
             else:
                 head.append(f"{self.ex(key)} = {r}.key({i});")
         if val is not None:
             if s.define:
                 self.declare(val.name)
-                head.append(f"auto {mangle(val.name)} = {r}.val({i});")
+                head.append(f"auto& {mangle(val.name)} = *go::New({r}.val({i}));" if val.name in captured else f"auto {mangle(val.name)} = {r}.val({i});")
             else:
                 head.append(f"{self.ex(val)} = {r}.val({i});")
         saved_fall = self.fall_var
@@ -1229,6 +1290,8 @@ class Translator:
     def begin_func(self, d):
         self.in_func = True
         self.scopes = [set()]
+        self.ltypes = [{}]
+        self.ltypes = [{}]
         self.cur_results = d.sig.results
         self.named_results = [r.name for r in d.sig.results] if d.sig.results and d.sig.results[0].name else None
         self.iota = None
@@ -1262,10 +1325,12 @@ class Translator:
         if pre:
             body = "{\n" + pre + body[2:]
         name = mangle(d.name) if owner is None else f"{mangle(owner)}::{mangle(d.name)}"
-        return f"{self.result_ctype(d.sig)} {name}({self.params_decl(d.sig)}) {body}\n"
+        hoisted, self.hoisted = "".join(h + "\n" for h in self.hoisted), []
+        return f"{hoisted}{self.result_ctype(d.sig)} {name}({self.params_decl(d.sig)}) {body}\n"
 
     def func_proto(self, d, in_class=False):
         self.scopes = [set()]
+        self.ltypes = [{}]
         self.iota = None
         self.heap_params = set()
         return f"{self.result_ctype(d.sig)} {mangle(d.name)}({self.params_decl(d.sig)});"
@@ -1288,6 +1353,7 @@ class Translator:
             if u.kind == "NamedType" and u.pkg is None and not t.alias and u.name in pk.types and pk.types[u.name].typ.kind == "StructType":
                 t.f["typ"] = pk.types[u.name].typ
         self.scopes = [set()]
+        self.ltypes = [{}]
         self.iota = None
         self.cur_results, self.named_results = [], None
         self.loop_label, self.fall_var, self.used_continue_labels = None, None, set()
@@ -1468,6 +1534,13 @@ class Translator:
                     out.append(self.func_def(d))
         for i, d in enumerate(pk.inits):
             out.append(f"static const int init_done_{i} = (init_{i}(), 0);")
+        # the package's own tests (files named *_test.go): registered by name for go_testing::run
+        for f in pk.files:
+            if not str(f.pos[0]).endswith("_test.go"):
+                continue
+            for d in f.decls:
+                if d.kind == "FuncDecl" and d.recv is None and d.body is not None and d.name.startswith("Test") and len(d.sig.params) == 1:
+                    out.append(f'static const ::go_testing::Register reg_{mangle(d.name)}("{pk.name}", "{d.name}", &{mangle(d.name)});')
         out.append(f"}}  // namespace {pk.ns}")
         return "\n".join(out)
 

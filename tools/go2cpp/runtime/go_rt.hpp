@@ -29,7 +29,8 @@ namespace go {
 // lands in the `case error:` arm of the reference's recover blocks); otherwise it is a string.
 struct PanicException : std::runtime_error {
     bool is_error;
-    explicit PanicException(const std::string& m, bool is_err = true) : std::runtime_error(m), is_error(is_err) {}
+    void* err_obj = nullptr;       // panic(err): the error value itself (recover() hands the same value back, so that errors.Is(err, io.EOF) holds)
+    explicit PanicException(const std::string& m, bool is_err = true, void* obj = nullptr) : std::runtime_error(m), is_error(is_err), err_obj(obj) {}
 };
 [[noreturn]] inline void panic_str(const std::string& m) { throw PanicException(m, true); }
 
@@ -226,7 +227,11 @@ template <class T> struct Slice {
     template <class K> T& operator[](K k) const { int64_t i = idx64(k); if ((uint64_t)i >= (uint64_t)n) oob(i, n); return p[i]; }
     static Slice make(int64_t n, int64_t c) {
         if (n < 0 || c < n) panic_str("makeslice: len out of range");
-        return Slice((T*)alloc_zero((size_t)c * sizeof(T)), n, c);
+        T* q = (T*)alloc_zero((size_t)c * sizeof(T));
+        // all-zero bytes ARE the zero value of integers, pointers, slices and of structs made of them; anything else (a string, a std::function, an
+        // object with a vtable) is constructed in place, over the whole capacity (s[:cap(s)] may be read)
+        if constexpr (!std::is_trivially_copyable_v<T>) for (int64_t i = 0; i < c; i++) new (q + i) T();
+        return Slice(q, n, c);
     }
     static Slice lit(std::initializer_list<T> l) {
         Slice s = make((int64_t)l.size(), (int64_t)l.size());
@@ -300,7 +305,9 @@ template <class L, class H> inline String slice(const String& s, L lo, H hi) {
 // copy
 template <class T> inline Int copy(const Slice<T>& d, const Slice<T>& s) {
     int64_t n = std::min(d.n, s.n);
-    if (n > 0) std::memmove((void*)d.p, (const void*)s.p, (size_t)n * sizeof(T));
+    if constexpr (std::is_trivially_copyable_v<T>) { if (n > 0) std::memmove((void*)d.p, (const void*)s.p, (size_t)n * sizeof(T)); }
+    else if (d.p <= s.p) { for (int64_t i = 0; i < n; i++) d.p[i] = s.p[i]; }
+    else { for (int64_t i = n - 1; i >= 0; i--) d.p[i] = s.p[i]; }
     return Int::from_raw(n);
 }
 inline Int copy(const Slice<Byte>& d, const String& s) {
@@ -331,7 +338,8 @@ template <class T, class... A> inline Slice<T> append(const Slice<T>& s, const A
 }
 template <class T> inline Slice<T> append_slice(const Slice<T>& s, const Slice<T>& t) {
     Slice<T> r = grow(s, s.n + t.n);
-    if (t.n > 0) std::memmove((void*)(r.p + r.n), (const void*)t.p, (size_t)t.n * sizeof(T));
+    if constexpr (std::is_trivially_copyable_v<T>) { if (t.n > 0) std::memmove((void*)(r.p + r.n), (const void*)t.p, (size_t)t.n * sizeof(T)); }
+    else { for (int64_t i = 0; i < t.n; i++) r.p[r.n + i] = t.p[i]; }
     r.n += t.n;
     return r;
 }
@@ -389,7 +397,7 @@ using error = error_iface*;
 struct errorString : error_iface { String msg; explicit errorString(String m) : msg(std::move(m)) {} String Error() override { return msg; } };
 
 template <class T> [[noreturn]] inline void panic(const T& v) {
-    if constexpr (std::is_convertible_v<T, error>) { error e = v; throw PanicException(e ? e->Error().s : std::string("nil error"), true); }
+    if constexpr (std::is_convertible_v<T, error>) { error e = v; throw PanicException(e ? e->Error().s : std::string("nil error"), true, (void*)e); }
     else if constexpr (std::is_same_v<T, String>) throw PanicException(v.s, false);
     else throw PanicException("panic", false);
 }
@@ -432,6 +440,16 @@ template <class T> inline T assert1(const any& a) {
     }
     panic_str(std::string("interface conversion: interface {} is ") + (a.ti ? a.ti->name() : "nil") + ", not " + typeid(T).name());
 }
+// x.(T) where x is a non-empty interface (a pointer to a polymorphic class here) and T a pointer type: a dynamic cast
+template <class T, class I, class = std::enable_if_t<std::is_polymorphic_v<I> && std::is_pointer_v<T>>> inline T assert1(I* p) {
+    T q = p ? dynamic_cast<T>(p) : nullptr;
+    if (!q) panic_str(std::string("interface conversion: interface is ") + (p ? typeid(*p).name() : "nil") + ", not " + typeid(T).name());
+    return q;
+}
+template <class T, class I, class = std::enable_if_t<std::is_polymorphic_v<I> && std::is_pointer_v<T>>> inline std::tuple<T, bool> assert2(I* p) {
+    T q = p ? dynamic_cast<T>(p) : nullptr;
+    return {q, q != nullptr};
+}
 
 // maps are references to shared storage, as in Go (a nil map reads as empty and panics on assignment)
 template <class K, class V> struct Map;
@@ -472,10 +490,11 @@ template <class K, class V> inline void map_delete(Map<K, V>& m, const K& k) { i
 struct DeferFrame {
     std::vector<std::function<void()>> fns;
     bool panicking = false, recovered = false, is_error = true;
+    void* err_obj = nullptr;
     std::string msg;
     DeferFrame* prev = nullptr;
     template <class F> void push(F&& f) { fns.emplace_back(std::forward<F>(f)); }
-    void set_panic(const PanicException& e) { panicking = true; recovered = false; msg = e.what(); is_error = e.is_error; }
+    void set_panic(const PanicException& e) { panicking = true; recovered = false; msg = e.what(); is_error = e.is_error; err_obj = e.err_obj; }
     void run();
 };
 inline thread_local DeferFrame* g_running_defers = nullptr;
@@ -488,13 +507,14 @@ inline void DeferFrame::run() {
         try { f(); } catch (const PanicException& e) { set_panic(e); }        // a panic inside a deferred call replaces the current one
     }
     g_running_defers = prev;
-    if (panicking && !recovered) throw PanicException(msg, is_error);
+    if (panicking && !recovered) throw PanicException(msg, is_error, err_obj);
 }
 // recover(): the value of the panic that is unwinding through the function whose deferred call this is, or nil
 inline any recover() {
     DeferFrame* f = g_running_defers;
     if (f == nullptr || !f->panicking || f->recovered) return any();
     f->recovered = true;
+    if (f->is_error && f->err_obj) return any((error)f->err_obj);
     if (f->is_error) return any((error)New<errorString>(errorString(String(f->msg))));
     return any(String(f->msg));
 }
@@ -537,6 +557,7 @@ template <class T, size_t N> inline auto ranger_keys(const Array<T, N>&) { retur
 // ---------------------------------------------------------------------------------------------------------------- std packages
 namespace go_errors {
 inline go::error New(const go::String& s) { return go::New<go::errorString>(go::errorString(s)); }
+inline bool Is(go::error err, go::error target) { return err == target; }     // (no translated error type wraps another)
 }
 
 namespace go_fmt {
@@ -634,7 +655,69 @@ struct WriteCloser : virtual Writer, virtual Closer {};
 struct ReadWriteCloser : virtual ReadCloser, virtual WriteCloser {};
 inline go::errorString EOF_value{go::String("EOF")};
 inline go::error EOF_ = &EOF_value;
+struct nopCloser : virtual ReadCloser {
+    Reader* r;
+    explicit nopCloser(Reader* r_) : r(r_) {}
+    std::tuple<go::Int, go::error> Read(go::Slice<go::Byte> b) override { return r->Read(b); }
+    go::error Close() override { return nullptr; }
+};
+inline ReadCloser* NopCloser(Reader* r) { return go::New<nopCloser>(nopCloser(r)); }
 }  // namespace go_io
+namespace go_fmt {
+template <class... A> inline std::tuple<go::Int, go::error> Fprintf(go_io::Writer* w, const go::String& f, const A&... a) {
+    go::String s = Sprintf(f, a...);
+    go::Slice<go::Byte> b = go::Slice<go::Byte>::make((int64_t)s.s.size(), (int64_t)s.s.size());
+    if (!s.s.empty()) std::memcpy((void*)b.p, s.s.data(), s.s.size());
+    return w->Write(b);
+}
+}  // namespace go_fmt
+namespace go_os {
+// os.Stdout / os.Stderr as io.Writers (the debug bit streams print through them): both go to stderr here, stdout belongs to the caller
+struct File : virtual go_io::ReadWriteCloser {
+    File* operator->() { return this; }
+    FILE* f = nullptr;               // nullptr: the process's stderr
+    std::string path;
+    std::tuple<go::Int, go::error> Write(go::Slice<go::Byte> b) override {
+        size_t n = b.n ? std::fwrite((const void*)b.p, 1, (size_t)b.n, f ? f : stderr) : 0;
+        if ((int64_t)n != b.n) return {go::Int::from_raw((int64_t)n), go_errors::New(go::String("write " + path + ": short write"))};
+        return {go::Int::from_raw(b.n), nullptr};
+    }
+    std::tuple<go::Int, go::error> Read(go::Slice<go::Byte> b) override {
+        if (!f) return {go::Int(), go_errors::New(go::String("read: file is not open"))};
+        size_t n = b.n ? std::fread((void*)b.p, 1, (size_t)b.n, f) : 0;
+        if (n == 0 && b.n > 0) return {go::Int(), go_io::EOF_};
+        return {go::Int::from_raw((int64_t)n), nullptr};
+    }
+    go::error Close() override { if (f) { std::fclose(f); f = nullptr; } return nullptr; }
+    go::String Name() { return go::String(path); }
+};
+inline File stdout_file, stderr_file;
+inline File* Stdout = &stdout_file;
+inline File* Stderr = &stderr_file;
+// os.CreateTemp(dir, pattern): a new file whose name replaces the last * of pattern by a random string
+inline std::tuple<File*, go::error> CreateTemp(const go::String& dir, const go::String& pattern) {
+    std::string d = dir.s.empty() ? std::string(std::getenv("TMPDIR") ? std::getenv("TMPDIR") : "/tmp") : dir.s;
+    std::string pre = pattern.s, suf;
+    size_t star = pattern.s.rfind('*');
+    if (star != std::string::npos) { pre = pattern.s.substr(0, star); suf = pattern.s.substr(star + 1); }
+    std::string tmpl = d + "/" + pre + "XXXXXX" + suf;
+    std::vector<char> buf(tmpl.begin(), tmpl.end()); buf.push_back(0);
+    int fd = mkstemps(buf.data(), (int)suf.size());
+    if (fd < 0) return {nullptr, go_errors::New(go::String("CreateTemp: cannot create " + tmpl))};
+    File* r = go::New<File>();
+    r->f = fdopen(fd, "w+b");
+    r->path = buf.data();
+    return {r, nullptr};
+}
+inline std::tuple<File*, go::error> Open(const go::String& name) {
+    FILE* f = std::fopen(name.s.c_str(), "rb");
+    if (!f) return {nullptr, go_errors::New(go::String("open " + name.s + ": no such file or directory"))};
+    File* r = go::New<File>();
+    r->f = f; r->path = name.s;
+    return {r, nullptr};
+}
+inline go::error Remove(const go::String& name) { return std::remove(name.s.c_str()) == 0 ? nullptr : go_errors::New(go::String("remove " + name.s + ": failed")); }
+}  // namespace go_os
 namespace go_sync {
 // goroutines of the translated files run one after the other (`go f(x)` is emitted as the call): a WaitGroup has nothing to wait for
 struct WaitGroup {
@@ -666,17 +749,24 @@ inline go::Slice<go::String> Split(const go::String& s, const go::String& sep) {
     for (size_t i = 0; i < parts.size(); i++) new (mem + i) go::String(parts[i]);
     return go::Slice<go::String>(mem, (int64_t)parts.size(), (int64_t)parts.size());
 }
+inline go::String Repeat(const go::String& s, go::Int count) {
+    if (count.v < 0) go::panic_str("strings: negative Repeat count");
+    std::string r; r.reserve(s.s.size() * (size_t)count.v);
+    for (int64_t i = 0; i < count.v; i++) r += s.s;
+    return go::String(r);
+}
 }  // namespace go_strings
 
 namespace go_bytes {
 // bytes.Buffer as internal.BufferStream uses it. NewBuffer(b) takes OWNERSHIP of b's backing array: writes append in place while they fit into
 // cap(b) (the block task of io/CompressedStream.go relies on that: it reads the encoded bits back through its own slice of the same array),
 // then the buffer moves to a larger array; reads consume from the front.
-struct Buffer {
+struct Buffer : virtual go_io::Writer, virtual go_io::Reader {
     Buffer* operator->() { return this; }
     go::Slice<go::Byte> buf;
     int64_t off = 0;
-    std::tuple<go::Int, go::error> Write(go::Slice<go::Byte> b) {
+    go::String String() { return go::String(std::string((const char*)buf.p + off, (size_t)(buf.n - off))); }
+    std::tuple<go::Int, go::error> Write(go::Slice<go::Byte> b) override {
         if (buf.n + b.n > buf.c) {
             int64_t nc = std::max<int64_t>(2 * buf.c + b.n, 64);
             go::Slice<go::Byte> nb = go::Slice<go::Byte>::make(buf.n, nc);
@@ -687,7 +777,7 @@ struct Buffer {
         buf.n += b.n;
         return {go::Int::from_raw(b.n), nullptr};
     }
-    std::tuple<go::Int, go::error> Read(go::Slice<go::Byte> b) {
+    std::tuple<go::Int, go::error> Read(go::Slice<go::Byte> b) override {
         int64_t n = std::min<int64_t>(b.n, buf.n - off);
         if (n == 0 && b.n > 0) return {go::Int(), go_io::EOF_};
         if (n) std::memmove((void*)b.p, (const void*)(buf.p + off), (size_t)n);
@@ -697,7 +787,28 @@ struct Buffer {
     go::Int Len() { return go::Int::from_raw(buf.n - off); }
     go::Int Available() { return go::Int::from_raw(buf.c - buf.n); }
 };
+struct Reader : virtual go_io::Reader {
+    Reader* operator->() { return this; }
+    go::Slice<go::Byte> b;
+    int64_t off = 0;
+    std::tuple<go::Int, go::error> Read(go::Slice<go::Byte> d) override {
+        if (off >= b.n) return {go::Int(), go_io::EOF_};
+        int64_t n = std::min<int64_t>(d.n, b.n - off);
+        if (n) std::memmove((void*)d.p, (const void*)(b.p + off), (size_t)n);
+        off += n;
+        return {go::Int::from_raw(n), nullptr};
+    }
+    go::Int Len() { return go::Int::from_raw(b.n - off); }
+};
+inline Reader* NewReader(go::Slice<go::Byte> b) { Reader* r = go::New<Reader>(); r->b = b; return r; }
 inline Buffer* NewBuffer(go::Slice<go::Byte> b) { Buffer* r = go::New<Buffer>(); r->buf = b; return r; }
+inline bool Equal(go::Slice<go::Byte> a, go::Slice<go::Byte> b) { return a.n == b.n && (a.n == 0 || std::memcmp((const void*)a.p, (const void*)b.p, (size_t)a.n) == 0); }
+inline go::Slice<go::Byte> Repeat(go::Slice<go::Byte> b, go::Int count) {
+    if (count.v < 0) go::panic_str("bytes: negative Repeat count");
+    go::Slice<go::Byte> r = go::Slice<go::Byte>::make(b.n * count.v, b.n * count.v);
+    for (int64_t i = 0; i < count.v; i++) if (b.n) std::memcpy((void*)(r.p + i * b.n), (const void*)b.p, (size_t)b.n);
+    return r;
+}
 }  // namespace go_bytes
 
 namespace go_atomic {
@@ -738,3 +849,75 @@ struct Pinner { Pinner* operator->() { return this; } template <class T> void Pi
 template <class T, class F> inline void SetFinalizer(T*, F) {}
 inline go::Int NumCPU() { return go::Int::from_raw(1); }
 }  // namespace go_runtime
+
+// ---- what the reference's own *_test.go files need (they are translated and run as tests of the translation, and on the device) ----
+namespace go_testing {
+struct FailNow {};                                   // t.Fatal / t.FailNow: leaves the test function
+struct T {
+    T* operator->() { return this; }
+    std::string name, log;
+    bool failed = false;
+    template <class... A> void note(const A&... a) { std::string s; ((go_fmt::fmt_arg(s, a), s += ' '), ...); log += name + ": " + s + "\n"; }
+    template <class... A> void Log(const A&... a) { note(a...); }
+    template <class... A> void Logf(const go::String& f, const A&... a) { note(go_fmt::Sprintf(f, a...)); }
+    template <class... A> void Error(const A&... a) { failed = true; note(a...); }
+    template <class... A> void Errorf(const go::String& f, const A&... a) { failed = true; note(go_fmt::Sprintf(f, a...)); }
+    template <class... A> [[noreturn]] void Fatal(const A&... a) { failed = true; note(a...); throw FailNow{}; }
+    template <class... A> [[noreturn]] void Fatalf(const go::String& f, const A&... a) { failed = true; note(go_fmt::Sprintf(f, a...)); throw FailNow{}; }
+    [[noreturn]] void FailNow_() { failed = true; throw FailNow{}; }
+    void Fail() { failed = true; }
+    bool Failed() const { return failed; }
+    void Helper() {}
+    void Parallel() {}
+    go::String Name() const { return go::String(name); }
+    template <class F> bool Run(const go::String& sub, F f) {
+        T t; t.name = name + "/" + sub.s;
+        try { f(&t); } catch (FailNow&) {}
+        if (t.failed) failed = true;
+        log += t.log;
+        return !t.failed;
+    }
+};
+inline bool Verbose() { return false; }
+inline bool Short() { return false; }
+using TestFn = void (*)(T*);
+inline std::vector<std::pair<std::string, TestFn>>& registry() { static std::vector<std::pair<std::string, TestFn>> r; return r; }
+struct Register { Register(const char* pkg, const char* name, TestFn f) { registry().emplace_back(std::string(pkg) + "." + name, f); } };
+// runs one registered test: 0 = pass, 1 = fail, 2 = no such test; the log of t.Log / t.Error / a panic text goes to `log`
+inline int run(const std::string& full, std::string& log) {
+    for (auto& e : registry()) {
+        if (e.first != full) continue;
+        T t; t.name = full;
+        try { e.second(&t); }
+        catch (FailNow&) {}
+        catch (go::PanicException& p) { t.failed = true; t.log += full + ": panic: " + p.what() + "\n"; }
+        catch (std::exception& x) { t.failed = true; t.log += full + ": exception: " + x.what() + "\n"; }
+        log = t.log;
+        return t.failed ? 1 : 0;
+    }
+    return 2;
+}
+}  // namespace go_testing
+namespace go_rand {
+// math/rand: the tests draw inputs from it, never compare against Go's own sequence (they are round trips), so any generator serves. Seeded per
+// process by the runner (KREF_TEST_SEED) so that a failure can be replayed.
+inline uint64_t& state() { static uint64_t s = 0x9E3779B97F4A7C15ull; return s; }
+inline uint64_t next(uint64_t& s) { s += 0x9E3779B97F4A7C15ull; uint64_t z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+struct Source { uint64_t s; };
+struct Rand {
+    Rand* operator->() { return this; }
+    uint64_t s = 1;
+    go::Int Intn(go::Int n) { if (n.v <= 0) go::panic_str("invalid argument to Intn"); return go::Int::from_raw((int64_t)(next(s) % (uint64_t)n.v)); }
+    go::Int Int() { return go::Int::from_raw((int64_t)(next(s) >> 1)); }
+    go::Int32 Int31n(go::Int32 n) { if (n.v <= 0) go::panic_str("invalid argument to Int31n"); return go::Int32::from_raw((int32_t)(next(s) % (uint64_t)n.v)); }
+    go::Uint32 Uint32() { return go::Uint32::from_raw((uint32_t)next(s)); }
+    go::Uint64 Uint64() { return go::Uint64::from_raw(next(s)); }
+};
+inline Source NewSource(go::Int64 seed) { return Source{(uint64_t)seed.v ^ state()}; }
+inline Rand* New(Source src) { Rand* r = go::New<Rand>(); r->s = src.s; return r; }
+inline go::Int Intn(go::Int n) { if (n.v <= 0) go::panic_str("invalid argument to Intn"); return go::Int::from_raw((int64_t)(next(state()) % (uint64_t)n.v)); }
+inline go::Int Int() { return go::Int::from_raw((int64_t)(next(state()) >> 1)); }
+inline go::Int32 Int31n(go::Int32 n) { return go::Int32::from_raw((int32_t)(next(state()) % (uint64_t)n.v)); }
+inline go::Uint32 Uint32() { return go::Uint32::from_raw((uint32_t)next(state())); }
+inline void Seed(go::Int64 seed) { state() = (uint64_t)seed.v; }
+}  // namespace go_rand
