@@ -1,8 +1,11 @@
 // gpu_entropy.go — goes into github.com/flanglet/kanzi-go/v2/entropy.
 //
 // kanzi.EntropyEncoder / kanzi.EntropyDecoder (v2/Definitions.go:154-179) backed by knz_entropy_encode /
-// knz_entropy_decode of libknz_gpu.so for HUFFMAN, ANS0, ANS1, FPAQ and NONE. entropy.NewEntropyEncoder /
-// NewEntropyDecoder (EntropyCodecFactory.go:45-134) return them when a GPU handle is present in the context.
+// knz_entropy_decode of libknz_gpu.so for HUFFMAN, ANS0, ANS1, FPAQ and NONE: what entropy.NewEntropyEncoder /
+// NewEntropyDecoder (EntropyCodecFactory.go:45-134) hand out for those types, for callers that hold a device handle and
+// build single codec objects. The factories themselves are not patched: the stream does not go through these objects
+// (its boundary is the block batch, gpu_stream.go); the reference's own unit tests reach them through the helpers of
+// testhooks/gpu_hooks_entropy_test.go.
 package entropy
 
 /*

@@ -2,7 +2,9 @@
 //
 // A kanzi.ByteTransform (v2/Definitions.go:78-91) backed by knz_transform_forward / knz_transform_inverse of
 // libknz_gpu.so for the transforms of the hot path: BWT (block codec form), RANK, MTFT, ZRLT, LZ, LZX, LZP, SRT, UTF, TEXT (DICT_TYPE).
-// transform.New (Factory.go:97-185) returns it for those ids when a GPU handle is present in the context.
+// What transform.New (Factory.go:97-185) builds for those ids, for callers that hold a device handle and want single
+// transform objects. The factory itself is not patched: the stream does not go through these objects (its boundary is the
+// block batch, gpu_stream.go); the reference's own unit tests reach them through testhooks/gpu_hooks_transform_test.go.
 package transform
 
 /*

@@ -280,3 +280,40 @@ func CallOrder() (int, int, int, int, int, int, int) {
 func pairOf(t *tape) (int, int) {
 	return t.next(8), t.next(9) // 8,9
 }
+
+// what table-driven tests lean on: struct types declared inside a function, anonymous struct types, map literals, a range variable captured by a
+// closure that outlives its iteration (Go >= 1.22: every iteration has its own copy), x.(T) on a non-empty interface, comma-ok included
+func TableDriven() (int, int, int, int, bool, string) {
+	type row struct {
+		name string
+		w, h int
+	}
+	rows := []row{{name: "a", w: 2, h: 3}, {"b", 4, 5}}
+	anon := []struct {
+		k string
+		v int
+	}{{"x", 1}, {"y", 2}}
+	m := map[string]int{"one": 1, "two": 2}
+	var fs []func() int
+
+	for _, r := range rows {
+		fs = append(fs, func() int { return r.w * r.h })
+	}
+
+	sum := 0
+
+	for _, f := range fs {
+		sum = sum*100 + f() // 6 then 20: each closure kept ITS r
+	}
+
+	var s shape = &rect{w: 3, h: 4}
+	rc := s.(*rect)
+	_, isSquare := s.(*square)
+	names := ""
+
+	for _, a := range anon {
+		names += a.k
+	}
+
+	return sum, anon[0].v + anon[1].v*10, m["one"] + m["two"]*10 + len(m)*100, rc.w*10 + rc.h, isSquare, names + rows[1].name
+}

@@ -2,7 +2,8 @@
 the language rules the kanzi-go sources lean on (shifts >= width, wrap-around, arithmetic >>, untyped constants, Go's operator precedence, truncating
 division, slices as views with append / copy / 3-index semantics, arrays as values, parallel assignment, shadowing, named results, switch / fallthrough /
 labelled break and continue / goto, defer order, recover of string and runtime panics through a type switch, structural interfaces, closures, maps as
-references whose reads do not insert, strings as bytes, calls inside one expression run left to right). It is translated and compiled here (g++), and every result must be the value Go gives."""
+references whose reads do not insert, strings as bytes, calls inside one expression run left to right, function-local and anonymous struct types, map literals, per-iteration range
+variables under closures, type assertions on non-empty interfaces). It is translated and compiled here (g++), and every result must be the value Go gives."""
 import os
 import subprocess
 import sys
@@ -31,6 +32,7 @@ int main() {
     { auto [a, b, c, d, e, f, g, h] = Values(go::Uint(go::U(40))); std::printf("values "); p(a.v); p(b.v); p(c.v); p(d.v); p(e.v); p(f.v); pu(g.v); p(h.v); std::printf("\n"); }
     { auto [a, ok, n, c, s, l] = MapsAndStrings(); std::printf("maps "); p(a.v); p(ok ? 1 : 0); p(n.v); pu(c.v); ps(s); p(l.v); std::printf("\n"); }
     { auto [a, l1, b, l2, l3, xy, l4] = CallOrder(); std::printf("order "); p(a.v); p(l1.v); p(b.v); p(l2.v); p(l3.v); p(xy.v); p(l4.v); std::printf("\n"); }
+    { auto [a, b, c, d, e, f] = TableDriven(); std::printf("table "); p(a.v); p(b.v); p(c.v); p(d.v); p(e ? 1 : 0); ps(f); std::printf("\n"); }
     return 0;
 }
 '''
@@ -53,6 +55,7 @@ ifaces 37 [rs] 5
 values 11 11 111 7 41 303 4294967295 1099511627776
 maps 7 0 6 195 [51-x] 1
 order 7 123 463 4567 1234055 89 89
+table 620 21 221 34 0 [xyb]
 """
 
 
