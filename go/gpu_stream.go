@@ -19,8 +19,10 @@
 package io
 
 import (
+	"fmt"
 	"sync"
 	"sync/atomic"
+	"time"
 
 	kanzi "github.com/flanglet/kanzi-go/v2"
 )
@@ -133,8 +135,37 @@ func (this *Writer) processBlockGPU(gb *gpuBatch) error {
 		return err
 	}
 
-	// ordered emission into the shared bitstream, as the tasks do it one after the other (:934-976)
-	emitBlocks(this.obs, out, res)
+	firstID := int(atomic.LoadInt32(&this.blockID))
+	hashType := kanzi.EVT_HASH_NONE
+
+	if this.hasher32 != nil {
+		hashType = kanzi.EVT_HASH_32BITS
+	} else if this.hasher64 != nil {
+		hashType = kanzi.EVT_HASH_64BITS
+	}
+
+	// ordered emission into the shared bitstream, as the tasks do it one after the other (:934-976); in front of each
+	// block the events its task would have sent (:766-771, :850-855, :889-894, :916-931), in the order a one-job Writer
+	// sends them, with the same ids, sizes and hashes
+	for i := range res {
+		if len(this.listeners) > 0 {
+			id := firstID + i + 1
+			notifyListeners(this.listeners, kanzi.NewEvent(kanzi.EVT_BEFORE_TRANSFORM, id, int64(lengths[i]), res[i].checksum, hashType, time.Now()))
+			notifyListeners(this.listeners, kanzi.NewEvent(kanzi.EVT_AFTER_TRANSFORM, id, int64(res[i].postLen), res[i].checksum, hashType, time.Now()))
+			notifyListeners(this.listeners, kanzi.NewEvent(kanzi.EVT_BEFORE_ENTROPY, id, int64(res[i].postLen), res[i].checksum, hashType, time.Now()))
+			notifyListeners(this.listeners, kanzi.NewEvent(kanzi.EVT_AFTER_ENTROPY, id, int64((res[i].written+7)>>3), res[i].checksum, hashType, time.Now()))
+
+			if v, hasKey := this.ctx["verbosity"]; hasKey {
+				if v.(uint) > 4 {
+					msg := fmt.Sprintf("{ \"type\":\"%s\", \"id\":%d, \"offset\":%d, \"skipFlags\":%.8b }", "BLOCK_INFO", id, this.obs.Written(), res[i].skipFlags)
+					notifyListeners(this.listeners, kanzi.NewEventFromString(kanzi.EVT_BLOCK_INFO, id, msg, time.Now()))
+				}
+			}
+		}
+
+		emitBlocks(this.obs, out[i:i+1], res[i:i+1])
+	}
+
 	atomic.AddInt32(&this.blockID, int32(len(lengths)))
 	return nil
 }
@@ -206,8 +237,11 @@ func (this *Reader) processBlockGPU(gb *gpuBatch) (int64, error) {
 
 	payload := make([][]byte, 0, this.jobs)
 	out := make([][]byte, 0, this.jobs)
+	firstID := int(atomic.LoadInt32(&this.blockID))
+	offsets := make([]uint64, 0, this.jobs)
 
 	for taskID := 0; taskID < this.jobs; taskID++ {
+		offsets = append(offsets, this.ibs.Read())
 		lr := uint(this.ibs.ReadBits(5)) + 3
 		read := this.ibs.ReadBits(lr)
 
@@ -270,8 +304,69 @@ func (this *Reader) processBlockGPU(gb *gpuBatch) (int64, error) {
 		}
 
 		decoded += int64(sizes[i])
+
+		if len(this.listeners) > 0 {
+			this.notifyBlockGPU(firstID+i+1, payload[i], sizes[i], offsets[i])
+		}
 	}
 
 	this.consumed = 0
 	return decoded, nil
+}
+
+// notifyBlockGPU sends the events a decodingTask sends for one block (CompressedStream.go:1905-1931, :1960-1971 and the
+// in-order EVT_AFTER_TRANSFORM of Reader.processBlock, :1722-1733), with the same ids, sizes and hashes: the fields they
+// carry are the first whole bytes of the block's payload (mode, skip flags, length, checksum: :1875-1916).
+func (this *Reader) notifyBlockGPU(id int, data []byte, decoded int, blockOffset uint64) {
+	pos := 0
+	mode := data[pos]
+	pos++
+	skipFlags := byte(0)
+
+	if mode&_COPY_BLOCK_MASK == 0 {
+		if mode&_TRANSFORMS_MASK != 0 {
+			skipFlags = data[pos]
+			pos++
+		} else {
+			skipFlags = (mode << 4) | 0x0F
+		}
+	}
+
+	dataSize := 1 + int((mode>>5)&0x03)
+	preTransformLength := uint64(0)
+
+	for k := 0; k < dataSize; k++ {
+		preTransformLength = (preTransformLength << 8) | uint64(data[pos])
+		pos++
+	}
+
+	hashType := kanzi.EVT_HASH_NONE
+	hashBytes := 0
+
+	if this.hasher32 != nil {
+		hashType = kanzi.EVT_HASH_32BITS
+		hashBytes = 4
+	} else if this.hasher64 != nil {
+		hashType = kanzi.EVT_HASH_64BITS
+		hashBytes = 8
+	}
+
+	checksum1 := uint64(0)
+
+	for k := 0; k < hashBytes; k++ {
+		checksum1 = (checksum1 << 8) | uint64(data[pos])
+		pos++
+	}
+
+	if v, hasKey := this.ctx["verbosity"]; hasKey {
+		if v.(uint) > 4 {
+			msg := fmt.Sprintf("{ \"type\":\"%s\", \"id\":%d, \"offset\":%d, \"skipFlags\":%.8b }", "BLOCK_INFO", id, blockOffset, skipFlags)
+			notifyListeners(this.listeners, kanzi.NewEventFromString(kanzi.EVT_BLOCK_INFO, id, msg, time.Now()))
+		}
+	}
+
+	notifyListeners(this.listeners, kanzi.NewEvent(kanzi.EVT_BEFORE_ENTROPY, id, int64(len(data)), checksum1, hashType, time.Now()))
+	notifyListeners(this.listeners, kanzi.NewEvent(kanzi.EVT_AFTER_ENTROPY, id, int64(preTransformLength), checksum1, hashType, time.Now()))
+	notifyListeners(this.listeners, kanzi.NewEvent(kanzi.EVT_BEFORE_TRANSFORM, id, int64(preTransformLength), checksum1, hashType, time.Now()))
+	notifyListeners(this.listeners, kanzi.NewEvent(kanzi.EVT_AFTER_TRANSFORM, id, int64(decoded), checksum1, hashType, time.Now()))
 }

@@ -237,6 +237,29 @@ int kref_bwt_inverse(const uint8_t* src, uint64_t n, uint8_t* dst, const uint64_
     KREF_CATCH
 }
 
+// A kanzi.Listener (Definitions.go, Event.go) that writes down what it is told: "type id size hash hashType" or "type id msg" per event. When
+// kref_record_events(verbosity) has been called, the four stream calls below attach it (Writer.AddListener / Reader.AddListener) and put
+// ctx["verbosity"] in place; kref_event_log returns the lines of the last call. Times are left out: they are the only field that may differ.
+struct EventRecorder : kz_kanzi::Listener {
+    std::string log;
+    void ProcessEvent(kz_kanzi::Event* e) override {
+        char line[160];
+        if (e->msg.s.empty())
+            snprintf(line, sizeof line, "%lld %lld %lld %llx %lld\n", (long long)e->eventType.v, (long long)e->id.v, (long long)e->size.v, (unsigned long long)e->hash.v,
+                     (long long)e->hashType.v);
+        else
+            snprintf(line, sizeof line, "%lld %lld %s\n", (long long)e->eventType.v, (long long)e->id.v, e->msg.s.c_str());
+        log += line;
+    }
+};
+static int g_record_verbosity = -1;          // < 0: no listener
+static std::string g_event_log;
+extern "C" void kref_record_events(int verbosity) { g_record_verbosity = verbosity; g_event_log.clear(); }
+extern "C" uint64_t kref_event_log(char* dst, uint64_t cap) {
+    if (dst && cap) { size_t k = std::min<size_t>(g_event_log.size(), (size_t)cap - 1); memcpy(dst, g_event_log.data(), k); dst[k] = 0; }
+    return g_event_log.size();
+}
+
 // == what app/BlockCompressor.go does with a file: io.NewWriterWithCtx(os, ctx); w.Write(data); w.Close()  (io/CompressedStream.go:232-620).
 // The goroutines of Writer.processBlock run one after the other (`go task.encode(..)` is emitted as the call; the tasks' lock-free hand-over of
 // the shared bit stream, :935-949, is satisfied in block order). file_size < 0: ctx["fileSize"] absent. Returns the .knz stream.
@@ -253,12 +276,16 @@ int kref_compress(const uint8_t* src, uint64_t n, const char* transform, const c
     if (file_size >= 0) ctx[go::String("fileSize")] = go::any(go::Int64(go::U(file_size)));
     ctx[go::String("headerless")] = go::any(false);
     if (skip_blocks) ctx[go::String("skipBlocks")] = go::any(true);
+    if (g_record_verbosity >= 0) ctx[go::String("verbosity")] = go::any(go::Uint(go::U(g_record_verbosity)));
     auto [w, err] = kz_io::NewWriterWithCtx(&ms, ctx);
     if (err != nullptr) return fail(err, 1);
+    EventRecorder rec;
+    if (g_record_verbosity >= 0) w->AddListener(&rec);
     // (the application hands the writer its read buffer piece by piece; one call with everything writes the same stream)
     auto [wr, werr] = w->Write(copy_in(src, n));
     if (werr != nullptr) return fail(werr, 2);
     go::error cerr = w->Close();
+    g_event_log = rec.log;
     if (cerr != nullptr) return fail(cerr, 3);
     if (ms.data.size() > cap) { g_err = "output buffer too small"; return 4; }
     memcpy(dst, ms.data.data(), ms.data.size());
@@ -267,13 +294,25 @@ int kref_compress(const uint8_t* src, uint64_t n, const char* transform, const c
     KREF_CATCH
 }
 
+// io.NewReader(is, jobs), or io.NewReaderWithCtx with ctx["verbosity"] when events are being recorded
+static std::tuple<kz_io::Reader*, go::error> open_reader(MemStream* ms, uint32_t jobs) {
+    if (g_record_verbosity < 0) return kz_io::NewReader(ms, go::Uint(go::U(jobs ? jobs : 1)));
+    Ctx ctx = go::make_map<go::String, go::any>();
+    ctx[go::String("jobs")] = go::any(go::Uint(go::U(jobs ? jobs : 1)));
+    ctx[go::String("verbosity")] = go::any(go::Uint(go::U(g_record_verbosity)));
+    return kz_io::NewReaderWithCtx(ms, ctx);
+}
+
 // == io.NewReader(is, jobs); r.Read(...) until EOF; r.Close()  (io/CompressedStream.go:1047-1760)
 int kref_decompress(const uint8_t* src, uint64_t n, uint32_t jobs, uint8_t* dst, uint64_t cap, uint64_t* out_n) {
     KREF_TRY
     MemStream ms;
     ms.data.assign((const char*)src, (size_t)n);
-    auto [r, err] = kz_io::NewReader(&ms, go::Uint(go::U(jobs ? jobs : 1)));
+    auto [r, err] = open_reader(&ms, jobs);
     if (err != nullptr) return fail(err, 1);
+    EventRecorder rec;
+    if (g_record_verbosity >= 0) r->AddListener(&rec);
+    struct KeepLog { EventRecorder& r; ~KeepLog() { g_event_log = r.log; } } keep{rec};
     go::Slice<go::Byte> buf = go::Slice<go::Byte>::make(1 << 20, 1 << 20);
     uint64_t total = 0;
     while (true) {
@@ -311,13 +350,17 @@ int kref_gpu_compress(const uint8_t* src, uint64_t n, const char* transform, con
     if (file_size >= 0) ctx[go::String("fileSize")] = go::any(go::Int64(go::U(file_size)));
     ctx[go::String("headerless")] = go::any(false);
     if (skip_blocks) ctx[go::String("skipBlocks")] = go::any(true);
+    if (g_record_verbosity >= 0) ctx[go::String("verbosity")] = go::any(go::Uint(go::U(g_record_verbosity)));
     auto [w, err] = kz_io::NewWriterWithCtx(&ms, ctx);
     if (err != nullptr) return fail(err, 1);
+    EventRecorder rec;
+    if (g_record_verbosity >= 0) w->AddListener(&rec);
     go::error gerr = w->EnableGPU();
     if (gerr != nullptr) return fail(gerr, 5);
     auto [wr, werr] = w->Write(copy_in(src, n));
     go::error cerr = werr != nullptr ? werr : w->Close();
     w->DisableGPU();
+    g_event_log = rec.log;
     if (cerr != nullptr) return fail(cerr, 3);
     if (ms.data.size() > cap) { g_err = "output buffer too small"; return 4; }
     memcpy(dst, ms.data.data(), ms.data.size());
@@ -331,8 +374,11 @@ int kref_gpu_decompress(const uint8_t* src, uint64_t n, uint32_t jobs, uint8_t* 
     KREF_TRY
     MemStream ms;
     ms.data.assign((const char*)src, (size_t)n);
-    auto [r, err] = kz_io::NewReader(&ms, go::Uint(go::U(jobs ? jobs : 1)));
+    auto [r, err] = open_reader(&ms, jobs);
     if (err != nullptr) return fail(err, 1);
+    EventRecorder rec;
+    if (g_record_verbosity >= 0) r->AddListener(&rec);
+    struct KeepLog { EventRecorder& r; ~KeepLog() { g_event_log = r.log; } } keep{rec};
     go::error gerr = r->EnableGPU();
     if (gerr != nullptr) return fail(gerr, 5);
     go::Slice<go::Byte> buf = go::Slice<go::Byte>::make(1 << 20, 1 << 20);

@@ -317,3 +317,10 @@ func TableDriven() (int, int, int, int, bool, string) {
 
 	return sum, anon[0].v + anon[1].v*10, m["one"] + m["two"]*10 + len(m)*100, rc.w*10 + rc.h, isSquare, names + rows[1].name
 }
+
+// fmt verbs with flags, width and precision as the reference's messages use them (%.8b for skip flags, %x for checksums)
+func Formats() string {
+	flags := byte(31)
+	sum := uint64(0xabcdef)
+	return fmt.Sprintf("[%.8b] [%x] [%X] [%5d] [%-5d] [%05d] [%q] [%v] [%d%%]", flags, sum, uint32(255), -42, 7, -42, "hi", 3, 50)
+}

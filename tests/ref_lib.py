@@ -221,3 +221,19 @@ def decompress(stream, cap, jobs=1):
     n = C.c_uint64()
     _chk(L.kref_decompress(p, len(a), jobs, out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n)))
     return out[: n.value].tobytes()
+
+
+def record_events(verbosity, L=None):
+    """from now on the stream calls attach a kanzi.Listener that writes every event down (ctx["verbosity"] = verbosity; < 0: stop)"""
+    (L or lib()).kref_record_events(verbosity)
+
+
+def event_log(L=None):
+    """the events of the last stream call, one per line: "type id size hash hashType" or "type id msg" (times left out)"""
+    L = L or lib()
+    L.kref_event_log.argtypes = [C.c_char_p, C.c_uint64]
+    L.kref_event_log.restype = C.c_uint64
+    n = L.kref_event_log(None, 0)
+    buf = C.create_string_buffer(int(n) + 1)
+    L.kref_event_log(buf, n + 1)
+    return buf.value.decode().splitlines()

@@ -33,6 +33,7 @@ int main() {
     { auto [a, ok, n, c, s, l] = MapsAndStrings(); std::printf("maps "); p(a.v); p(ok ? 1 : 0); p(n.v); pu(c.v); ps(s); p(l.v); std::printf("\n"); }
     { auto [a, l1, b, l2, l3, xy, l4] = CallOrder(); std::printf("order "); p(a.v); p(l1.v); p(b.v); p(l2.v); p(l3.v); p(xy.v); p(l4.v); std::printf("\n"); }
     { auto [a, b, c, d, e, f] = TableDriven(); std::printf("table "); p(a.v); p(b.v); p(c.v); p(d.v); p(e ? 1 : 0); ps(f); std::printf("\n"); }
+    { std::printf("formats "); ps(Formats()); std::printf("\n"); }
     return 0;
 }
 '''
@@ -56,6 +57,7 @@ values 11 11 111 7 41 303 4294967295 1099511627776
 maps 7 0 6 195 [51-x] 1
 order 7 123 463 4567 1234055 89 89
 table 620 21 221 34 0 [xyb]
+formats [[00011111] [abcdef] [FF] [ -42] [7 ] [-0042] ["hi"] [3] [50%]]
 """
 
 

@@ -125,3 +125,31 @@ def test_plugin_objects_of_the_go_shim(G):
             assert rc == 0, (ename, name, G.kref_last_error())
             ob, obits = O.entropy_encode(et, data)
             assert bits.value == obits and out[: (obits + 7) // 8].tobytes() == ob, (ename, name)
+
+
+@pytest.mark.parametrize("cfg", [("BWT+RANK+ZRLT", "ANS1", 1 << 16, 64), ("LZ", "HUFFMAN", 1 << 15, 32), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0", 1 << 17, 0)])
+def test_listeners_hear_the_same_events_through_the_go_shim(G, cfg):
+    """kanzi.Listener (Definitions.go, Event.go): a Writer / Reader whose batches go to the device tells its listeners what a one-job Writer / Reader tells
+    them - the same events in the same order with the same block ids, sizes (block, post-transform, compressed) and hashes, EVT_BLOCK_INFO with its
+    stream offset and skip flags included (verbosity 5)."""
+    if not R.available():
+        pytest.skip("oracle/_ref is not here to say what the reference's listeners hear")
+    transform, entropy, bs, ck = cfg
+    for n in (1, 40, 3 * bs + 77, 21 * bs + 5):
+        data = P.corpus(n, seed=7 + n % 13)
+        R.record_events(5)
+        stream = R.compress(data, transform, entropy, bs, ck, jobs=1)
+        want_w = R.event_log()
+        assert R.decompress(stream, n + 64, jobs=1) == data
+        want_r = R.event_log()
+        R.record_events(-1)
+        assert len(want_w) >= 5 * max(1, -(-n // bs)) and len(want_r) >= 5 * max(1, -(-n // bs)), (cfg, n, want_w[:3])
+        for jobs in (1, 16):
+            R.record_events(5, G)
+            assert gpu_compress(G, data, transform, entropy, bs, ck, jobs=jobs) == stream
+            got_w = R.event_log(G)
+            assert gpu_decompress(G, stream, n + 64, jobs=jobs) == data
+            got_r = R.event_log(G)
+            R.record_events(-1, G)
+            assert got_w == want_w, (cfg, n, jobs, "Writer events", [(a, b) for a, b in zip(got_w, want_w) if a != b][:3], len(got_w), len(want_w))
+            assert got_r == want_r, (cfg, n, jobs, "Reader events", [(a, b) for a, b in zip(got_r, want_r) if a != b][:3], len(got_r), len(want_r))

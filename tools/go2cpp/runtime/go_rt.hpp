@@ -181,6 +181,8 @@ template <class T, class Tag> struct I {
 template <class T, class G> constexpr U operator<<(U a, I<T, G> s) { return a << U((__int128)shift_count(s)); }
 template <class T, class G> constexpr U operator>>(U a, I<T, G> s) { return a >> U((__int128)shift_count(s)); }
 
+template <class X> struct is_int_wrapper : std::false_type {};
+template <class T, class Tag> struct is_int_wrapper<I<T, Tag>> : std::true_type {};
 using Int = I<int64_t>;   using Uint = I<uint64_t>;  using Uintptr = I<uint64_t>;
 using Int8 = I<int8_t>;   using Int16 = I<int16_t>;  using Int32 = I<int32_t>;   using Int64 = I<int64_t>;
 using Uint8 = I<uint8_t>; using Uint16 = I<uint16_t>; using Uint32 = I<uint32_t>; using Uint64 = I<uint64_t>;
@@ -571,19 +573,55 @@ template <class T, class G> inline void fmt_arg(std::string& out, go::I<T, G> v)
     if constexpr (std::is_signed_v<T>) out += std::to_string((long long)v.v); else out += std::to_string((unsigned long long)v.v);
 }
 template <class T> inline void fmt_arg(std::string& out, const T&) { out += "?"; }
-// verbs are replaced in order by the arguments' default renderings (messages are diagnostics: never compared)
+// one argument of a formatting call: its default rendering (%v) and, for integers, sign and magnitude (for %d %b %o %x %X %c with flags, width, precision)
+struct FmtArg { std::string text; bool is_int = false, neg = false; unsigned long long mag = 0; };
+template <class T> inline FmtArg fmt_capture(const T& v) {
+    FmtArg a; fmt_arg(a.text, v);
+    if constexpr (go::is_int_wrapper<T>::value) {
+        a.is_int = true;
+        if constexpr (std::is_signed_v<decltype(v.v)>) { a.neg = v.v < 0; a.mag = a.neg ? 0ull - (unsigned long long)v.v : (unsigned long long)v.v; }
+        else a.mag = (unsigned long long)v.v;
+    } else if constexpr (std::is_same_v<T, go::U>) { a.is_int = true; a.neg = v.v < 0; a.mag = (unsigned long long)(a.neg ? -v.v : v.v); }
+    return a;
+}
+inline std::string fmt_digits(unsigned long long m, unsigned base, bool upper) {
+    if (m == 0) return "0";
+    std::string d;
+    while (m) { unsigned k = (unsigned)(m % base); d += (char)(k < 10 ? '0' + k : (upper ? 'A' : 'a') + (k - 10)); m /= base; }
+    return std::string(d.rbegin(), d.rend());
+}
+// fmt.Sprintf for the verbs the translated files use: %v %d %s %q %x %X %b %o %c with the flags - 0 +, a width and a precision (for integers a precision
+// is the least number of digits, as in Go); anything else renders the argument's default form
 template <class... A> inline go::String Sprintf(const go::String& f, const A&... a) {
-    std::vector<std::string> args;
-    (([&] { std::string s; fmt_arg(s, a); args.push_back(s); })(), ...);
+    std::vector<FmtArg> args;
+    (args.push_back(fmt_capture(a)), ...);
     std::string out;
     size_t k = 0;
     for (size_t i = 0; i < f.s.size(); i++) {
         if (f.s[i] != '%') { out += f.s[i]; continue; }
         if (i + 1 < f.s.size() && f.s[i + 1] == '%') { out += '%'; i++; continue; }
         size_t j = i + 1;
-        while (j < f.s.size() && !isalpha((unsigned char)f.s[j])) j++;
-        out += k < args.size() ? args[k++] : std::string("%!missing");
+        bool left = false, zero = false, plus = false;
+        for (; j < f.s.size() && (f.s[j] == '-' || f.s[j] == '0' || f.s[j] == '+' || f.s[j] == ' ' || f.s[j] == '#'); j++) { left |= f.s[j] == '-'; zero |= f.s[j] == '0'; plus |= f.s[j] == '+'; }
+        int width = -1, prec = -1;
+        if (j < f.s.size() && isdigit((unsigned char)f.s[j])) { width = 0; while (j < f.s.size() && isdigit((unsigned char)f.s[j])) width = width * 10 + (f.s[j++] - '0'); }
+        if (j < f.s.size() && f.s[j] == '.') { j++; prec = 0; while (j < f.s.size() && isdigit((unsigned char)f.s[j])) prec = prec * 10 + (f.s[j++] - '0'); }
+        const char verb = j < f.s.size() ? f.s[j] : 'v';
         i = j;
+        if (k >= args.size()) { out += "%!"; out += verb; out += "(MISSING)"; continue; }
+        const FmtArg& g = args[k++];
+        std::string body;
+        if (g.is_int && (verb == 'd' || verb == 'v' || verb == 'b' || verb == 'o' || verb == 'x' || verb == 'X')) {
+            std::string d = fmt_digits(g.mag, verb == 'b' ? 2 : verb == 'o' ? 8 : (verb == 'x' || verb == 'X') ? 16 : 10, verb == 'X');
+            if (prec >= 0 && (int)d.size() < prec) d = std::string((size_t)prec - d.size(), '0') + d;
+            const std::string sign = g.neg ? "-" : (plus ? "+" : "");
+            if (zero && !left && prec < 0 && width > (int)(d.size() + sign.size())) d = std::string((size_t)width - d.size() - sign.size(), '0') + d;
+            body = sign + d;
+        } else if (g.is_int && verb == 'c') body = std::string(1, (char)g.mag);
+        else if (verb == 'q') body = "\"" + g.text + "\"";
+        else { body = g.text; if (prec >= 0 && !g.is_int && (int)body.size() > prec) body.resize((size_t)prec); }
+        if (width > (int)body.size()) body = left ? body + std::string((size_t)width - body.size(), ' ') : std::string((size_t)width - body.size(), ' ') + body;
+        out += body;
     }
     return go::String(out);
 }
