@@ -239,6 +239,7 @@ func (this *Reader) processBlockGPU(gb *gpuBatch) (int64, error) {
 	out := make([][]byte, 0, this.jobs)
 	firstID := int(atomic.LoadInt32(&this.blockID))
 	offsets := make([]uint64, 0, this.jobs)
+	endOfStream := false
 
 	for taskID := 0; taskID < this.jobs; taskID++ {
 		offsets = append(offsets, this.ibs.Read())
@@ -248,6 +249,7 @@ func (this *Reader) processBlockGPU(gb *gpuBatch) (int64, error) {
 		if read == 0 {
 			// end of stream: nothing is decoded from here on (what the first task that reads an empty block does, :1781-1793)
 			atomic.StoreInt32(&this.blockID, _CANCEL_TASKS_ID)
+			endOfStream = true
 			break
 		}
 
@@ -286,6 +288,10 @@ func (this *Reader) processBlockGPU(gb *gpuBatch) (int64, error) {
 	}
 
 	if len(payload) == 0 {
+		if endOfStream {
+			this.notifyEndGPU(firstID + 1)
+		}
+
 		this.consumed = 0
 		return 0, nil
 	}
@@ -308,6 +314,10 @@ func (this *Reader) processBlockGPU(gb *gpuBatch) (int64, error) {
 		if len(this.listeners) > 0 {
 			this.notifyBlockGPU(firstID+i+1, payload[i], sizes[i], offsets[i])
 		}
+	}
+
+	if endOfStream {
+		this.notifyEndGPU(firstID + len(payload) + 1)
 	}
 
 	this.consumed = 0
@@ -369,4 +379,22 @@ func (this *Reader) notifyBlockGPU(id int, data []byte, decoded int, blockOffset
 	notifyListeners(this.listeners, kanzi.NewEvent(kanzi.EVT_AFTER_ENTROPY, id, int64(preTransformLength), checksum1, hashType, time.Now()))
 	notifyListeners(this.listeners, kanzi.NewEvent(kanzi.EVT_BEFORE_TRANSFORM, id, int64(preTransformLength), checksum1, hashType, time.Now()))
 	notifyListeners(this.listeners, kanzi.NewEvent(kanzi.EVT_AFTER_TRANSFORM, id, int64(decoded), checksum1, hashType, time.Now()))
+}
+
+// notifyEndGPU: the task that reads the end-of-stream marker decodes nothing, and Reader.processBlock still reports its
+// (empty) result to the listeners (:1700-1733): one EVT_AFTER_TRANSFORM of size 0 with the id behind the last block.
+func (this *Reader) notifyEndGPU(id int) {
+	if len(this.listeners) == 0 {
+		return
+	}
+
+	hashType := kanzi.EVT_HASH_NONE
+
+	if this.hasher32 != nil {
+		hashType = kanzi.EVT_HASH_32BITS
+	} else if this.hasher64 != nil {
+		hashType = kanzi.EVT_HASH_64BITS
+	}
+
+	notifyListeners(this.listeners, kanzi.NewEvent(kanzi.EVT_AFTER_TRANSFORM, id, 0, 0, hashType, time.Now()))
 }
