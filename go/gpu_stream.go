@@ -79,6 +79,39 @@ func (this *Writer) EnableGPU() error {
 	return nil
 }
 
+// EnableGPUDepth is EnableGPU with a batch depth of its own: `depth` blocks (1..1024) are buffered and handed to the
+// device per batch instead of `jobs` (which the reference caps at 64, _MAX_CONCURRENCY: it is a number of goroutines
+// there; here it is only how many blocks are in flight on the device, and the chains of the BWT pipelines want hundreds:
+// DESIGN.md section 4, saturation curve). To be called before the first Write. The stream written is the same for
+// every depth. Host memory: depth x 2 block buffers, allocated as they fill; device workspace grows with the batch and
+// the library takes a batch in halves when the device cannot hold it.
+func (this *Writer) EnableGPUDepth(depth int) error {
+	if depth < 1 || depth > 1024 {
+		return &IOError{msg: "The batch depth must be in [1..1024]", code: kanzi.ERR_INVALID_PARAM}
+	}
+
+	if this.available != 0 || atomic.LoadInt32(&this.blockID) != 0 {
+		return &IOError{msg: "The batch depth must be set before the first Write", code: kanzi.ERR_INVALID_PARAM}
+	}
+
+	if err := this.EnableGPU(); err != nil {
+		return err
+	}
+
+	if depth != this.jobs {
+		first := this.buffers[0]
+		this.jobs = depth
+		this.buffers = make([]blockBuffer, 2*depth)
+		this.buffers[0] = first
+
+		for i := 1; i < 2*depth; i++ {
+			this.buffers[i] = blockBuffer{Buf: make([]byte, 0)}
+		}
+	}
+
+	return nil
+}
+
 // DisableGPU gives the batch scheduler back (to be called after Close).
 func (this *Writer) DisableGPU() {
 	gpuLock.Lock()
@@ -206,6 +239,33 @@ func (this *Reader) EnableGPU() error {
 	gpuLock.Lock()
 	gpuReaders[this] = gb
 	gpuLock.Unlock()
+	return nil
+}
+
+// EnableGPUDepth is EnableGPU with a batch depth of its own (see Writer.EnableGPUDepth): up to `depth` blocks are read
+// from the stream and decoded per device batch. To be called before the first Read.
+func (this *Reader) EnableGPUDepth(depth int) error {
+	if depth < 1 || depth > 1024 {
+		return &IOError{msg: "The batch depth must be in [1..1024]", code: kanzi.ERR_INVALID_PARAM}
+	}
+
+	if this.available != 0 || this.consumed != 0 || atomic.LoadInt32(&this.blockID) != 0 {
+		return &IOError{msg: "The batch depth must be set before the first Read", code: kanzi.ERR_INVALID_PARAM}
+	}
+
+	if err := this.EnableGPU(); err != nil {
+		return err
+	}
+
+	if depth != this.jobs {
+		this.jobs = depth
+		this.buffers = make([]blockBuffer, 2*depth)
+
+		for i := range this.buffers {
+			this.buffers[i] = blockBuffer{Buf: make([]byte, 0)}
+		}
+	}
+
 	return nil
 }
 

@@ -335,6 +335,10 @@ int kref_decompress(const uint8_t* src, uint64_t n, uint32_t jobs, uint8_t* dst,
 }
 
 #ifdef KREF_WITH_CGO
+// kref_gpu_depth(n): from now on the two calls below ask for a batch depth of their own (Writer / Reader.EnableGPUDepth, go/gpu_stream.go); 0 = `jobs` blocks per batch
+static int g_gpu_depth = 0;
+extern "C" void kref_gpu_depth(int depth) { g_gpu_depth = depth; }
+
 // The Go host with its block batches re-pointed at the GPU batch scheduler: io.NewWriterWithCtx + Writer.EnableGPU (go/gpu_stream.go), `jobs` blocks per
 // device batch. Same arguments and result as kref_compress.
 int kref_gpu_compress(const uint8_t* src, uint64_t n, const char* transform, const char* entropy, uint32_t block_size, uint32_t checksum_bits, uint32_t jobs,
@@ -355,7 +359,7 @@ int kref_gpu_compress(const uint8_t* src, uint64_t n, const char* transform, con
     if (err != nullptr) return fail(err, 1);
     EventRecorder rec;
     if (g_record_verbosity >= 0) w->AddListener(&rec);
-    go::error gerr = w->EnableGPU();
+    go::error gerr = g_gpu_depth > 0 ? w->EnableGPUDepth(go::Int(go::U(g_gpu_depth))) : w->EnableGPU();
     if (gerr != nullptr) return fail(gerr, 5);
     auto [wr, werr] = w->Write(copy_in(src, n));
     go::error cerr = werr != nullptr ? werr : w->Close();
@@ -379,7 +383,7 @@ int kref_gpu_decompress(const uint8_t* src, uint64_t n, uint32_t jobs, uint8_t* 
     EventRecorder rec;
     if (g_record_verbosity >= 0) r->AddListener(&rec);
     struct KeepLog { EventRecorder& r; ~KeepLog() { g_event_log = r.log; } } keep{rec};
-    go::error gerr = r->EnableGPU();
+    go::error gerr = g_gpu_depth > 0 ? r->EnableGPUDepth(go::Int(go::U(g_gpu_depth))) : r->EnableGPU();
     if (gerr != nullptr) return fail(gerr, 5);
     go::Slice<go::Byte> buf = go::Slice<go::Byte>::make(1 << 20, 1 << 20);
     uint64_t total = 0;

@@ -27,9 +27,10 @@ def main():
             assert R.decompress(stream, n + 64, jobs=1) == data
             want_r = R.event_log()
             R.record_events(-1)
-            for jobs in (1, 2, 16):
+            for jobs, depth in ((1, 0), (16, 0), (2, 100)):       # depth: Writer / Reader.EnableGPUDepth (a batch depth of its own; 0 = `jobs` blocks per batch)
+                L.kref_gpu_depth(depth)
                 R.record_events(5, L)
-                assert T.gpu_compress(L, data, transform, entropy, bs, ck, jobs=jobs) == stream, (transform, entropy, n, jobs, "stream")
+                assert T.gpu_compress(L, data, transform, entropy, bs, ck, jobs=jobs) == stream, (transform, entropy, n, jobs, depth, "stream")
                 got_w = R.event_log(L)
                 assert T.gpu_decompress(L, stream, n + 64, jobs=jobs) == data, (transform, entropy, n, jobs, "decode")
                 got_r = R.event_log(L)
@@ -37,6 +38,7 @@ def main():
                 assert got_w == want_w, (transform, entropy, n, jobs, "Writer events", [(a, b) for a, b in zip(got_w, want_w) if a != b][:3], len(got_w), len(want_w))
                 assert got_r == want_r, (transform, entropy, n, jobs, "Reader events", [(a, b) for a, b in zip(got_r, want_r) if a != b][:3], len(got_r), len(want_r))
                 cases += 1
+            L.kref_gpu_depth(0)
     print(f"go shim on the emulator: {cases} cases ok")
 
 

@@ -153,3 +153,19 @@ def test_listeners_hear_the_same_events_through_the_go_shim(G, cfg):
             R.record_events(-1, G)
             assert got_w == want_w, (cfg, n, jobs, "Writer events", [(a, b) for a, b in zip(got_w, want_w) if a != b][:3], len(got_w), len(want_w))
             assert got_r == want_r, (cfg, n, jobs, "Reader events", [(a, b) for a, b in zip(got_r, want_r) if a != b][:3], len(got_r), len(want_r))
+
+
+def test_batch_depth_of_its_own_through_the_go_shim(G):
+    """Writer / Reader.EnableGPUDepth (go/gpu_stream.go): more blocks per device batch than `jobs` allows (the reference caps jobs at 64). 300 blocks of 16 KiB with
+    depths 1, 100 and 1000: the streams are the stream of the reference without the device, and they decode at every depth."""
+    bs, n = 1 << 14, 300 * (1 << 14) + 123
+    data = P.corpus(n, seed=31)
+    for transform, entropy, ck in (("BWT+RANK+ZRLT", "ANS1", 32), ("LZ", "HUFFMAN", 0)):
+        want = R.compress(data, transform, entropy, bs, ck) if R.available() else O.compress(data, transform, entropy, bs, ck)
+        try:
+            for depth in (1, 100, 1000):
+                G.kref_gpu_depth(depth)
+                assert gpu_compress(G, data, transform, entropy, bs, ck, jobs=4) == want, (transform, entropy, depth)
+                assert gpu_decompress(G, want, n + 64, jobs=4) == data, (transform, entropy, depth)
+        finally:
+            G.kref_gpu_depth(0)
