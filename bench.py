@@ -787,7 +787,7 @@ def main():
                                   "tests/test_ref_build.py, tests/test_ref_streams.py; DESIGN.md section 2)")
         if not multi and not emu and not args.no_host_hook:
             try:
-                out["host_hook_MBps"] = host_hook_rate(K, (transform, entropy, bs, 0, local_rank), base[:size], bs)
+                out["host_hook_MBps"] = host_hook_rate(K, (transform, entropy, bs, 0, local_rank), base[:size] if size <= base_size else tiled(0, size), bs)
                 # (the metric of SURVEY 8d "including H2D / D2H": never `value`, kept beside it)
                 roof["host_hook_round_trip_MBps"] = out["host_hook_MBps"]["round_trip"]
                 roof["host_hook_encode_MBps"] = out["host_hook_MBps"]["encode"]; roof["host_hook_decode_MBps"] = out["host_hook_MBps"]["decode"]
