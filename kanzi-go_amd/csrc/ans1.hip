@@ -530,7 +530,7 @@ struct Ans1DecArgs {
     uint32_t* info;                // [nslots * 8] {mode, st0..st3, lr}
     uint64_t* paybit;              // [nslots]
     int32_t* blk_status;
-    uint32_t plain_loop;           // (KNZ_ANS1_PLAIN: the compiler's schedule of the LDS decoder's loop instead of the hand-written block; A/B and cross-check)
+    uint32_t plain_loop;           // 0: the hand-written block; 1 (KNZ_ANS1_PLAIN): the compiler's schedule of the same loop; 2 (KNZ_ANS1_LOHI_LDS): round 4's hand-written block (A/B and cross-check)
     uint64_t* progress;            // [nslots] or null: steps whose bytes are stored (first-quarter bytes of the chunk), ~0 = chunk complete: read by the fused ZRLT / RANK inverse (rank_pipe.hip)
 };
 
@@ -909,7 +909,93 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
         };
         const uint32_t t4 = tn >> 2;
 #ifndef KNZ_HIP_EMU
-        if (t4 != 0 && !a.plain_loop) {
+        if (t4 != 0 && a.plain_loop == 0) {
+            // The four steps per output word as ONE hand-written block with its own loop (a lone wave pays for every instruction it issues).
+            // Round 5: ONE LDS round trip on the path from a state to the next instead of two. The second level of the search is read as
+            // (cum[k], cum[k + 1]) per lane (two reads in flight together), every lane of the state's sixteen computes the new state from ITS
+            // pair, the one lane whose pair holds the slot keeps it (lane l with l + ffbh(mask) == 31) and four rotate-and-or moves inside the
+            // row of sixteen (DPP row_ror 1 / 2 / 4 / 8) hand it to the others: the read of cum[sym], cum[sym + 1] that waited for the symbol is
+            // gone. The slots behind a compare whose mask is read as data and behind a write that a DPP move reads hold the next things the
+            // step needs (the first-level read of the coming step, the collected word), s_nop only where nothing is left.
+            // v254:v255 = the 64-bit scratch of the two mask shifts and of the window shift (named, so that its halves can be addressed).
+#define KNZ_A1_STEP(SHIFT, EXTRA) \
+            "v_and_b32_e32 %[slot], 0x7ff, %[st]\n\t" \
+            "s_waitcnt lgkmcnt(0)\n\t"                     /* the first-level value */ \
+            "v_cmp_ge_u32_e32 vcc, %[slot], %[c1]\n\t" \
+            "v_mad_u32_u24 %[basel], %[ctx], %[k514], %[cumL]\n\t"      /* &cum[ctx][16 * 31 + l] */ \
+            "s_add_u32 %[cnt], %[cnt], %[wds]\n\t"                       /* the words the step before took */ \
+            "v_lshrrev_b64 v[254:255], %[sh], vcc\n\t" \
+            "v_ffbh_u32_sdwa v254, v254 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t" \
+            "v_mad_i32_i24 %[adr], v254, %[m32], %[basel]\n\t"          /* group 31 - clz: 32 bytes per group */ \
+            "ds_read_u16 %[c2], %[adr]\n\t"                              /* cum[k], k = 16 group + l */ \
+            "ds_read_u16 %[c2h], %[adr] offset:2\n\t"                    /* cum[k + 1] */ \
+            "s_and_b32 %[s0], %[cnt], 0xfff\n\t"                         /* under that round trip: this step's renormalisation window ... */ \
+            "v_lshl_add_u32 %[adr], %[s0], 1, %[payA]\n\t" \
+            "ds_read_b64 %[win], %[adr]\n\t" \
+            "v_lshrrev_b32_e32 %[hi11], 11, %[st]\n\t"                   /* ... and what else does not wait for the pair */ \
+            "v_mad_i32_i24 %[g16], v254, -16, %[c527]\n\t"              /* 16 (31 - clz) + 31 */ \
+            "s_waitcnt lgkmcnt(1)\n\t"                                   /* the pair (the window behind it may still be on its way) */ \
+            "v_cmp_ge_u32_e32 vcc, %[slot], %[c2]\n\t" \
+            "v_sub_u32_e32 %[fr], %[c2h], %[c2]\n\t"                     /* this lane's frequency ... */ \
+            "v_sub_u32_e32 %[slot], %[slot], %[c2]\n\t"                  /* ... and slot - cum[k] */ \
+            "v_lshrrev_b64 v[254:255], %[sh], vcc\n\t" \
+            "v_ffbh_u32_sdwa v254, v254 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t" \
+            "v_sub_u32_e32 %[ctx], %[g16], v254\n\t"                    /* the symbol = the next context */ \
+            "v_cmp_eq_u32_e32 vcc, %[l31], v254\n\t"                     /* the lane whose pair holds the slot: l = popc - 1 = 31 - ffbh */ \
+            "v_min_u32_e32 %[fr], 0x7ff, %[fr]\n\t"                      /* decSymbol.reset :972-977 */ \
+            "v_mad_u32_u24 %[fr], %[fr], %[hi11], %[slot]\n\t"           /* freq (st >> 11) + slot - cum (:846-858), right in that lane only */ \
+            "v_cndmask_b32_e32 %[st], 0, %[fr], vcc\n\t" \
+            "v_lshl_add_u32 %[adr], %[ctx], 5, %[l1L]\n\t" \
+            "ds_read_u16 %[c1], %[adr]\n\t"                              /* first level of the coming step */ \
+            "v_or_b32_dpp %[st], %[st], %[st] row_ror:1 row_mask:0xf bank_mask:0xf\n\t" \
+            "v_lshl_or_b32 %[acc], %[ctx], " SHIFT ", %[acc]\n\t" \
+            EXTRA                                                        /* the second of the two slots in front of the next DPP move */ \
+            "v_or_b32_dpp %[st], %[st], %[st] row_ror:2 row_mask:0xf bank_mask:0xf\n\t" \
+            "s_nop 1\n\t" \
+            "v_or_b32_dpp %[st], %[st], %[st] row_ror:4 row_mask:0xf bank_mask:0xf\n\t" \
+            "s_nop 1\n\t" \
+            "v_or_b32_dpp %[st], %[st], %[st] row_ror:8 row_mask:0xf bank_mask:0xf\n\t" \
+            "v_cmp_gt_u32_e32 vcc, %[thr], %[st]\n\t"                   /* which states renormalise */ \
+            "s_and_b64 s[100:101], vcc, %[m15]\n\t"                     /* one bit per state, in the top lane of its sixteen (s100:s101 named: its halves are operands) */ \
+            "s_bcnt1_i32_b64 %[wds], s[100:101]\n\t" \
+            "v_mbcnt_lo_u32_b32 v254, s100, 0\n\t"                      /* states in the lanes below that renormalise = words in front of this state's */ \
+            "v_mbcnt_hi_u32_b32 v254, s101, v254\n\t" \
+            "v_lshlrev_b32_e32 v254, 4, v254\n\t" \
+            "s_waitcnt lgkmcnt(1)\n\t"                                   /* the window (the coming step's first-level value may still be on its way) */ \
+            "v_lshrrev_b64 v[254:255], v254, %[win]\n\t" \
+            "v_perm_b32 v254, %[st], v254, %[sel]\n\t" \
+            "v_cndmask_b32_e32 %[st], %[st], v254, vcc\n\t"
+            uint32_t slot, basel, hi11, g16, adr, c2, c2h, fr, accv, c1v, s0, wds = 0, n4 = wave_uniform(t4), cntw = wave_uniform(cnt2 >> 1);
+            uint64_t winv;
+            uint32_t obp = knz_lds_addr(&s_ob[g][0]);
+            const uint32_t cumA = knz_lds_addr(s_cum), cumL = cumA + 2u * (uint32_t)l + 992u, l1L = knz_lds_addr(s_l1) + 2u * (uint32_t)l, payA = knz_lds_addr(s_pay);
+            asm volatile(
+                "v_lshl_add_u32 %[adr], %[ctx], 5, %[l1L]\n\t"
+                "ds_read_u16 %[c1], %[adr]\n"
+                ".Lknz_a1d_loop_%=:\n\t"
+                "v_mov_b32_e32 %[acc], 0\n\t"
+                KNZ_A1_STEP("0", "s_nop 0\n\t") KNZ_A1_STEP("8", "s_nop 0\n\t") KNZ_A1_STEP("16", "s_nop 0\n\t")
+                KNZ_A1_STEP("24", "ds_write_b32 %[obp], %[acc]\n\t")              /* the collected word leaves in a slot that would be empty */
+                "v_add_u32_e32 %[obp], 4, %[obp]\n\t"
+                "s_sub_u32 %[n4], %[n4], 1\n\t"
+                "s_cmp_lg_u32 %[n4], 0\n\t"
+                "s_cbranch_scc1 .Lknz_a1d_loop_%=\n\t"
+                "s_add_u32 %[cnt], %[cnt], %[wds]\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : [st] "+v"(st), [ctx] "+v"(ctx), [cnt] "+s"(cntw), [obp] "+v"(obp), [n4] "+s"(n4), [wds] "+s"(wds),
+                  [slot] "=&v"(slot), [basel] "=&v"(basel), [hi11] "=&v"(hi11), [g16] "=&v"(g16), [adr] "=&v"(adr), [c2] "=&v"(c2), [c2h] "=&v"(c2h), [fr] "=&v"(fr),
+                  [acc] "=&v"(accv), [c1] "=&v"(c1v), [win] "=&v"(winv), [s0] "=&s"(s0)
+                : [sh] "v"(sh), [cumL] "v"(cumL), [l1L] "v"(l1L), [payA] "v"(payA), [l31] "v"(31u - (uint32_t)l), [thr] "s"(1u << 15), [sel] "s"(0x05040100u),
+                  [k514] "s"(2u * KNZ_ANS1_CUM_STRIDE), [m32] "s"(-32), [c527] "s"(527u), [m15] "s"(0x8000800080008000ull)
+                : "vcc", "scc", "v254", "v255", "s100", "s101", "memory");
+            cnt2 = 2 * cntw;
+#undef KNZ_A1_STEP
+            c1 = s_l1[16 * ctx + l];
+            win = load_win(cnt2);
+            acc = 0;
+        } else
+        if (t4 != 0 && a.plain_loop == 2) {
+            // (round 3-4's block, kept for A/B and cross-check: KNZ_ANS1_LOHI_LDS. Two LDS round trips per step: the second level, then cum[sym], cum[sym + 1])
             // The same four steps per output word as ONE hand-written block with its own loop (a lone wave pays for every instruction it
             // issues: no s_nop - the two slots behind each compare whose mask is read as data hold the next things the step needs - and
             // three instructions less address arithmetic per step than the compiler's schedule of the lambda above). LDS reads in flight
@@ -957,7 +1043,7 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
             "s_and_b32 %[s0], %[cnt], 0xfff\n\t" \
             "v_lshl_add_u32 %[adr], %[s0], 1, %[payA]\n\t" \
             "ds_read_b64 %[win], %[adr]\n\t"
-            uint32_t slot, base, basel, hi11, g16, adr, c2, lohi, accv, c1v, s0, n4 = t4, cntw = cnt2 >> 1;
+            uint32_t slot, base, basel, hi11, g16, adr, c2, lohi, accv, c1v, s0, n4 = wave_uniform(t4), cntw = wave_uniform(cnt2 >> 1);
             uint64_t winv;
             uint32_t obp = knz_lds_addr(&s_ob[g][0]);
             const uint32_t cumA = knz_lds_addr(s_cum), cumL = cumA + 2u * (uint32_t)l + 992u, l1L = knz_lds_addr(s_l1) + 2u * (uint32_t)l, payA = knz_lds_addr(s_pay);
