@@ -887,17 +887,22 @@ def check_ans1_table_decoder(be):
         check_entropy_encode(be, "ANS1")
     finally:
         del os.environ["KNZ_ANS1_TABLE_DECODER"]
-    # the LDS decoder's loop exists twice on the device: a hand-written gfx950 block (default) and the compiler's schedule of the same steps
-    # (KNZ_ANS1_PLAIN; the only one the emulator runs): both against the oracle on ragged chunk lengths (tiles of 256 steps + tails of 1..3)
-    for plain in (False, True):
-        if plain:
-            os.environ["KNZ_ANS1_PLAIN"] = "1"
+    # the LDS decoder's loop exists three times on the device: a hand-written gfx950 block with one LDS round trip per step (default: the pair of the
+    # second level, the state computed in every lane, a DPP hand-over inside the state's sixteen lanes), round 4's block with two (KNZ_ANS1_LOHI_LDS) and
+    # the compiler's schedule of the same steps (KNZ_ANS1_PLAIN; the only one the emulator runs): all against the oracle on ragged chunk lengths
+    # (tiles of 256 steps + tails of 1..3)
+    for form in (None, "KNZ_ANS1_PLAIN", "KNZ_ANS1_LOHI_LDS"):
+        if form == "KNZ_ANS1_LOHI_LDS" and be.name != "gpu":
+            continue
+        if form:
+            os.environ[form] = "1"
         try:
             for n in (3 * 65536 + 777, 4 * 1024 + 1, 4 * 1024 + 2, 4 * 1024 + 3, 1021):
                 check_stream(be, "NONE", "ANS1", 1 << 16, n)
             check_stream(be, "BWT+RANK+ZRLT", "ANS1", 1 << 18, (1 << 18) + 12345)
         finally:
-            os.environ.pop("KNZ_ANS1_PLAIN", None)
+            if form:
+                os.environ.pop(form, None)
 
 
 def check_huffman_split_walk(be):
