@@ -416,6 +416,11 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--no-host-hook", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
     args = ap.parse_args()
+    if args.handles:
+        # several handles = several streams: the HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues and
+        # kernels of streams that share a queue run one after the other. libknz_gpu asks for 32 when it is loaded (unless the host chose a value); under
+        # this harness torch brings the HIP runtime up first, so the same request is made here, before that
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
     import torch
     import torch.distributed as dist
