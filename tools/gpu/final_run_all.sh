@@ -1,3 +1,4 @@
+# round 5, final state (one gpurun call): all bench configurations, kernel trace of the default one, differential fuzz with fresh seeds, the whole GPU suite
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 O=gpurun_out/r05_final; mkdir -p $O
 python bench.py > $O/config_bwt_bench.json 2> $O/bwt.err
@@ -8,5 +9,6 @@ python bench.py --config ans0 > $O/config_ans0_bench.json 2> $O/ans0.err
 rocprofv3 --kernel-trace --stats -d $O/prof -- python bench.py --steps 3 --warmup 1 --no-pmc --no-cpu-baseline --no-host-hook --no-verify > $O/prof_bench.json 2> $O/prof.err
 DB=$(find $O/prof -name "*.db" | head -1); python tools/rocpd_summary.py $DB $O/config4_kernel_stats.md > /dev/null 2>&1
 rm -rf $O/prof
-python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/gpu_suite.log
-tail -3 $O/gpu_suite.log
+timeout 400 python tools/gpu/ext_fuzz.py 240 5000 > $O/ext_fuzz.log 2>&1
+timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/gpu_suite.log
+tail -2 $O/ext_fuzz.log; tail -3 $O/gpu_suite.log; for f in bwt l5 lz huffman ans0; do cut -c1-160 $O/config_${f}_bench.json; done
