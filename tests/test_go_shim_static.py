@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools", "go2cpp"))
 import goparse  # noqa: E402
 
-GO_FILES = ["gpu_batch.go", "gpu_transform.go", "gpu_entropy.go"]
+GO_FILES = ["gpu_batch.go", "gpu_transform.go", "gpu_entropy.go", "testhooks/gpu_hooks_entropy_test.go", "testhooks/gpu_hooks_transform_test.go"]   # (the files that import "C")
 
 
 def _walk(n, fn):
@@ -71,3 +71,10 @@ def test_go_shim_parses_and_matches_the_c_header():
     enc = [t for t, ms in methods.items() if {"Write", "BitStream", "Dispose"} <= ms]
     dec = [t for t, ms in methods.items() if {"Read", "BitStream", "Dispose"} <= ms]
     assert enc and dec, methods
+
+
+def test_every_go_file_of_the_shim_parses():
+    """gpu_stream.go and the io test hook do not import "C" (they go through gpu_batch.go): they must still parse with the translator's Go parser"""
+    for f in ("gpu_stream.go", "testhooks/gpu_hooks_io_test.go"):
+        ast = goparse.parse_file(os.path.join(ROOT, "go", f))
+        assert ast.package == "io" and len(ast.decls) >= 3, f
