@@ -892,8 +892,8 @@ def check_ans1_table_decoder(be):
     # the compiler's schedule of the same steps (KNZ_ANS1_PLAIN; the only one the emulator runs): all against the oracle on ragged chunk lengths
     # (tiles of 256 steps + tails of 1..3)
     for form in (None, "KNZ_ANS1_PLAIN", "KNZ_ANS1_LOHI_LDS"):
-        if form == "KNZ_ANS1_LOHI_LDS" and be.name != "gpu":
-            continue
+        if form is not None and be.name != "gpu":
+            continue                                  # (the emulator build has the compiler's loop only: one pass covers it)
         if form:
             os.environ[form] = "1"
         try:
