@@ -201,28 +201,53 @@ def cpu_baseline_reference(data, transform, entropy, bs, budget_s=14.0):
     cores = os.cpu_count() or 1
     blocks_all = [data[i:i + bs] for i in range(0, len(data), bs)]
 
-    def enc(b):
-        return R.compress(b, transform, entropy, bs, 0, jobs=1)
+    import ctypes as C
+    L = R.lib()
+    u8p = C.POINTER(C.c_uint8)
+    L.kref_compress.argtypes = [u8p, C.c_uint64, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int64, C.c_int, u8p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.kref_decompress.argtypes = [u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, C.POINTER(C.c_uint64)]
+    tr, en = transform.encode(), entropy.encode()
 
-    def dec(args):
-        s, n = args
-        return R.decompress(s, n + 64, jobs=1)
+    # Only the reference's Writer / Reader are inside the timed calls: the buffers are allocated and touched before (a fresh 6 MiB numpy buffer per call
+    # costs about as much as the Huffman codec needs for a block; rounds 1-5a timed it with the call)
+    class Job:
+        def __init__(self, b):
+            self.src = np.ascontiguousarray(b)
+            self.cap = len(b) + len(b) // 2 + (1 << 20)
+            self.out = np.ones(self.cap, dtype=np.uint8)
+            self.back = np.ones(len(b) + 64, dtype=np.uint8)
+            self.n = C.c_uint64()
+            self.m = C.c_uint64()
+
+    def enc(j):
+        rc = L.kref_compress(j.src.ctypes.data_as(u8p), len(j.src), tr, en, bs, 0, 1, len(j.src), 0, j.out.ctypes.data_as(u8p), j.cap, C.byref(j.n))
+        if rc != 0:
+            raise RuntimeError(f"oracle/_ref compress: rc {rc}")
+
+    def dec(j):
+        rc = L.kref_decompress(j.out.ctypes.data_as(u8p), j.n.value, 1, j.back.ctypes.data_as(u8p), len(j.back), C.byref(j.m))
+        if rc != 0:
+            raise RuntimeError(f"oracle/_ref decompress: rc {rc}")
 
     # one block on one thread sets the sample: about budget_s of wall clock with every core busy
+    j0 = Job(blocks_all[0])
     t0 = time.perf_counter()
-    s0 = enc(blocks_all[0])
-    dec((s0, len(blocks_all[0])))
+    enc(j0)
+    dec(j0)
     per_block = max(time.perf_counter() - t0, 1e-3)
     nblk = int(max(1, min(len(blocks_all), (budget_s / per_block) * min(cores, len(blocks_all)))))
     blocks = blocks_all[:nblk]
     nbytes = sum(len(b) for b in blocks)
     busy = min(cores, nblk)
+    jobs = [Job(b) for b in blocks]
     with ThreadPoolExecutor(max_workers=busy) as ex:
+        list(ex.map(lambda j: None, jobs))                                   # (the pool's threads exist before the clock starts)
         t0 = time.perf_counter()
-        streams = list(ex.map(enc, blocks))
+        list(ex.map(enc, jobs))
         t1 = time.perf_counter()
-        backs = list(ex.map(dec, [(s, len(b)) for s, b in zip(streams, blocks)]))
+        list(ex.map(dec, jobs))
         t2 = time.perf_counter()
+    backs = [j.back[: j.m.value].tobytes() for j in jobs]
     assert all(bk == b.tobytes() for bk, b in zip(backs, blocks))
     return {
         "value": round(nbytes / 1e6 / (t2 - t0), 2), "unit": "MB/s", "cores": busy, "kind": "reference",
