@@ -232,6 +232,8 @@ template <class T> struct Slice {
         T* q = (T*)alloc_zero((size_t)c * sizeof(T));
         // all-zero bytes ARE the zero value of integers, pointers, slices and of structs made of them; anything else (a string, a std::function, an
         // object with a vtable) is constructed in place, over the whole capacity (s[:cap(s)] may be read)
+        // (never destructed: memory goes back with the call's arena, as Go's collector would take it; a std::string that outgrew its small buffer keeps
+        // its heap block until the process ends - test infrastructure, bounded by what one call builds)
         if constexpr (!std::is_trivially_copyable_v<T>) for (int64_t i = 0; i < c; i++) new (q + i) T();
         return Slice(q, n, c);
     }
