@@ -350,7 +350,8 @@ def multi_handle_curve(K, codec_args, data, bs, ks, per_handle_blocks=51, rounds
         dec_arr, keep2 = [], []
         for r in range(rounds + 1):                           # (round 0 grows the workspaces: untimed)
             dt = run("knz_encode_blocks", enc_arr)
-            te = dt if r else None if te is None else te
+            if r and (te is None or dt < te):                 # (best of the timed rounds, as for the decode below)
+                te = dt
             if r == 0:
                 for t in range(k):
                     arr = (A._Block * per_handle_blocks)()
@@ -359,8 +360,6 @@ def multi_handle_curve(K, codec_args, data, bs, ks, per_handle_blocks=51, rounds
                     for i in range(per_handle_blocks):
                         arr[i].src = pays[i].ctypes.data; arr[i].src_len = len(pays[i]); arr[i].dst = outs[i].ctypes.data; arr[i].dst_cap = len(outs[i])
                     dec_arr.append(arr); keep2.append((pays, outs))
-            elif te is None or dt < te:
-                te = dt
             dt = run("knz_decode_blocks", dec_arr)
             if r and (td is None or dt < td):
                 td = dt
@@ -371,6 +370,59 @@ def multi_handle_curve(K, codec_args, data, bs, ks, per_handle_blocks=51, rounds
         for c in codecs:
             c.close()
     return out
+
+
+def in_process_devices_curve(K, transform, entropy, bs, data, ks, depth, rounds=2):
+    """The boundary the Go host has, over several GPUs (row e' of the round-5 verdict): ONE handle of knz_open_devices with k lanes, ONE host thread calling
+    knz_encode_blocks / knz_decode_blocks on a batch of `depth` blocks in pageable host memory (what Writer / Reader.EnableGPUDevices(devices, depth) does per
+    batch). The library cuts the batch into k contiguous balanced ranges; every lane uploads, runs and downloads its own range at the same time as the others.
+    Lane i sits on device i % (devices present): on a one-GPU box the lanes are logical devices of that GPU, on an 8-GPU box k = 8 is one lane per GPU."""
+    from kanzi_go_amd import api as A
+    L = K.load_library()
+    ndev = max(int(L.knz_device_count()), 1)
+    nb_total = (len(data) + bs - 1) // bs
+    blks = []
+    for j in range(depth):
+        b = j % nb_total
+        a = np.ascontiguousarray(data[b * bs:(b + 1) * bs])
+        blks.append(a if len(a) == bs else np.ascontiguousarray(data[:bs]))      # (a short block may only be the last of a batch: take a full one instead)
+    out = []
+    for k in ks:
+        devices = [i % ndev for i in range(k)]
+        c = K.Codec(transform, entropy, bs, devices=devices)
+        cap = int(c.L.knz_max_encoded_len(c.cfg.transform, bs)) * 2 + 262144
+        arr = (A._Block * depth)()
+        outs = [np.zeros(cap, dtype=np.uint8) for _ in range(depth)]
+        for i, a in enumerate(blks):
+            arr[i].src = a.ctypes.data; arr[i].src_len = len(a); arr[i].dst = outs[i].ctypes.data; arr[i].dst_cap = cap
+        te = td = None
+        lanes_e = lanes_d = None
+        arr2 = keep2 = None
+        for r in range(rounds + 1):                           # (round 0 grows the workspaces: untimed)
+            t0 = time.perf_counter()
+            c._chk(c.L.knz_encode_blocks(c.h, arr, depth))
+            dt = time.perf_counter() - t0
+            if r and (te is None or dt < te):
+                te, lanes_e = dt, c.lane_times()
+            if r == 0:
+                pays = [outs[i][: (arr[i].out_bits + 7) // 8].copy() for i in range(depth)]
+                backs = [np.zeros(bs + max(512, bs >> 4), dtype=np.uint8) for _ in range(depth)]
+                arr2 = (A._Block * depth)()
+                for i in range(depth):
+                    arr2[i].src = pays[i].ctypes.data; arr2[i].src_len = len(pays[i]); arr2[i].dst = backs[i].ctypes.data; arr2[i].dst_cap = len(backs[i])
+                keep2 = (pays, backs)
+            t0 = time.perf_counter()
+            c._chk(c.L.knz_decode_blocks(c.h, arr2, depth))
+            dt = time.perf_counter() - t0
+            if r and (td is None or dt < td):
+                td, lanes_d = dt, c.lane_times()
+        ok = all(bytes(keep2[1][i][: arr2[i].out_bits]) == blks[i].tobytes() for i in range(depth))
+        n = depth * bs
+        out.append({"lanes": k, "devices": devices, "blocks_per_call": depth, "encode_MBps": round(n / 1e6 / te, 1), "decode_MBps": round(n / 1e6 / td, 1),
+                    "round_trip_MBps": round(n / 1e6 / (te + td), 1), "ok": ok,
+                    "lane_ms_encode": [round(t[2], 1) for t in lanes_e], "lane_ms_decode": [round(t[2], 1) for t in lanes_d], "lane_blocks": [t[1] for t in lanes_e]})
+        c.close()
+    return {"devices_present": ndev, "curve": out}
 
 
 def pmc_traffic(argv_child, timeout_s=900):
@@ -436,12 +488,16 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, sharded encode, gather, assembly, collectives) at world size 1: "
                                                               "puts RCCL under bench.py on a one-GPU box (debug / pre-flight of the driver's multi-GPU run)")
     ap.add_argument("--handles", default="", help="e.g. 1,2,4,8: instead of the step, the multi-handle curve of the host-pointer boundary (k threads x one handle x 51 blocks per call), one JSON object")
+    ap.add_argument("--in-process-devices", default="", help="e.g. 1,2,4,8: instead of the step, the host-pointer boundary through ONE handle of knz_open_devices with k lanes "
+                                                              "(lane i on device i %% devices present: logical devices on a one-GPU box, one lane per GPU on an 8-GPU box), one JSON object")
+    ap.add_argument("--depth", type=int, default=0, help="--in-process-devices: blocks per knz_encode_blocks / knz_decode_blocks call (default: the blocks of the corpus)")
+    ap.add_argument("--corpus", default="", help="a file to use instead of the synthetic corpus (the real silesia.tar / enwik9 where a driver has them); `data` says \"file\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--no-host-hook", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
     args = ap.parse_args()
-    if args.handles:
+    if args.handles or args.in_process_devices:
         # several handles = several streams: the HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues and
         # kernels of streams that share a queue run one after the other. libknz_gpu asks for 32 when it is loaded (unless the host chose a value); under
         # this harness torch brings the HIP runtime up first, so the same request is made here, before that
@@ -492,7 +548,13 @@ def main():
     transform, entropy = args.transform or transform, args.entropy or entropy
     bs = args.block_size or bs
 
-    if corpus == "enwik":
+    if args.corpus:
+        base = np.fromfile(args.corpus, dtype=np.uint8)
+        if args.size:
+            base = base[:args.size]
+        base_size = len(base)
+        corpus_name = "file " + os.path.basename(args.corpus)
+    elif corpus == "enwik":
         base_size = args.size or 1_000_000_000
         base = bench_corpus.s_enwik(base_size)
         corpus_name = "S-enwik"
@@ -521,6 +583,15 @@ def main():
         curve = multi_handle_curve(K, (transform, entropy, bs, 0, local_rank), base, bs, ks, per_handle_blocks=per)
         print(json.dumps({"what": "knz_encode_blocks / knz_decode_blocks from k host threads, one handle each, pageable host memory, all calls at the same time",
                           "config": f"-t {transform} -e {entropy} -b {bs >> 20}m", "blocks_per_call": per, "curve": curve}), file=json_out, flush=True)
+        return
+    if args.in_process_devices:
+        ks = [int(x) for x in args.in_process_devices.split(",") if x]
+        depth = args.depth or (base_size + bs - 1) // bs * max(1, args.copies)
+        res = in_process_devices_curve(K, transform, entropy, bs, base, ks, depth)
+        res.update({"what": "ONE handle of knz_open_devices with k lanes, one host thread, knz_encode_blocks / knz_decode_blocks on `blocks_per_call` blocks in pageable host memory "
+                            "(H2D and D2H inside the timed calls); lane i on device i % devices_present",
+                    "config": f"-t {transform} -e {entropy} -b {bs >> 20}m", "corpus": corpus_name})
+        print(json.dumps(res), file=json_out, flush=True)
         return
     codec = K.Codec(transform, entropy, bs, device=local_rank, lib=lib)
 
@@ -661,10 +732,10 @@ def main():
             "value": round(size / 1e6 / (elapsed / K_), 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "u8",
-            "data": "synthetic" if not emu else "synthetic (EMULATOR TEST HARNESS on CPU: not a measurement)",
+            "data": ("file" if args.corpus else "synthetic") if not emu else "synthetic (EMULATOR TEST HARNESS on CPU: not a measurement)",
             "config": {"workload": (f"BASELINE.json configs[{cfg_idx}]" if args.config != "l5" else "kanzi-go preset -l 5 (README.md:79; not a BASELINE.json config)") +
                                    f": -t {transform} -e {entropy} -b {bs >> 20}m on {corpus_name} "
-                                   f"(one .knz stream of {size} B" + ("" if size == base_size else f" = {size // base_size} copies of {base_size} B") + ", bench_corpus.py)",
+                                   f"(one .knz stream of {size} B" + ("" if size == base_size else f" = {size // base_size} copies of {base_size} B") + (", bench_corpus.py)" if not args.corpus else ")"),
                        "blocks": nblocks, "block_size": bs,
                        "parallelism": f"contiguous block ranges over {world} GPU(s) ({','.join(str(x) for x in counts)} blocks), segments gathered to rank 0"},
             "encode_MBps": round(size / 1e6 / (t_enc / K_), 2), "decode_MBps": round(size / 1e6 / (t_dec / K_), 2),

@@ -31,9 +31,11 @@ type gpuBatch struct {
 
 // newGPUBatch opens the scheduler for the stream's configuration. transformType / entropyType are the values
 // transform.GetType and entropy.GetType return (Factory.go:289-328, EntropyCodecFactory.go:173-206).
-// skipBlocks is ctx["skipBlocks"] (the CLI's -s). The library has no CPU fallback: with no usable GPU this fails
-// and the caller keeps the goroutine path.
-func newGPUBatch(transformType uint64, entropyType uint32, blockSize int, checksumBits int, skipBlocks bool) (*gpuBatch, error) {
+// skipBlocks is ctx["skipBlocks"] (the CLI's -s). devices: nil = the current HIP device; otherwise the HIP ordinals the
+// batches fan out over, one lane each (knz_open_devices: contiguous balanced block ranges, every device copies its own
+// blocks in and out, no collective; an ordinal may be named several times: its lanes overlap each other's copies and
+// kernels). The library has no CPU fallback: with no usable GPU this fails and the caller keeps the goroutine path.
+func newGPUBatch(transformType uint64, entropyType uint32, blockSize int, checksumBits int, skipBlocks bool, devices []int) (*gpuBatch, error) {
 	var cfg C.knz_cfg
 	cfg.transform = C.uint64_t(transformType)
 	cfg.entropy = C.uint32_t(entropyType)
@@ -47,8 +49,27 @@ func newGPUBatch(transformType uint64, entropyType uint32, blockSize int, checks
 	}
 
 	b := &gpuBatch{}
+	rc := C.int(0)
 
-	if rc := C.knz_open(&cfg, &b.h); rc != 0 {
+	if len(devices) == 0 {
+		rc = C.knz_open(&cfg, &b.h)
+	} else {
+		if len(devices) > _MAX_CONCURRENCY {
+			return nil, &IOError{msg: "Too many GPU lanes", code: kanzi.ERR_INVALID_PARAM}
+		}
+
+		n := len(devices)
+		ords := (*[_MAX_CONCURRENCY]C.int32_t)(C.calloc(C.size_t(n), C.size_t(4)))[:n:n]
+		defer C.free(unsafe.Pointer(&ords[0]))
+
+		for i := range ords {
+			ords[i] = C.int32_t(devices[i])
+		}
+
+		rc = C.knz_open_devices(&cfg, &ords[0], C.int(n), &b.h)
+	}
+
+	if rc != 0 {
 		return nil, &IOError{msg: "Cannot open the GPU batch scheduler: " + C.GoString(C.knz_last_error(nil)), code: int(rc)}
 	}
 
@@ -179,6 +200,11 @@ func (b *gpuBatch) decodeBlocks(payload [][]byte, out [][]byte) ([]int, error) {
 	}
 
 	return sizes, nil
+}
+
+// GPUDeviceCount returns the number of HIP devices the library sees (0 without a usable GPU).
+func GPUDeviceCount() int {
+	return int(C.knz_device_count())
 }
 
 // gpuSupports tells whether a transform / entropy combination has a device implementation in the linked build

@@ -49,6 +49,28 @@ func gpuBatchOfReader(r *Reader) *gpuBatch {
 // NewWriterWithCtx. Returns an error (and leaves the goroutine path in place) when the stream's transform sequence or
 // entropy codec has no device implementation or no GPU can be opened: the library has no CPU fallback.
 func (this *Writer) EnableGPU() error {
+	return this.enableGPU(nil)
+}
+
+// EnableGPUDevices is EnableGPUDepth over several GPUs: `devices` are HIP ordinals (GPUDeviceCount tells how many there
+// are), every batch of `depth` blocks is cut into len(devices) contiguous balanced ranges and each device encodes its own
+// range (upload, kernels, download) at the same time as the others, inside the one knz_encode_blocks call of the batch.
+// Blocks are independent (Definitions.go:73-77): the stream written is the same for every list of devices. An ordinal
+// may be named several times: its lanes share the device and overlap each other's copies and kernels. depth <= 0 keeps
+// the Writer's `jobs`. To be called before the first Write.
+func (this *Writer) EnableGPUDevices(devices []int, depth int) error {
+	if len(devices) == 0 || len(devices) > _MAX_CONCURRENCY {
+		return &IOError{msg: "The number of GPU lanes must be in [1..64]", code: kanzi.ERR_INVALID_PARAM}
+	}
+
+	if depth <= 0 {
+		depth = this.jobs
+	}
+
+	return this.enableGPUDepth(depth, devices)
+}
+
+func (this *Writer) enableGPU(devices []int) error {
 	if gpuSupports(this.transformType, this.entropyType) == false {
 		return &IOError{msg: "No device implementation for this transform / entropy combination", code: kanzi.ERR_INVALID_CODEC}
 	}
@@ -67,7 +89,7 @@ func (this *Writer) EnableGPU() error {
 		skipBlocks, _ = v.(bool)
 	}
 
-	gb, err := newGPUBatch(this.transformType, this.entropyType, this.blockSize, checksum, skipBlocks)
+	gb, err := newGPUBatch(this.transformType, this.entropyType, this.blockSize, checksum, skipBlocks, devices)
 
 	if err != nil {
 		return err
@@ -86,6 +108,10 @@ func (this *Writer) EnableGPU() error {
 // every depth. Host memory: depth x 2 block buffers, allocated as they fill; device workspace grows with the batch and
 // the library takes a batch in halves when the device cannot hold it.
 func (this *Writer) EnableGPUDepth(depth int) error {
+	return this.enableGPUDepth(depth, nil)
+}
+
+func (this *Writer) enableGPUDepth(depth int, devices []int) error {
 	if depth < 1 || depth > 1024 {
 		return &IOError{msg: "The batch depth must be in [1..1024]", code: kanzi.ERR_INVALID_PARAM}
 	}
@@ -94,7 +120,7 @@ func (this *Writer) EnableGPUDepth(depth int) error {
 		return &IOError{msg: "The batch depth must be set before the first Write", code: kanzi.ERR_INVALID_PARAM}
 	}
 
-	if err := this.EnableGPU(); err != nil {
+	if err := this.enableGPU(devices); err != nil {
 		return err
 	}
 
@@ -125,14 +151,31 @@ func (this *Writer) DisableGPU() {
 }
 
 // processBlockGPU = Writer.processBlock with the per-block goroutines replaced by one device batch.
-func (this *Writer) processBlockGPU(gb *gpuBatch) error {
-	if err := this.writeHeader(); err != nil {
+// A panic of the shared bitstream (a failing io.Writer under it) comes back as IOError{ERR_PROCESS_BLOCK}, as from an
+// encodingTask (:735-743), and any error behind the header cancels the stream's block counter (:745-747).
+func (this *Writer) processBlockGPU(gb *gpuBatch) (err error) {
+	if err = this.writeHeader(); err != nil {
 		return err
 	}
 
 	if this.available == 0 {
 		return nil
 	}
+
+	defer func() {
+		if r := recover(); r != nil {
+			switch v := r.(type) {
+			case error:
+				err = &IOError{msg: v.Error(), code: kanzi.ERR_PROCESS_BLOCK}
+			default:
+				err = &IOError{msg: fmt.Sprint(v), code: kanzi.ERR_PROCESS_BLOCK}
+			}
+		}
+
+		if err != nil {
+			atomic.StoreInt32(&this.blockID, _CANCEL_TASKS_ID)
+		}
+	}()
 
 	data := make([][]byte, 0, this.jobs)
 	out := make([][]byte, 0, this.jobs)
@@ -162,10 +205,10 @@ func (this *Writer) processBlockGPU(gb *gpuBatch) error {
 		lengths = append(lengths, dataLength)
 	}
 
-	res, err := gb.encodeBlocks(data, lengths, out)
+	res, encErr := gb.encodeBlocks(data, lengths, out)
 
-	if err != nil {
-		return err
+	if encErr != nil {
+		return encErr
 	}
 
 	firstID := int(atomic.LoadInt32(&this.blockID))
@@ -206,16 +249,26 @@ func (this *Writer) processBlockGPU(gb *gpuBatch) error {
 // EnableGPU re-points the block batches of this Reader at the GPU batch scheduler. The stream header is read first:
 // the codecs, the block size and the checksum size come from it.
 func (this *Reader) EnableGPU() error {
+	return this.enableGPU(nil)
+}
+
+// EnableGPUDevices is EnableGPUDepth over several GPUs (see Writer.EnableGPUDevices): up to `depth` blocks are read from
+// the stream per batch and decoded on len(devices) devices side by side. depth <= 0 keeps the Reader's `jobs`.
+func (this *Reader) EnableGPUDevices(devices []int, depth int) error {
+	if len(devices) == 0 || len(devices) > _MAX_CONCURRENCY {
+		return &IOError{msg: "The number of GPU lanes must be in [1..64]", code: kanzi.ERR_INVALID_PARAM}
+	}
+
+	if depth <= 0 {
+		depth = this.jobs
+	}
+
+	return this.enableGPUDepth(depth, devices)
+}
+
+func (this *Reader) enableGPU(devices []int) error {
 	if err := this.readHeader(); err != nil {
 		return err
-	}
-
-	if _, hasKey := this.ctx["from"]; hasKey {
-		return &IOError{msg: "Block ranges are not supported on the device path", code: kanzi.ERR_INVALID_PARAM}
-	}
-
-	if _, hasKey := this.ctx["to"]; hasKey {
-		return &IOError{msg: "Block ranges are not supported on the device path", code: kanzi.ERR_INVALID_PARAM}
 	}
 
 	if gpuSupports(this.transformType, this.entropyType) == false {
@@ -230,7 +283,7 @@ func (this *Reader) EnableGPU() error {
 		checksum = 64
 	}
 
-	gb, err := newGPUBatch(this.transformType, this.entropyType, this.blockSize, checksum, false)
+	gb, err := newGPUBatch(this.transformType, this.entropyType, this.blockSize, checksum, false, devices)
 
 	if err != nil {
 		return err
@@ -245,6 +298,10 @@ func (this *Reader) EnableGPU() error {
 // EnableGPUDepth is EnableGPU with a batch depth of its own (see Writer.EnableGPUDepth): up to `depth` blocks are read
 // from the stream and decoded per device batch. To be called before the first Read.
 func (this *Reader) EnableGPUDepth(depth int) error {
+	return this.enableGPUDepth(depth, nil)
+}
+
+func (this *Reader) enableGPUDepth(depth int, devices []int) error {
 	if depth < 1 || depth > 1024 {
 		return &IOError{msg: "The batch depth must be in [1..1024]", code: kanzi.ERR_INVALID_PARAM}
 	}
@@ -253,7 +310,7 @@ func (this *Reader) EnableGPUDepth(depth int) error {
 		return &IOError{msg: "The batch depth must be set before the first Read", code: kanzi.ERR_INVALID_PARAM}
 	}
 
-	if err := this.EnableGPU(); err != nil {
+	if err := this.enableGPU(devices); err != nil {
 		return err
 	}
 
@@ -283,11 +340,29 @@ func (this *Reader) DisableGPU() {
 
 // processBlockGPU = Reader.processBlock: the payloads are read from the shared bitstream one after the other as the
 // decoding tasks do (:1816-1852), then ONE device batch replaces the concurrent part of the tasks (:1875-2011).
-// Block b of the batch is decoded into this.buffers[b].Buf, where Reader.Read picks it up.
-func (this *Reader) processBlockGPU(gb *gpuBatch) (int64, error) {
+// Block n of the blocks that are decoded is left in this.buffers[n].Buf, where Reader.Read picks it up (:1713). Blocks
+// outside ctx["from"] / ctx["to"] are read and dropped as the tasks do (:1854-1867); a batch that holds nothing else is
+// followed by the next one (:1736-1739). A panic of the shared bitstream (a truncated stream: "No more data to read in
+// the bitstream") comes back as IOError{ERR_PROCESS_BLOCK}, as from a decodingTask (:1778-1786), and every error cancels
+// the stream's block counter (:1789-1791).
+func (this *Reader) processBlockGPU(gb *gpuBatch) (decoded int64, err error) {
 	if atomic.LoadInt32(&this.blockID) == _CANCEL_TASKS_ID {
 		return 0, nil
 	}
+
+	defer func() {
+		if r := recover(); r != nil {
+			if e, ok := r.(error); ok {
+				err = &IOError{msg: e.Error(), code: kanzi.ERR_PROCESS_BLOCK}
+			} else {
+				err = &IOError{msg: "Unknown error", code: kanzi.ERR_PROCESS_BLOCK}
+			}
+		}
+
+		if err != nil {
+			atomic.StoreInt32(&this.blockID, _CANCEL_TASKS_ID)
+		}
+	}()
 
 	bufSize := this.blockSize + _EXTRA_BUFFER_SIZE
 
@@ -295,89 +370,118 @@ func (this *Reader) processBlockGPU(gb *gpuBatch) (int64, error) {
 		bufSize = this.blockSize + (this.blockSize >> 4)
 	}
 
-	payload := make([][]byte, 0, this.jobs)
-	out := make([][]byte, 0, this.jobs)
-	firstID := int(atomic.LoadInt32(&this.blockID))
-	offsets := make([]uint64, 0, this.jobs)
-	endOfStream := false
+	from, to := 0, 0x7FFFFFFF
 
-	for taskID := 0; taskID < this.jobs; taskID++ {
-		offsets = append(offsets, this.ibs.Read())
-		lr := uint(this.ibs.ReadBits(5)) + 3
-		read := this.ibs.ReadBits(lr)
+	if v, hasKey := this.ctx["from"]; hasKey {
+		from = v.(int)
+	}
 
-		if read == 0 {
-			// end of stream: nothing is decoded from here on (what the first task that reads an empty block does, :1781-1793)
-			atomic.StoreInt32(&this.blockID, _CANCEL_TASKS_ID)
-			endOfStream = true
+	if v, hasKey := this.ctx["to"]; hasKey {
+		to = v.(int)
+	}
+
+	for {
+		payload := make([][]byte, 0, this.jobs)
+		out := make([][]byte, 0, this.jobs)
+		ids := make([]int, 0, this.jobs)
+		firstID := int(atomic.LoadInt32(&this.blockID))
+		offsets := make([]uint64, 0, this.jobs)
+		endOfStream := false
+		read1 := 0
+
+		for taskID := 0; taskID < this.jobs; taskID++ {
+			blockOffset := this.ibs.Read()
+			lr := uint(this.ibs.ReadBits(5)) + 3
+			read := this.ibs.ReadBits(lr)
+
+			if read == 0 {
+				// end of stream: nothing is decoded from here on (what the first task that reads an empty block does, :1781-1793)
+				atomic.StoreInt32(&this.blockID, _CANCEL_TASKS_ID)
+				endOfStream = true
+				break
+			}
+
+			if read > uint64(1)<<34 {
+				return 0, &IOError{msg: "Invalid block size", code: kanzi.ERR_BLOCK_SIZE}
+			}
+
+			r := int((read + 7) >> 3)
+
+			if len(this.buffers[this.jobs+taskID].Buf) < r {
+				this.buffers[this.jobs+taskID].Buf = make([]byte, r)
+			}
+
+			data := this.buffers[this.jobs+taskID].Buf
+
+			// Read data from shared bitstream
+			for n := uint(0); read > 0; {
+				chkSize := uint(1 << 30)
+
+				if read < 1<<30 {
+					chkSize = uint(read)
+				}
+
+				this.ibs.ReadArray(data[n:], chkSize)
+				n += ((chkSize + 7) >> 3)
+				read -= uint64(chkSize)
+			}
+
+			atomic.AddInt32(&this.blockID, 1)
+			read1++
+			id := firstID + taskID + 1
+
+			if id < from || id >= to {
+				continue // Check if the block must be skipped (:1854-1867)
+			}
+
+			k := len(payload)
+
+			if len(this.buffers[k].Buf) < bufSize {
+				this.buffers[k].Buf = make([]byte, bufSize)
+			}
+
+			payload = append(payload, data[0:r])
+			out = append(out, this.buffers[k].Buf)
+			ids = append(ids, id)
+			offsets = append(offsets, blockOffset)
+		}
+
+		if len(payload) == 0 {
+			if endOfStream {
+				this.notifyEndGPU(firstID + read1 + 1)
+				break
+			}
+
+			if read1 != 0 {
+				continue // Unless all blocks were skipped, exit the loop (usual case) (:1736-1739)
+			}
+
 			break
 		}
 
-		if read > uint64(1)<<34 {
-			return 0, &IOError{msg: "Invalid block size", code: kanzi.ERR_BLOCK_SIZE}
+		sizes, decErr := gb.decodeBlocks(payload, out)
+
+		if decErr != nil {
+			return 0, decErr
 		}
 
-		r := int((read + 7) >> 3)
-
-		if len(this.buffers[this.jobs+taskID].Buf) < r {
-			this.buffers[this.jobs+taskID].Buf = make([]byte, r)
-		}
-
-		if len(this.buffers[taskID].Buf) < bufSize {
-			this.buffers[taskID].Buf = make([]byte, bufSize)
-		}
-
-		data := this.buffers[this.jobs+taskID].Buf
-
-		// Read data from shared bitstream
-		for n := uint(0); read > 0; {
-			chkSize := uint(1 << 30)
-
-			if read < 1<<30 {
-				chkSize = uint(read)
+		for i := range sizes {
+			if sizes[i] > this.blockSize {
+				return decoded, &IOError{msg: "Block incorrectly decompressed", code: kanzi.ERR_PROCESS_BLOCK}
 			}
 
-			this.ibs.ReadArray(data[n:], chkSize)
-			n += ((chkSize + 7) >> 3)
-			read -= uint64(chkSize)
+			decoded += int64(sizes[i])
+
+			if len(this.listeners) > 0 {
+				this.notifyBlockGPU(ids[i], payload[i], sizes[i], offsets[i])
+			}
 		}
 
-		atomic.AddInt32(&this.blockID, 1)
-		payload = append(payload, data[0:r])
-		out = append(out, this.buffers[taskID].Buf)
-	}
-
-	if len(payload) == 0 {
 		if endOfStream {
-			this.notifyEndGPU(firstID + 1)
+			this.notifyEndGPU(firstID + read1 + 1)
 		}
 
-		this.consumed = 0
-		return 0, nil
-	}
-
-	sizes, err := gb.decodeBlocks(payload, out)
-
-	if err != nil {
-		return 0, err
-	}
-
-	decoded := int64(0)
-
-	for i := range sizes {
-		if sizes[i] > this.blockSize {
-			return decoded, &IOError{msg: "Block incorrectly decompressed", code: kanzi.ERR_PROCESS_BLOCK}
-		}
-
-		decoded += int64(sizes[i])
-
-		if len(this.listeners) > 0 {
-			this.notifyBlockGPU(firstID+i+1, payload[i], sizes[i], offsets[i])
-		}
-	}
-
-	if endOfStream {
-		this.notifyEndGPU(firstID + len(payload) + 1)
+		break
 	}
 
 	this.consumed = 0

@@ -78,6 +78,24 @@ int knz_close(void* handle);
 const char* knz_last_error(void* handle);
 
 /*
+ * One handle over several devices: the `jobs`-wide goroutine fan-out of Writer.processBlock / Reader.processBlock
+ * (v2/io/CompressedStream.go:621-710, :1614-1744) becomes a fan-out over GPUs inside knz_encode_blocks / knz_decode_blocks (SURVEY 8b's
+ * device_mask, as a list). ordinals[0..n): HIP device ordinals, one LANE each (own workspace, own stream, own host worker thread), 1 <= n <= 64.
+ * An ordinal may be named several times: its lanes share the device, and the uploads / downloads of one run under the kernels of another.
+ * A batch is cut into n contiguous balanced ranges (the first nblocks % n lanes take one block more: 26 blocks over 8 lanes = 4,4,3,3,3,3,3,3);
+ * every lane copies its blocks in, runs them and copies the results straight into the caller's dst. Blocks are independent
+ * (v2/Definitions.go:73-77, io/CompressedStream.go:896-898): no collective is involved and the bytes are those of a one-device handle.
+ * Per-block status and the first failing block's error code are reported as by a one-device batch. The other entry points accept such a handle too:
+ * single-object calls run on the first lane, device-resident calls (knz_dev_*) on the lane whose device owns d_dst.
+ * cfg->device is ignored. knz_device_count() = hipGetDeviceCount (0 without a usable GPU).
+ */
+int knz_open_devices(const knz_cfg* cfg, const int32_t* ordinals, int n, void** handle);
+int knz_device_count(void);
+/* lanes behind a handle (1 for a knz_open handle) ; per lane of the last batch call: device ordinal, blocks taken, wall-clock ms (upload .. download). Returns lanes filled. */
+int knz_lane_count(void* handle);
+int knz_last_lane_times(void* handle, int32_t* devices, int32_t* blocks, float* ms, int cap);
+
+/*
  * Replaces the goroutine fan-out of Writer.processBlock (v2/io/CompressedStream.go:636-701): the n
  * buffered blocks are encoded in one device batch. For every block the result equals
  * encodingTask.encode up to obs.Close() (:729-914): dst holds mode byte .. entropy payload, out_bits the

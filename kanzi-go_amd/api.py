@@ -85,6 +85,10 @@ def load_library(path=None):
     L = C.CDLL(path)
     vp, u8p, u64p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)
     L.knz_open.argtypes = [C.POINTER(_Cfg), C.POINTER(vp)]
+    L.knz_open_devices.argtypes = [C.POINTER(_Cfg), C.POINTER(C.c_int32), C.c_int, C.POINTER(vp)]
+    L.knz_device_count.argtypes = []
+    L.knz_lane_count.argtypes = [vp]
+    L.knz_last_lane_times.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int]
     L.knz_close.argtypes = [vp]
     L.knz_last_error.argtypes = [vp]
     L.knz_last_error.restype = C.c_char_p
@@ -120,14 +124,26 @@ def _u8(a):
 class Codec:
     """One GPU batch scheduler handle (knz_open): what an io.Writer/io.Reader owns in the drop-in."""
 
-    def __init__(self, transform="NONE", entropy="NONE", block_size=4 << 20, checksum_bits=0, device=-1, lib=None, skip_blocks=False):
-        """skip_blocks = the CLI's -s / ctx["skipBlocks"] (KNZ_FLAG_SKIP_BLOCKS): incompressible blocks become copy blocks."""
+    def __init__(self, transform="NONE", entropy="NONE", block_size=4 << 20, checksum_bits=0, device=-1, lib=None, skip_blocks=False, devices=None):
+        """skip_blocks = the CLI's -s / ctx["skipBlocks"] (KNZ_FLAG_SKIP_BLOCKS): incompressible blocks become copy blocks.
+        devices = a list of HIP ordinals (knz_open_devices): one lane each, the block batches fan out over them; an ordinal may repeat."""
         self.L = load_library(lib)
         self.cfg = _Cfg(transform_type(transform), entropy_type(entropy), block_size, checksum_bits, 6, device, 1 if skip_blocks else 0)
         self.h = C.c_void_p()
-        rc = self.L.knz_open(C.byref(self.cfg), C.byref(self.h))
+        if devices is not None:
+            ords = (C.c_int32 * len(devices))(*devices)
+            rc = self.L.knz_open_devices(C.byref(self.cfg), ords, len(devices), C.byref(self.h))
+        else:
+            rc = self.L.knz_open(C.byref(self.cfg), C.byref(self.h))
         if rc:
             raise KnzError(rc, "knz_open failed: " + self.L.knz_last_error(None).decode() + " (no CPU fallback exists)")
+
+    def lane_times(self):
+        """[(device ordinal, blocks taken, wall-clock ms)] per lane of the last batch call of a knz_open_devices handle."""
+        n = self.L.knz_lane_count(self.h)
+        dev, blk, ms = (C.c_int32 * n)(), (C.c_int32 * n)(), (C.c_float * n)()
+        k = self.L.knz_last_lane_times(self.h, dev, blk, ms, n)
+        return [(int(dev[i]), int(blk[i]), float(ms[i])) for i in range(k)]
 
     def close(self):
         if self.h:

@@ -956,10 +956,10 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
             "s_nop 1\n\t" \
             "v_or_b32_dpp %[st], %[st], %[st] row_ror:8 row_mask:0xf bank_mask:0xf\n\t" \
             "v_cmp_gt_u32_e32 vcc, %[thr], %[st]\n\t"                   /* which states renormalise */ \
-            "s_and_b64 s[100:101], vcc, %[m15]\n\t"                     /* one bit per state, in the top lane of its sixteen (s100:s101 named: its halves are operands) */ \
-            "s_bcnt1_i32_b64 %[wds], s[100:101]\n\t" \
-            "v_mbcnt_lo_u32_b32 v254, s100, 0\n\t"                      /* states in the lanes below that renormalise = words in front of this state's */ \
-            "v_mbcnt_hi_u32_b32 v254, s101, v254\n\t" \
+            "s_and_b64 s[98:99], vcc, %[m15]\n\t"                     /* one bit per state, in the top lane of its sixteen (s98:s99 named: its halves are operands) */ \
+            "s_bcnt1_i32_b64 %[wds], s[98:99]\n\t" \
+            "v_mbcnt_lo_u32_b32 v254, s98, 0\n\t"                      /* states in the lanes below that renormalise = words in front of this state's */ \
+            "v_mbcnt_hi_u32_b32 v254, s99, v254\n\t" \
             "v_lshlrev_b32_e32 v254, 4, v254\n\t" \
             "s_waitcnt lgkmcnt(1)\n\t"                                   /* the window (the coming step's first-level value may still be on its way) */ \
             "v_lshrrev_b64 v[254:255], v254, %[win]\n\t" \
@@ -987,7 +987,7 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
                   [acc] "=&v"(accv), [c1] "=&v"(c1v), [win] "=&v"(winv), [s0] "=&s"(s0)
                 : [sh] "v"(sh), [cumL] "v"(cumL), [l1L] "v"(l1L), [payA] "v"(payA), [l31] "v"(31u - (uint32_t)l), [thr] "s"(1u << 15), [sel] "s"(0x05040100u),
                   [k514] "s"(2u * KNZ_ANS1_CUM_STRIDE), [m32] "s"(-32), [c527] "s"(527u), [m15] "s"(0x8000800080008000ull)
-                : "vcc", "scc", "v254", "v255", "s100", "s101", "memory");
+                : "vcc", "scc", "v254", "v255", "s98", "s99", "memory");
             cnt2 = 2 * cntw;
 #undef KNZ_A1_STEP
             c1 = s_l1[16 * ctx + l];
@@ -1031,10 +1031,10 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
             "v_min_u32_e32 %[g16], 0x7ff, %[g16]\n\t" \
             "v_mad_u32_u24 %[st], %[g16], %[hi11], %[slot]\n\t" \
             "v_cmp_gt_u32_e32 vcc, %[thr], %[st]\n\t"                   /* which states renormalise */ \
-            "s_and_b64 s[100:101], vcc, %[m15]\n\t"                     /* one bit per state, in the top lane of its sixteen (s100:s101 named: its halves are operands) */ \
-            "s_bcnt1_i32_b64 %[s0], s[100:101]\n\t" \
-            "v_mbcnt_lo_u32_b32 v254, s100, 0\n\t"                      /* states in the lanes below that renormalise = words in front of this state's */ \
-            "v_mbcnt_hi_u32_b32 v254, s101, v254\n\t" \
+            "s_and_b64 s[98:99], vcc, %[m15]\n\t"                     /* one bit per state, in the top lane of its sixteen (s98:s99 named: its halves are operands) */ \
+            "s_bcnt1_i32_b64 %[s0], s[98:99]\n\t" \
+            "v_mbcnt_lo_u32_b32 v254, s98, 0\n\t"                      /* states in the lanes below that renormalise = words in front of this state's */ \
+            "v_mbcnt_hi_u32_b32 v254, s99, v254\n\t" \
             "v_lshlrev_b32_e32 v254, 4, v254\n\t" \
             "v_lshrrev_b64 v[254:255], v254, %[win]\n\t" \
             "s_add_u32 %[cnt], %[cnt], %[s0]\n\t" \
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(64) void knz_ans1_decode_lds2_kernel(Ans1DecArgs a,
                   [acc] "=&v"(accv), [c1] "=&v"(c1v), [win] "=&v"(winv), [s0] "=&s"(s0)
                 : [sh] "v"(sh), [cumL] "v"(cumL), [cumA] "v"(cumA), [l1L] "v"(l1L), [payA] "v"(payA), [thr] "s"(1u << 15), [sel] "s"(0x05040100u),
                   [k514] "s"(2u * KNZ_ANS1_CUM_STRIDE), [m32] "s"(-32), [c527] "s"(527u), [m15] "s"(0x8000800080008000ull)
-                : "vcc", "scc", "v254", "v255", "s100", "s101", "memory");
+                : "vcc", "scc", "v254", "v255", "s98", "s99", "memory");
             cnt2 = 2 * cntw;
 #undef KNZ_A1_STEP
             c1 = s_l1[16 * ctx + l];

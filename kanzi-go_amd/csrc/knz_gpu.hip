@@ -64,12 +64,18 @@ struct DeviceGuard {
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
+// several lanes behind one handle (knz_multi.inc)
+static int multi_blocks(Handle* h, knz_block* blocks, int n, int job);
+static void multi_close(Handle* h);
+static Handle* lane0(Handle* h);
+static Handle* lane_of_pointer(Handle* h, const void* d_ptr);
+
 int knz_set_error(Handle* h, int code, const char* msg) {
     if (h) h->err = msg ? msg : "";
     return code;
 }
 
-// Workspace growth is refused while it would leave the device with less than 1/16 of its memory (4 GiB at least): a device driven to its
+// A workspace growth of 64 MiB or more is refused while it would leave the device with less than 1/16 of its memory (4 GiB at least): a device driven to its
 // last byte takes the HIP runtime down with it (queue creation aborts the process), and several handles share one device. A refused
 // growth comes back as KNZ_ERR_CREATE_COMPRESSOR / _DECOMPRESSOR; the host-pointer entry points then release the workspace and take the
 // batch in halves (knz_host_api.inc). KNZ_TEST_ALLOC_LIMIT (tests): bytes one buffer may hold.
@@ -78,15 +84,17 @@ static thread_local bool g_alloc_refused = false;
 DevBuf::DevBuf() { if (g_buf_registry) g_buf_registry->push_back(this); }
 int DevBuf::reserve(size_t n) {
     if (n <= cap) return 0;
-    if (p) hipFree(p);
-    p = nullptr; cap = 0;
-    size_t want = n + n / 8 + 256;
+    // (every check comes before the old buffer is given back: a refused growth leaves the handle as it was)
+    const size_t want = n + n / 8 + 256;
     if (const char* lim = knz_test_switch("KNZ_TEST_ALLOC_LIMIT")) { if (want > (size_t)strtoull(lim, nullptr, 10)) { g_alloc_refused = true; return -1; } }
     size_t freeB = 0, totalB = 0;
-    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB != 0) {
-        const size_t keep = std::max<size_t>(totalB / 16, (size_t)4 << 30);
-        if (want > freeB || freeB - want < std::min(keep, totalB / 2)) { g_alloc_refused = true; return -1; }
+    if (want - cap >= ((size_t)64 << 20) && hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB != 0) {   // the headroom rule is for growths that matter (>= 64 MiB)
+        const size_t keep = std::min(std::max<size_t>(totalB / 16, (size_t)4 << 30), totalB / 2);
+        const size_t avail = freeB + cap;                 // (the old buffer goes first)
+        if (want > avail || avail - want < keep) { g_alloc_refused = true; return -1; }
     }
+    if (p) hipFree(p);
+    p = nullptr; cap = 0;
     if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; (void)hipGetLastError(); g_alloc_refused = true; return -1; }
     cap = want;
     return 0;
@@ -229,6 +237,7 @@ extern "C" int knz_open(const knz_cfg* cfg, void** handle) {
 extern "C" int knz_close(void* handle) {
     Handle* h = (Handle*)handle;
     if (!h) return KNZ_OK;
+    if (h->multi) { multi_close(h); delete h; return KNZ_OK; }
     DeviceGuard dg(h);                                  // (the workspace buffers are freed by ~Handle while the device is bound)
     if (h->own_stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); h->stream = nullptr; h->own_stream = false; }
     if (h->pinned) hipHostFree(h->pinned);
@@ -244,9 +253,14 @@ extern "C" int knz_close(void* handle) {
 
 extern "C" const char* knz_last_error(void* handle) { return handle ? ((Handle*)handle)->err.c_str() : g_open_error.c_str(); }
 
+static int multi_last_timing(Handle* h, float* stage_ms, int cap);
+static int multi_last_counter(Handle* h, int id, uint64_t* value);
+
 extern "C" int knz_last_timing(void* handle, float* stage_ms, int cap) {
     Handle* h = (Handle*)handle;
     if (!h || !stage_ms) return 0;
+    if (h->multi) return multi_last_timing(h, stage_ms, cap);
+    DeviceGuard dg(h);
     if (h->ev_valid) {
         hipEventSynchronize(h->ev[KNZ_STAGE_COUNT]);
         for (int i = 0; i < KNZ_STAGE_COUNT; i++) hipEventElapsedTime(&h->stage_ms[i], h->ev[i], h->ev[i + 1]);
@@ -257,7 +271,7 @@ extern "C" int knz_last_timing(void* handle, float* stage_ms, int cap) {
 }
 
 extern "C" int knz_last_kernel_times(void* handle, char* names, int names_cap, float* ms, int cap) {
-    Handle* h = (Handle*)handle;
+    Handle* h = lane0((Handle*)handle);                  // (several lanes: the launches of the first one)
     if (!h || !names || !ms || names_cap <= 0) return 0;
     DeviceGuard dg(h);
     int n = 0, pos = 0;
@@ -276,6 +290,7 @@ extern "C" int knz_last_kernel_times(void* handle, char* names, int names_cap, f
 extern "C" int knz_last_counter(void* handle, int id, uint64_t* value) {
     Handle* h = (Handle*)handle;
     if (!h || !value || id < KNZ_COUNTER_HUF_SERIAL_CHUNKS || id > KNZ_COUNTER_STAGE_BYTES0 + 7 || (id > KNZ_COUNTER_RANK_PIPE_BLOCKS && id < KNZ_COUNTER_STAGE_BYTES0)) return KNZ_ERR_INVALID_PARAM;
+    if (h->multi) return multi_last_counter(h, id, value);
     DeviceGuard dg(h);
     *value = 0;
     if (id == KNZ_COUNTER_POST_TRANSFORM_BYTES) { *value = h->post_bytes; return KNZ_OK; }
@@ -587,7 +602,7 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
 
 extern "C" int knz_dev_compress(void* handle, const void* d_src, uint64_t n, int64_t header_input_size, void* d_dst,
                                 uint64_t dst_cap, uint64_t* out_bytes, void* hip_stream) {
-    Handle* h = (Handle*)handle;
+    Handle* h = lane_of_pointer((Handle*)handle, d_dst);
     if (!h || !d_dst || !out_bytes || (!d_src && n)) return KNZ_ERR_MISSING_PARAM;
     DeviceGuard dg(h);
     if (((uintptr_t)d_dst & 3) || ((uintptr_t)d_src & 15)) return knz_set_error(h, KNZ_ERR_INVALID_PARAM, "d_src must be 16-byte and d_dst 4-byte aligned");
@@ -601,7 +616,7 @@ extern "C" int knz_dev_compress(void* handle, const void* d_src, uint64_t n, int
 
 extern "C" int knz_dev_compress_blocks(void* handle, const void* d_src, uint64_t n, void* d_dst, uint64_t dst_cap,
                                        uint64_t* out_bits, void* hip_stream) {
-    Handle* h = (Handle*)handle;
+    Handle* h = lane_of_pointer((Handle*)handle, d_dst);
     if (!h || !d_dst || !out_bits || (!d_src && n)) return KNZ_ERR_MISSING_PARAM;
     DeviceGuard dg(h);
     if (((uintptr_t)d_dst & 3) || ((uintptr_t)d_src & 15)) return knz_set_error(h, KNZ_ERR_INVALID_PARAM, "d_src must be 16-byte and d_dst 4-byte aligned");
@@ -614,3 +629,4 @@ extern "C" int knz_dev_compress_blocks(void* handle, const void* d_src, uint64_t
 }
 
 #include "knz_host_api.inc"
+#include "knz_multi.inc"

@@ -33,8 +33,11 @@ struct DevBuf {
 #define KNZ_MAX_PROBES 128
 struct KernelProbe { const char* name = nullptr; hipEvent_t a = nullptr, b = nullptr; };
 
+struct MultiDev;                      // several lanes (devices, or streams of one device) behind one handle: knz_multi.inc
+
 struct Handle {
     knz_cfg cfg;
+    MultiDev* multi = nullptr;        // != nullptr: a handle of knz_open_devices(); the batch calls fan out over its lanes, the workspace below stays empty
     KernelProbe probes[KNZ_MAX_PROBES];
     int nprobes = 0;
     uint64_t stage_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // bytes that entered transform stage i of the last encode batch (knz_last_counter 8 + i)

@@ -12,7 +12,7 @@
 // Memory: ZRLT stream = the decoder's output in region 1; ranks go to region 3 (zero-filled before: only literals are scattered); the decoded
 // symbols go to region 2, where the regular inverse RANK of a block that took two stages would have left them two stages later.
 // Anything this wave does not like (a stream no encoder writes: 0xFF 0xFF, a run of more than 31 digits, output beyond the block's region, a
-// producer that does not move) leaves piped[b] = 0: the regular stage kernels then take the block from the decoder's untouched output.
+// producer that does not move for 250 ms) leaves piped[b] = 0: the regular stage kernels then take the block from the decoder's untouched output.
 #pragma once
 
 struct RankPipeArgs {
@@ -34,6 +34,7 @@ struct RankPipeArgs {
     uint32_t group_sel;
 };
 #define KNZ_PIPE_DONE 0xFFFFFFFFFFFFFFFFull
+#define KNZ_PIPE_GIVE_UP_TICKS 25000000ull   // 250 ms of the 100 MHz counter
 #define KNZ_PIPE_PIECE 2048u          // input bytes per expansion step: 32 per lane
 
 // one piece [lo, hi) of the ZRLT stream (hi - lo <= 2048, lo a multiple of 2048): returns the ranks it produced, or 0xFFFFFFFF to decline.
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(128) void knz_zrlti_rank_pipe_kernel(RankPipeArgs a
     if (wave == 1) {
         // ---------------------------------------------------------------- the expander
         uint32_t inPos = 0, outPos = 0, cv = 1, cL = 0, lastByte = 0, fenced = 0, idle = 0;
+        uint64_t idleSince = 0;
         KNZ_PIPE_T(unsigned long long tFirst = 0, tDone = 0;)
         while (inPos < m) {
             // contiguous prefix of the stream that is there: whole chunks that are done + the first quarter of the one in flight
@@ -188,8 +190,10 @@ __global__ __launch_bounds__(128) void knz_zrlti_rank_pipe_kernel(RankPipeArgs a
                 if (lane == 0) s_ready = outPos;
                 idle = 0;
             } else {
+                if (idle++ == 0) idleSince = knz_realtime();
                 wg_spin_pause();
-                if (++idle > (1u << 24)) { if (lane == 0) s_state = KNZ_PIPE_DECLINED; return; }   // (~ seconds: a producer that does not move)
+                // a producer that has not moved for a quarter of a second of wall clock (its workgroup is queued behind a full device): hand the block back
+                if ((idle & 63u) == 0 && knz_realtime() - idleSince > KNZ_PIPE_GIVE_UP_TICKS) { if (lane == 0) s_state = KNZ_PIPE_DECLINED; return; }
             }
         }
         agent_fence_release();

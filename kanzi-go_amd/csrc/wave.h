@@ -162,6 +162,8 @@ __device__ __forceinline__ void wg_fence_acquire() { __builtin_amdgcn_fence(__AT
 __device__ __forceinline__ void knz_publish64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint64_t knz_poll64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wg_spin_pause() { __builtin_amdgcn_s_sleep(16); }
+// constant 100 MHz counter (s_memrealtime): wall-clock bounds for polls that wait on ANOTHER kernel
+__device__ __forceinline__ uint64_t knz_realtime() { return __builtin_amdgcn_s_memrealtime(); }
 // memory that only ONE workgroup touches during a kernel (a block's private hash table): workgroup-scope relaxed atomics are served by
 // the XCD's own L2; agent scope on this multi-XCD part goes to the memory side (~1 us per access, measured on the LZ parse)
 // the lanes of a wave issue their memory operations together, in program order: nothing to do on the device. (The emulator runs
@@ -198,6 +200,7 @@ inline void wg_fence_acquire() {}
 inline void knz_publish64(uint64_t* p, uint64_t v) { *(volatile uint64_t*)p = v; }
 inline uint64_t knz_poll64(const uint64_t* p) { return *(const volatile uint64_t*)p; }
 inline void wg_spin_pause() { hipemu::spin_pause(); }
+inline uint64_t knz_realtime() { static uint64_t t = 0; return t += 1000; }   // (kernels run one after the other here: nothing ever waits on another one)
 inline void wave_order_lanes() { hipemu::wave_barrier(); }
 inline int32_t knz_wg_load_i32(const int32_t* p) { return *(const volatile int32_t*)p; }
 inline int32_t knz_agent_load_i32(const int32_t* p) { return *(const volatile int32_t*)p; }

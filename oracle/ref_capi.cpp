@@ -253,7 +253,7 @@ struct EventRecorder : kz_kanzi::Listener {
     }
 };
 static int g_record_verbosity = -1;          // < 0: no listener
-static std::string g_event_log;
+static thread_local std::string g_event_log;   // (per calling thread: bench.py's CPU baseline runs many of these calls side by side)
 extern "C" void kref_record_events(int verbosity) { g_record_verbosity = verbosity; g_event_log.clear(); }
 extern "C" uint64_t kref_event_log(char* dst, uint64_t cap) {
     if (dst && cap) { size_t k = std::min<size_t>(g_event_log.size(), (size_t)cap - 1); memcpy(dst, g_event_log.data(), k); dst[k] = 0; }
@@ -295,11 +295,16 @@ int kref_compress(const uint8_t* src, uint64_t n, const char* transform, const c
 }
 
 // io.NewReader(is, jobs), or io.NewReaderWithCtx with ctx["verbosity"] when events are being recorded
+// kref_decode_range(from, to): ctx["from"] / ctx["to"] of the readers opened from now on (block ids, first block = 1; the CLI's --from / --to); < 0 = key absent
+static int g_from = -1, g_to = -1;
+extern "C" void kref_decode_range(int from, int to) { g_from = from; g_to = to; }
 static std::tuple<kz_io::Reader*, go::error> open_reader(MemStream* ms, uint32_t jobs) {
-    if (g_record_verbosity < 0) return kz_io::NewReader(ms, go::Uint(go::U(jobs ? jobs : 1)));
+    if (g_record_verbosity < 0 && g_from < 0 && g_to < 0) return kz_io::NewReader(ms, go::Uint(go::U(jobs ? jobs : 1)));
     Ctx ctx = go::make_map<go::String, go::any>();
     ctx[go::String("jobs")] = go::any(go::Uint(go::U(jobs ? jobs : 1)));
-    ctx[go::String("verbosity")] = go::any(go::Uint(go::U(g_record_verbosity)));
+    if (g_from >= 0) ctx[go::String("from")] = go::any(go::Int(go::U(g_from)));
+    if (g_to >= 0) ctx[go::String("to")] = go::any(go::Int(go::U(g_to)));
+    if (g_record_verbosity >= 0) ctx[go::String("verbosity")] = go::any(go::Uint(go::U(g_record_verbosity)));
     return kz_io::NewReaderWithCtx(ms, ctx);
 }
 
@@ -338,6 +343,17 @@ int kref_decompress(const uint8_t* src, uint64_t n, uint32_t jobs, uint8_t* dst,
 // kref_gpu_depth(n): from now on the two calls below ask for a batch depth of their own (Writer / Reader.EnableGPUDepth, go/gpu_stream.go); 0 = `jobs` blocks per batch
 static int g_gpu_depth = 0;
 extern "C" void kref_gpu_depth(int depth) { g_gpu_depth = depth; }
+// kref_gpu_lanes(n): from now on the two calls below open the scheduler over n lanes (Writer / Reader.EnableGPUDevices with n times ordinal 0: logical
+// devices on the one GPU of the box); 0 = the one-device handle of EnableGPU / EnableGPUDepth
+static int g_gpu_lanes = 0;
+extern "C" void kref_gpu_lanes(int lanes) { g_gpu_lanes = lanes; }
+extern "C++" template <class W> go::error enable_gpu(W* w) {
+    if (g_gpu_lanes > 0) {
+        go::Slice<go::Int> devs = go::Slice<go::Int>::make(g_gpu_lanes, g_gpu_lanes);   // (all zero: ordinal 0)
+        return w->EnableGPUDevices(devs, go::Int(go::U(g_gpu_depth)));
+    }
+    return g_gpu_depth > 0 ? w->EnableGPUDepth(go::Int(go::U(g_gpu_depth))) : w->EnableGPU();
+}
 
 // The Go host with its block batches re-pointed at the GPU batch scheduler: io.NewWriterWithCtx + Writer.EnableGPU (go/gpu_stream.go), `jobs` blocks per
 // device batch. Same arguments and result as kref_compress.
@@ -359,7 +375,7 @@ int kref_gpu_compress(const uint8_t* src, uint64_t n, const char* transform, con
     if (err != nullptr) return fail(err, 1);
     EventRecorder rec;
     if (g_record_verbosity >= 0) w->AddListener(&rec);
-    go::error gerr = g_gpu_depth > 0 ? w->EnableGPUDepth(go::Int(go::U(g_gpu_depth))) : w->EnableGPU();
+    go::error gerr = enable_gpu(w);
     if (gerr != nullptr) return fail(gerr, 5);
     auto [wr, werr] = w->Write(copy_in(src, n));
     go::error cerr = werr != nullptr ? werr : w->Close();
@@ -383,7 +399,7 @@ int kref_gpu_decompress(const uint8_t* src, uint64_t n, uint32_t jobs, uint8_t* 
     EventRecorder rec;
     if (g_record_verbosity >= 0) r->AddListener(&rec);
     struct KeepLog { EventRecorder& r; ~KeepLog() { g_event_log = r.log; } } keep{rec};
-    go::error gerr = g_gpu_depth > 0 ? r->EnableGPUDepth(go::Int(go::U(g_gpu_depth))) : r->EnableGPU();
+    go::error gerr = enable_gpu(r);
     if (gerr != nullptr) return fail(gerr, 5);
     go::Slice<go::Byte> buf = go::Slice<go::Byte>::make(1 << 20, 1 << 20);
     uint64_t total = 0;

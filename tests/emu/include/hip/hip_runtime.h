@@ -64,6 +64,9 @@ inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+struct hipPointerAttribute_t { int device; };
+inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) { a->device = 0; return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }

@@ -39,6 +39,9 @@ def main():
                 assert got_r == want_r, (transform, entropy, n, jobs, "Reader events", [(a, b) for a, b in zip(got_r, want_r) if a != b][:3], len(got_r), len(want_r))
                 cases += 1
             L.kref_gpu_depth(0)
+    # several lanes behind the one handle of a Writer / Reader (EnableGPUDevices), block ranges, damaged streams
+    cases += T.check_lanes(L, [("BWT+RANK+ZRLT", "ANS1", 1 << 13, 64), ("LZ", "HUFFMAN", 1 << 14, 0)], lambda bs: (1, 5 * bs + 321, 21 * bs), (1, 2, 3, 8), ((16, 0), (3, 128)))
+    cases += T.check_ranges_and_damage(L, [("NONE", "HUFFMAN", 1 << 13, 32)], lanes_list=(0, 2))
     print(f"go shim on the emulator: {cases} cases ok")
 
 

@@ -208,6 +208,20 @@ func MapsAndStrings() (int, bool, int, byte, string, int) {
 	return m["a"] + v + missing, ok, len(s), s[1], fmt.Sprintf("%d-%s", p.a+q.a, "x"), len(m)
 }
 
+// x.(T) on an element of a map of interfaces is an assertion on the element (kanzi-go: ctx["from"].(int), io/CompressedStream.go:1150): an int is an
+// int and not a uint, a missing key is a nil interface and asserts to nothing
+func MapAsserts() (int, bool, bool, bool) {
+	ctx := make(map[string]any)
+	ctx["from"] = 3
+	ctx["jobs"] = uint(4)
+	a, okA := ctx["from"].(int)
+	_, okB := ctx["jobs"].(int)
+	_, okC := ctx["to"].(int)
+	v := ctx["from"]
+	b, _ := v.(int)
+	return a + b, okA, okB, okC
+}
+
 type counter struct {
 	n    int
 	hist [3]int

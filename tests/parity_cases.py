@@ -167,6 +167,42 @@ def check_block_batch(be, transform, entropy, block_size, nblocks, last_len):
     c.close()
 
 
+def check_multi_device_batch(be, transform, entropy, block_size, nblocks, last_len, lanes, checksum_bits=0):
+    """knz_open_devices: the batch hook fanned out over `lanes` lanes (io/CompressedStream.go:621-710 over GPUs instead of goroutines). The lanes are
+    logical devices on ordinal 0 (one GPU box / the emulator): partition into contiguous balanced ranges, a ragged last range, lanes without blocks.
+    Every block must carry the bytes, bit count, mode, post-transform length and skip flags the oracle's encodingTask.encode gives, whatever the
+    number of lanes; decode through the same handle must give the blocks back."""
+    c = K.Codec(transform, entropy, block_size, checksum_bits=checksum_bits, lib=be.lib, devices=[0] * lanes)
+    assert c.L.knz_lane_count(c.h) == lanes
+    bb = K.BlockBatch(c)
+    blocks = [corpus(block_size, 10 + i) for i in range(nblocks - 1)] + [corpus(last_len, 99)]
+    res = bb.encode(blocks)
+    took = c.lane_times()
+    q, rem = divmod(nblocks, lanes)
+    assert [t[1] for t in took] == [q + (1 if l < rem else 0) for l in range(lanes)], took     # dist.block_range's rule
+    assert all(t[0] == 0 for t in took)
+    tt, et = O.transform_type(transform), O.entropy_type(entropy)
+    for blk, (bits, written, mode, post, skip) in zip(blocks, res):
+        o = O.encode_block(blk, tt, et, checksum_bits)
+        assert written == o["written"] and bits == o["bits"]
+        assert mode == o["mode"] and post == o["post_len"] and skip == o["skip_flags"]
+    assert bb.decode([r[0] for r in res]) == blocks
+    # a damaged payload in the range of a later lane: the call fails with that block's code, the blocks of the other lanes are decoded all the same
+    if nblocks >= 2 and entropy != "NONE" and len(res[-1][0]) > 40:
+        bad = [r[0] for r in res]
+        bad[-1] = bad[-1][:1] + bytes([bad[-1][1] ^ 0xFF]) * 3 + b"\xff" * (len(bad[-1]) - 4)
+        try:
+            bb.decode(bad)
+            failed = None
+        except K.KnzError as e:
+            failed = e.code
+        assert failed, "a damaged block went through"
+    # the single-object entry points accept the handle too (first lane)
+    enc = K.EntropyEncoder(c, entropy)
+    assert enc.write(blocks[0][:5000])[0] == K.EntropyEncoder(K.Codec(transform, entropy, block_size, lib=be.lib), entropy).write(blocks[0][:5000])[0]
+    c.close()
+
+
 def check_alloc_split(be, monkeypatch):
     """A batch whose workspace the device refuses (KNZ_TEST_ALLOC_LIMIT: bytes one workspace buffer may hold) is taken in halves by
     knz_encode_blocks / knz_decode_blocks after the handle has given its workspace back: same bytes as the unrestricted batch, and an
@@ -1201,6 +1237,38 @@ def check_concurrent_handles(be, threads=8, rounds=3):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def check_deep_batches_several_handles(be, handles=4, depth=1024, bs=1 << 14, seed=3):
+    """Several handles at EnableGPUDepth-sized ANS1 batches at the same time (round-5 verdict, weak #8): the fused ZRLT / RANK chain keeps two polling
+    waves per block resident, and their number is bounded per DEVICE (KNZ_PIPE_DEVICE_BLOCKS): a handle that finds the budget spent takes the regular
+    stage kernels. Every handle must get its blocks back, whichever path each batch took; together the handles may not have more than the budget piped."""
+    import threading
+    blocks = [corpus(bs, seed + (i % 37)) for i in range(depth)]
+    enc = K.Codec("BWT+RANK+ZRLT", "ANS1", bs, lib=be.lib)
+    pays = [r[0] for r in K.BlockBatch(enc).encode(blocks)]
+    enc.close()
+    codecs = [K.Codec("BWT+RANK+ZRLT", "ANS1", bs, lib=be.lib) for _ in range(handles)]
+    errors, piped = [], [0] * handles
+
+    def work(t):
+        try:
+            for _ in range(2):
+                back = K.BlockBatch(codecs[t]).decode(pays)
+                assert back == blocks, (t, "decoded blocks differ")
+                piped[t] = codecs[t].last_counter(6)
+        except Exception as e:                       # noqa: BLE001 - reported below with the thread number
+            errors.append((t, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(handles)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for c in codecs:
+        c.close()
+    assert not errors, errors
+    return piped
 
 
 def check_skip_blocks(be, light=False):

@@ -3,7 +3,7 @@ the language rules the kanzi-go sources lean on (shifts >= width, wrap-around, a
 division, slices as views with append / copy / 3-index semantics, arrays as values, parallel assignment, shadowing, named results, switch / fallthrough /
 labelled break and continue / goto, defer order, recover of string and runtime panics through a type switch, structural interfaces, closures, maps as
 references whose reads do not insert, strings as bytes, calls inside one expression run left to right, function-local and anonymous struct types, map literals, per-iteration range
-variables under closures, type assertions on non-empty interfaces). It is translated and compiled here (g++), and every result must be the value Go gives."""
+variables under closures, type assertions on non-empty interfaces and on elements of maps of interfaces). It is translated and compiled here (g++), and every result must be the value Go gives."""
 import os
 import subprocess
 import sys
@@ -31,6 +31,7 @@ int main() {
     { auto [a, b, c] = Interfaces(); std::printf("ifaces "); p(a.v); ps(b); p(c.v); std::printf("\n"); }
     { auto [a, b, c, d, e, f, g, h] = Values(go::Uint(go::U(40))); std::printf("values "); p(a.v); p(b.v); p(c.v); p(d.v); p(e.v); p(f.v); pu(g.v); p(h.v); std::printf("\n"); }
     { auto [a, ok, n, c, s, l] = MapsAndStrings(); std::printf("maps "); p(a.v); p(ok ? 1 : 0); p(n.v); pu(c.v); ps(s); p(l.v); std::printf("\n"); }
+    { auto [a, okA, okB, okC] = MapAsserts(); std::printf("mapassert "); p(a.v); p(okA ? 1 : 0); p(okB ? 1 : 0); p(okC ? 1 : 0); std::printf("\n"); }
     { auto [a, l1, b, l2, l3, xy, l4] = CallOrder(); std::printf("order "); p(a.v); p(l1.v); p(b.v); p(l2.v); p(l3.v); p(xy.v); p(l4.v); std::printf("\n"); }
     { auto [a, b, c, d, e, f] = TableDriven(); std::printf("table "); p(a.v); p(b.v); p(c.v); p(d.v); p(e ? 1 : 0); ps(f); std::printf("\n"); }
     { std::printf("formats "); ps(Formats()); std::printf("\n"); }
@@ -55,6 +56,7 @@ deferred 101 [error:runtime error:]
 ifaces 37 [rs] 5
 values 11 11 111 7 41 303 4294967295 1099511627776
 maps 7 0 6 195 [51-x] 1
+mapassert 6 1 0 0
 order 7 123 463 4567 1234055 89 89
 table 620 21 221 34 0 [xyb]
 formats [[00011111] [abcdef] [FF] [ -42] [7 ] [-0042] ["hi"] [3] [50%]]

@@ -56,13 +56,79 @@ def gpu_compress(L, data, transform, entropy, bs, ck=0, jobs=16, skip=False):
     return out[: n.value].tobytes()
 
 
-def gpu_decompress(L, stream, cap, jobs=16):
+def gpu_decompress(L, stream, cap, jobs=16, may_fail=False):
     a, p = _buf(stream)
     out = np.zeros(max(cap, 1), dtype=np.uint8)
     n = C.c_uint64()
     rc = L.kref_gpu_decompress(p, len(stream), jobs, out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n))
+    if may_fail and rc != 0:
+        return None
     assert rc == 0, (rc, L.kref_last_error())
     return out[: n.value].tobytes()
+
+
+def ref_decompress_or_none(stream, cap, jobs=1):
+    try:
+        return R.decompress(stream, cap, jobs=jobs)
+    except Exception:   # noqa: BLE001 (the reference's Reader returned an error)
+        return None
+
+
+def check_lanes(L, cfgs, sizes, lanes_list, jobs_depth):
+    """Writer / Reader.EnableGPUDevices (go/gpu_stream.go, knz_open_devices): the batches fan out over K lanes (K logical devices on ordinal 0). The
+    stream the reference's Writer writes is the stream it writes without any device, whatever K, `jobs` and the batch depth; its Reader reads it back."""
+    cases = 0
+    for transform, entropy, bs, ck in cfgs:
+        for n in sizes(bs):
+            data = P.corpus(n, seed=n % 89)
+            want = R.compress(data, transform, entropy, bs, ck) if R.available() else O.compress(data, transform, entropy, bs, ck)
+            try:
+                for lanes in lanes_list:
+                    L.kref_gpu_lanes(lanes)
+                    for jobs, depth in jobs_depth:
+                        L.kref_gpu_depth(depth)
+                        assert gpu_compress(L, data, transform, entropy, bs, ck, jobs=jobs) == want, (transform, entropy, n, lanes, jobs, depth, "stream")
+                        assert gpu_decompress(L, want, n + 64, jobs=jobs) == data, (transform, entropy, n, lanes, jobs, depth, "decode")
+                        cases += 1
+            finally:
+                L.kref_gpu_lanes(0)
+                L.kref_gpu_depth(0)
+    return cases
+
+
+def check_ranges_and_damage(L, cfgs, lanes_list=(0,)):
+    """ctx["from"] / ctx["to"] on the device path (io/CompressedStream.go:1854-1867: blocks outside the range are read and dropped) and streams that end too
+    early or carry damaged framing: the Reader over the device returns what the reference's Reader returns, an error where it returns an error, and
+    the process lives (the shared bitstream's panics are recovered in processBlockGPU as in decodingTask.decode, :1778-1786)."""
+    cases = 0
+    for transform, entropy, bs, ck in cfgs:
+        n = 6 * bs + 77
+        data = P.corpus(n, seed=5)
+        stream = R.compress(data, transform, entropy, bs, ck)
+        for lanes in lanes_list:
+            L.kref_gpu_lanes(lanes)
+            try:
+                for frm, to in ((2, 4), (1, 2), (3, 100), (5, 5), (7, 8), (-1, 3), (4, -1)):
+                    R.lib().kref_decode_range(frm, to)
+                    L.kref_decode_range(frm, to)
+                    for jobs in (1, 2, 16):
+                        want = R.decompress(stream, n + 64, jobs=jobs)
+                        lo, hi = max(frm, 1), (to if to >= 0 else 100)
+                        assert want == b"".join(data[(b - 1) * bs: b * bs] for b in range(lo, min(hi, 8))), (frm, to, jobs, "reference itself")
+                        assert gpu_decompress(L, stream, n + 64, jobs=jobs) == want, (transform, entropy, frm, to, jobs, lanes)
+                        cases += 1
+            finally:
+                R.lib().kref_decode_range(-1, -1)
+                L.kref_decode_range(-1, -1)
+            for cut in (len(stream) - 1, len(stream) - 40, len(stream) // 2, 30, 24):
+                bad = stream[:cut]
+                for jobs in (1, 16):
+                    want = ref_decompress_or_none(bad, n + 64, jobs=jobs)
+                    got = gpu_decompress(L, bad, n + 64, jobs=jobs, may_fail=True)
+                    assert (got is None) == (want is None), (transform, entropy, cut, jobs, lanes, "error or not", got is None, want is None)
+                    cases += 1
+            L.kref_gpu_lanes(0)
+    return cases
 
 
 @pytest.mark.parametrize("cfg", [("NONE", "HUFFMAN", 1 << 16, 0), ("BWT+RANK+ZRLT", "ANS1", 1 << 16, 64), ("LZ", "ANS0", 1 << 16, 32),
@@ -169,3 +235,18 @@ def test_batch_depth_of_its_own_through_the_go_shim(G):
                 assert gpu_decompress(G, want, n + 64, jobs=4) == data, (transform, entropy, depth)
         finally:
             G.kref_gpu_depth(0)
+
+
+def test_several_devices_through_the_go_shim(G):
+    """Row e' of the round-5 verdict: the GPUs behind the boundary the Go host has. K = 1, 2, 3, 8 logical devices on the one GPU of the box, `jobs` 16 and a
+    batch depth of 128, six pipelines: stream == reference stream, every time."""
+    cfgs = [("NONE", "HUFFMAN", 1 << 16, 0), ("BWT+RANK+ZRLT", "ANS1", 1 << 16, 64), ("LZ", "ANS0", 1 << 16, 32), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0", 1 << 17, 0),
+            ("BWT+RANK+ZRLT", "FPAQ", 1 << 16, 0), ("NONE", "NONE", 1 << 16, 0)]
+    n = check_lanes(G, cfgs, lambda bs: (1, 70000, 5 * bs + 4321, 40 * bs + 17, 200 * (1 << 14) + 3), (1, 2, 3, 8), ((16, 0), (3, 128)))
+    assert n == 6 * 5 * 4 * 2
+
+
+def test_block_ranges_and_damaged_streams_through_the_go_shim(G):
+    if not R.available():
+        pytest.skip("oracle/_ref is not here to say what the reference's Reader does")
+    check_ranges_and_damage(G, [("BWT+RANK+ZRLT", "ANS1", 1 << 15, 32), ("LZ", "HUFFMAN", 1 << 15, 0)], lanes_list=(0, 3))

@@ -78,3 +78,19 @@ def test_every_go_file_of_the_shim_parses():
     for f in ("gpu_stream.go", "testhooks/gpu_hooks_io_test.go"):
         ast = goparse.parse_file(os.path.join(ROOT, "go", f))
         assert ast.package == "io" and len(ast.decls) >= 3, f
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    """The C ABI is what the reference's FFI binds: every function include/knz_gpu.h declares is a dynamic symbol of the in-tree libknz_gpu.so (no compute
+    call, no GPU needed: the symbol table is read with nm)."""
+    import subprocess
+    lib = os.path.join(ROOT, "kanzi-go_amd", "libknz_gpu.so")
+    if not os.path.exists(lib):
+        import pytest
+        pytest.skip("libknz_gpu.so is not built (__graft_entry__.build())")
+    protos, _consts, _types = _header()
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    missing = sorted(set(protos) - exported)
+    assert not missing, missing
+    assert {"knz_open_devices", "knz_device_count", "knz_lane_count", "knz_last_lane_times"} <= set(protos)

@@ -48,6 +48,24 @@ def test_block_batch_hook(be):
     P.check_block_batch(be, "NONE", "ANS0", 1 << 20, 3, 33)
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 3, 8])
+def test_multi_device_batch_hook(be, lanes):
+    """knz_open_devices (row e' of the round-5 verdict): K logical devices on the one GPU of the box, through the C ABI, against the oracle block by block"""
+    P.check_multi_device_batch(be, "NONE", "HUFFMAN", 1 << 16, 7, 1234, lanes)
+    P.check_multi_device_batch(be, "NONE", "ANS0", 1 << 16, 2, 9, lanes, checksum_bits=32)
+    P.check_multi_device_batch(be, "BWT+RANK+ZRLT", "ANS1", 1 << 18, 26, 77777, lanes, checksum_bits=64)
+    P.check_multi_device_batch(be, "LZ", "ANS0", 1 << 20, 11, 4321, lanes)
+    P.check_multi_device_batch(be, "TEXT+UTF+BWT+RANK+ZRLT", "ANS0", 1 << 17, 9, 100000, lanes)
+
+
+@pytest.mark.timeout(900)
+def test_deep_batches_on_several_handles(be):
+    piped = P.check_deep_batches_several_handles(be, handles=4, depth=1024)
+    assert sum(1 for v in piped if v) <= 4 and max(piped) <= 1024
+    piped = P.check_deep_batches_several_handles(be, handles=4, depth=256)          # 4 x 256 = the whole budget: every batch may take the fused chain
+    assert all(v <= 256 for v in piped)
+
+
 @pytest.mark.parametrize("ranks", [1, 2, 8])
 def test_multi_gpu_assemble_single_device(be, ranks):
     P.check_assemble(be, "HUFFMAN", 1 << 16, 5 * (1 << 16) + 777, ranks)

@@ -72,6 +72,10 @@ inline go_unsafe::Pointer calloc(size_t n, size_t sz) { return go_unsafe::Pointe
 inline void free(go_unsafe::Pointer) {}
 
 inline int_ knz_open(knz_cfg* cfg, go_unsafe::Pointer* handle) { return int_::from_raw(::knz_open((const ::knz_cfg*)cfg, &handle->p)); }
+inline int_ knz_open_devices(knz_cfg* cfg, int32_t* ordinals, int_ n, go_unsafe::Pointer* handle) {
+    return int_::from_raw(::knz_open_devices((const ::knz_cfg*)cfg, (const ::int32_t*)ordinals, n.v, &handle->p));
+}
+inline int_ knz_device_count() { return int_::from_raw(::knz_device_count()); }
 inline int_ knz_close(go_unsafe::Pointer h) { return int_::from_raw(::knz_close(h.p)); }
 inline const char* knz_last_error(go_unsafe::Pointer h) { return ::knz_last_error(h.p); }
 inline int_ knz_encode_blocks(go_unsafe::Pointer h, knz_block* blocks, int_ n) { return int_::from_raw(::knz_encode_blocks(h.p, (::knz_block*)blocks, n.v)); }

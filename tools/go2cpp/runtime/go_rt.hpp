@@ -407,6 +407,10 @@ template <class T> [[noreturn]] inline void panic(const T& v) {
 }
 
 // `any`: holds one value of a type the ctx maps of the translated constructors use
+template <class K, class V> struct MapRef;
+struct any;
+template <class X> struct is_any_mapref : std::false_type {};
+template <class K> struct is_any_mapref<MapRef<K, any>> : std::true_type {};
 struct any {
     const std::type_info* ti = nullptr;
     std::shared_ptr<void> box;
@@ -416,7 +420,8 @@ struct any {
     template <class T, class = std::enable_if_t<!std::is_same_v<std::decay_t<T>, any> && !std::is_same_v<std::decay_t<T>, nil_t> && !std::is_same_v<std::decay_t<T>, U>>>
     any(T&& v) {
         using D = std::decay_t<T>;
-        if constexpr (std::is_convertible_v<D, error>) { ti = &typeid(error); box = std::make_shared<error>((error)v); }   // a value that implements `error` is kept as one
+        if constexpr (is_any_mapref<D>::value) { any e = v.operator any(); ti = e.ti; box = e.box; }                       // m[k] of a map of interfaces: the element, not the proxy (ctx["from"].(int))
+        else if constexpr (std::is_convertible_v<D, error>) { ti = &typeid(error); box = std::make_shared<error>((error)v); }   // a value that implements `error` is kept as one
         else { ti = &typeid(D); box = std::make_shared<D>(std::forward<T>(v)); }
     }
     friend bool operator==(const any& a, nil_t) { return a.ti == nullptr; }
