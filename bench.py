@@ -884,6 +884,19 @@ def main():
             exp = O.compress(tiled(0, size), transform, entropy, bs, 0, jobs=os.cpu_count() or 1)
             got = (d_seg if not multi else d_stream)[:C_bytes].cpu().numpy().tobytes()
             out["bit_exact_vs_oracle"] = bool(got == exp)
+            # ... and with the stream the REFERENCE's Writer writes for this very input (tests/golden/ref_streams/fullsize_manifest.json: oracle/_ref over the same
+            # corpus in the build container, by length + sha256; tools/make_ref_fullsize_vectors.py). null: no vector for this workload
+            out["bit_exact_vs_reference"] = None
+            try:
+                import hashlib
+                man = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_streams", "fullsize_manifest.json")))
+                for c in man["cases"]:
+                    if (c["transform"], c["entropy"], c["block_size"], c["input_bytes"]) == (transform, entropy, bs, size) and not args.corpus:
+                        same_input = hashlib.sha256(tiled(0, size).tobytes()).hexdigest() == c["input_sha256"]
+                        out["bit_exact_vs_reference"] = bool(same_input and len(got) == c["stream_bytes"] and hashlib.sha256(got).hexdigest() == c["sha256"])
+                        out["reference_vector"] = {"case": c["name"], "sha256": c["sha256"], "stream_bytes": c["stream_bytes"], "producer": man["producer"]}
+            except Exception as e:   # noqa: BLE001
+                out["reference_vector_error"] = str(e)
             out["parity_note"] = ("oracle = in-repo C++ restatement of kanzi-go, pinned by oracle/_ref (the reference's own .go sources translated mechanically to C++ and compiled: "
                                   "tests/test_ref_build.py, tests/test_ref_streams.py; DESIGN.md section 2)")
         if not multi and not emu and not args.no_host_hook:

@@ -102,6 +102,7 @@ int DevBuf::reserve(size_t n) {
 void DevBuf::release() { if (p) hipFree(p); p = nullptr; cap = 0; }
 static void knz_release_workspace(Handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->hstream) hipStreamSynchronize(h->hstream);
     if (h->pipe_ready) { hipStreamSynchronize(h->stream2); hipStreamSynchronize(h->stream3); }
     for (DevBuf* b : h->all_bufs) b->release();
     h->text_stat_ready = false;                      // (the static TEXT dictionary lives in one of them: uploaded again on demand)
@@ -226,6 +227,9 @@ extern "C" int knz_open(const knz_cfg* cfg, void** handle) {
     // default stream, PyTorch included, need no extra synchronisation) but not against the streams of other handles
     if (hipStreamCreateWithFlags(&h->stream, hipStreamDefault) == hipSuccess) h->own_stream = true;
     else h->stream = nullptr;
+    // ... and one for the host-pointer entry points (knz_encode_blocks, knz_decode_blocks, the single-object calls): every buffer of the caller is host
+    // memory there, so nothing has to be ordered against the NULL stream of whatever else lives in the process
+    if (hipStreamCreateWithFlags(&h->hstream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); h->hstream = nullptr; }
     for (int i = 0; i <= KNZ_STAGE_COUNT; i++) hipEventCreate(&h->ev[i]);
     h->pipe_ready = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 3; i++) if (hipEventCreateWithFlags(&h->ev_pipe[i], hipEventDisableTiming) != hipSuccess) h->pipe_ready = false;
@@ -241,8 +245,9 @@ extern "C" int knz_close(void* handle) {
     DeviceGuard dg(h);                                  // (the workspace buffers are freed by ~Handle while the device is bound)
     if (h->own_stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); h->stream = nullptr; h->own_stream = false; }
     if (h->pinned) hipHostFree(h->pinned);
-    if (h->pinned_status) hipHostFree(h->pinned_status);
-    if (h->pinned_len) hipHostFree(h->pinned_len);
+    if (h->pinned_rows) hipHostFree(h->pinned_rows);
+    if (h->hstream && h->hstream != h->stream) { hipStreamSynchronize(h->hstream); hipStreamDestroy(h->hstream); }
+    h->hstream = nullptr;
     for (int i = 0; i <= KNZ_STAGE_COUNT; i++) hipEventDestroy(h->ev[i]);
     if (h->pipe_ready) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); h->stream2 = nullptr; hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); h->stream3 = nullptr; }
     for (int i = 0; i < 3; i++) if (h->ev_pipe[i]) { hipEventDestroy(h->ev_pipe[i]); h->ev_pipe[i] = nullptr; }
@@ -379,6 +384,21 @@ __global__ void knz_enc_tables_kernel(EncTablesArgs a) {
     a.blk_skip[b] = (copy || a.none_only) ? 0x7F : 0xFF;                // NullTransform always applies: slot 0 cleared
     a.blk_status[b] = 0;
     if (a.active) { a.active[b] = (copy || a.none_only) ? 0 : 1; a.side[b] = 0; }
+}
+
+// the rows of Handle::ResultRow for the blocks of a batch, the totals (bits written, overflow flag) in the row behind the last block
+__global__ void knz_pack_results_kernel(uint32_t nblocks, const uint64_t* written, const uint64_t* cksum, const uint32_t* post_len, const int32_t* status,
+                                        const uint32_t* hdr, const uint8_t* skip, const uint64_t* totals, Handle::ResultRow* rows) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nblocks) {
+        Handle::ResultRow r;
+        r.written = written[b]; r.cksum = cksum[b]; r.post_len = post_len[b]; r.status = status[b]; r.mode = hdr[(size_t)b * 6 + 1]; r.skip = skip[b];
+        rows[b] = r;
+    } else if (b == nblocks) {
+        Handle::ResultRow r;
+        r.written = totals[0]; r.cksum = totals[1]; r.post_len = 0; r.status = 0; r.mode = 0; r.skip = 0;
+        rows[b] = r;
+    }
 }
 
 static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
@@ -579,23 +599,24 @@ static int encode_batch(Handle* h, EncodeBatch& eb, hipStream_t st) {
     hipEventRecord(h->ev[4], st);
     h->ev_valid = true;
 
-    // results come back through the handle's pinned page (truly asynchronous copies, one synchronisation): total bits, overflow flag,
-    // and the per-block status / post-transform length tables (batches beyond the page's capacity go through a pinned side buffer)
-    uint64_t* res = (uint64_t*)h->pinned;
-    HIP_OK(hipMemcpyAsync(res, h->total_bits.p, 16, hipMemcpyDeviceToHost, st));
-    if (h->reserve_pinned_tables((size_t)nblocks)) return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "pinned host allocation failed");
-    int32_t* stv = h->pinned_status;
-    uint32_t* lenv = h->pinned_len;
-    if (nblocks) HIP_OK(hipMemcpyAsync(stv, h->blk_status.p, 4 * (size_t)nblocks, hipMemcpyDeviceToHost, st));
-    if (nblocks) HIP_OK(hipMemcpyAsync(lenv, h->blk_len.p, 4 * (size_t)nblocks, hipMemcpyDeviceToHost, st));
+    // results come back packed: one row per block (bit count, checksum, post-transform length, status, mode, skip flags) and the batch totals, gathered
+    // by one small kernel and brought over by ONE asynchronous copy into pinned memory, one synchronisation
+    if (h->res_rows.reserve(sizeof(Handle::ResultRow) * ((size_t)nblocks + 1)) || h->reserve_pinned_rows((size_t)nblocks))
+        return knz_set_error(h, KNZ_ERR_CREATE_COMPRESSOR, "pinned host allocation failed");
+    hipLaunchKernelGGL(knz_pack_results_kernel, dim3((nblocks + 1 + 255) / 256), dim3(256), 0, st, nblocks, (const uint64_t*)h->blk_written.as<uint64_t>(),
+                       (const uint64_t*)h->blk_cksum.as<uint64_t>(), (const uint32_t*)h->blk_len.as<uint32_t>(), (const int32_t*)h->blk_status.as<int32_t>(),
+                       (const uint32_t*)h->blk_hdr.as<uint32_t>(), (const uint8_t*)h->blk_skip.as<uint8_t>(), (const uint64_t*)h->total_bits.as<uint64_t>(),
+                       h->res_rows.as<Handle::ResultRow>());
+    Handle::ResultRow* rows = h->pinned_rows;
+    HIP_OK(hipMemcpyAsync(rows, h->res_rows.p, sizeof(Handle::ResultRow) * ((size_t)nblocks + 1), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     HIP_OK(hipGetLastError());
-    if (res[1] != 0) return knz_set_error(h, KNZ_ERR_WRITE_FILE, "destination buffer too small");
+    if (rows[nblocks].cksum != 0) return knz_set_error(h, KNZ_ERR_WRITE_FILE, "destination buffer too small");     // (the totals row: bits, overflow flag)
     for (uint32_t b = 0; b < nblocks; b++)
-        if (stv[b] != 0) return knz_set_error(h, stv[b], "block failed (the reference panics on this input: ERR_PROCESS_BLOCK)");
-    eb.total_bits = res[0];
+        if (rows[b].status != 0) return knz_set_error(h, rows[b].status, "block failed (the reference panics on this input: ERR_PROCESS_BLOCK)");
+    eb.total_bits = rows[nblocks].written;
     h->post_bytes = 0;
-    for (uint32_t b = 0; b < nblocks; b++) h->post_bytes += lenv[b];
+    for (uint32_t b = 0; b < nblocks; b++) h->post_bytes += rows[b].post_len;
     for (int i = 0; i < 8; i++) h->stage_bytes[i] = (nblocks && cfg.transform != 0) ? ((const uint64_t*)((const uint8_t*)h->pinned + 3072))[i] : 0;
     return KNZ_OK;
 }

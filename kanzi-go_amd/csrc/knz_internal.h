@@ -46,6 +46,7 @@ struct Handle {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t hstream = nullptr;    // the stream of the host-pointer entry points: non-blocking (nothing of the caller's lives on a device stream there)
     std::string err;
     // workspace
     DevBuf blk_off, blk_len, blk_src_len, blk_skip, blk_cksum, blk_status;
@@ -81,17 +82,18 @@ struct Handle {
     DevBuf sa_keys0, sa_keys1, sa_vals0, sa_vals1, sa_rank, sa_gs, sa_head, sa_unres, sa_pos, sa_tmp, sa_links, sa_sp;
     DevBuf sa_hb, sa_tiles, sa_posl0, sa_posl1, sa_gid0, sa_gid1;   // suffix sort (bwt_sort.hip): head bits, per-tile tables, the large list
     void* pinned = nullptr;           // small pinned host area for results
-    int32_t* pinned_status = nullptr; // pinned per-block tables of the last encode batch (grow-only)
-    uint32_t* pinned_len = nullptr;
-    size_t pinned_tables_cap = 0;
-    int reserve_pinned_tables(size_t n) {
-        if (n <= pinned_tables_cap) return 0;
-        if (pinned_status) hipHostFree(pinned_status);
-        if (pinned_len) hipHostFree(pinned_len);
-        pinned_status = nullptr; pinned_len = nullptr; pinned_tables_cap = 0;
+    // results of the last encode batch, one row per block + the batch totals behind them: packed on the device (knz_pack_results_kernel), ONE copy into pinned memory
+    struct ResultRow { uint64_t written; uint64_t cksum; uint32_t post_len; int32_t status; uint32_t mode; uint32_t skip; };
+    DevBuf res_rows;
+    ResultRow* pinned_rows = nullptr; // grow-only
+    size_t pinned_rows_cap = 0;
+    int reserve_pinned_rows(size_t n) {
+        if (n + 1 <= pinned_rows_cap) return 0;
+        if (pinned_rows) hipHostFree(pinned_rows);
+        pinned_rows = nullptr; pinned_rows_cap = 0;
         const size_t want = n + n / 4 + 64;
-        if (hipHostMalloc((void**)&pinned_status, 4 * want) != hipSuccess || hipHostMalloc((void**)&pinned_len, 4 * want) != hipSuccess) return -1;
-        pinned_tables_cap = want;
+        if (hipHostMalloc((void**)&pinned_rows, sizeof(ResultRow) * want) != hipSuccess) return -1;
+        pinned_rows_cap = want;
         return 0;
     }
     std::vector<DevBuf*> all_bufs;    // every workspace buffer of this handle (filled while the handle is constructed)

@@ -182,10 +182,13 @@ def check_multi_device_batch(be, transform, entropy, block_size, nblocks, last_l
     assert [t[1] for t in took] == [q + (1 if l < rem else 0) for l in range(lanes)], took     # dist.block_range's rule
     assert all(t[0] == 0 for t in took)
     tt, et = O.transform_type(transform), O.entropy_type(entropy)
-    for blk, (bits, written, mode, post, skip) in zip(blocks, res):
+    O.set_ctx(block_size, et)                          # ctx["blockSize"] / ctx["entropy"] as the Writer hands them to its tasks (the TEXT codec reads both)
+    for i, (blk, (bits, written, mode, post, skip)) in enumerate(zip(blocks, res)):
         o = O.encode_block(blk, tt, et, checksum_bits)
-        assert written == o["written"] and bits == o["bits"]
+        assert written == o["written"], (transform, entropy, lanes, i, written, o["written"])
+        assert bits == o["bits"], (transform, entropy, lanes, i, "bytes differ", [k for k in range(min(len(bits), len(o["bits"]))) if bits[k] != o["bits"][k]][:4])
         assert mode == o["mode"] and post == o["post_len"] and skip == o["skip_flags"]
+    O.set_ctx()
     assert bb.decode([r[0] for r in res]) == blocks
     # a damaged payload in the range of a later lane: the call fails with that block's code, the blocks of the other lanes are decoded all the same
     if nblocks >= 2 and entropy != "NONE" and len(res[-1][0]) > 40:

@@ -92,11 +92,25 @@ def test_full_size_config2_properties(be):
     exp = O.compress(data, "NONE", "HUFFMAN", bs, 0, jobs=os.cpu_count() or 1)
     assert len(got) == len(exp)
     assert hashlib.sha256(got).digest() == hashlib.sha256(exp).digest()
+    ref = _reference_hash("NONE", "HUFFMAN", bs, n)
+    assert ref is not None and len(got) == ref["stream_bytes"] and hashlib.sha256(got).hexdigest() == ref["sha256"], "device stream differs from the reference Writer's"
     c.close()
 
 
+def _reference_hash(transform, entropy, bs, n):
+    """(length, sha256) of the stream the REFERENCE's Writer writes for a full-size case (tests/golden/ref_streams/fullsize_manifest.json, made by
+    tools/make_ref_fullsize_vectors.py from oracle/_ref in the build container) or None"""
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_streams", "fullsize_manifest.json")
+    for c in json.load(open(path))["cases"]:
+        if (c["transform"], c["entropy"], c["block_size"], c["input_bytes"]) == (transform, entropy, bs, n):
+            return c
+    return None
+
+
 def _full_size_stream(be, transform, entropy, bs, data):
-    """device stream == oracle stream (sha256 of both + length) and device round trip, at a BASELINE configuration's full size"""
+    """device stream == the reference's stream (length + sha256 from the committed full-size manifest) == oracle stream (sha256 of both + length), and
+    device round trip, at a BASELINE configuration's full size"""
     import hashlib
     import oracle_lib as O
     import torch
@@ -110,6 +124,10 @@ def _full_size_stream(be, transform, entropy, bs, data):
     assert c.dev_decompress(d_dst.data_ptr(), nb, d_back.data_ptr(), n + 4096) == n
     assert torch.equal(d_back[:n], d_src)
     got = d_dst[:nb].cpu().numpy().tobytes()
+    ref = _reference_hash(transform, entropy, bs, n)
+    assert ref is not None, "no reference-written vector for this full-size case"
+    assert hashlib.sha256(np.ascontiguousarray(data).tobytes()).hexdigest() == ref["input_sha256"], "the corpus generator changed: regenerate the manifest"
+    assert len(got) == ref["stream_bytes"] and hashlib.sha256(got).hexdigest() == ref["sha256"], "device stream differs from the stream the reference's Writer writes"
     exp = O.compress(data, transform, entropy, bs, 0, jobs=os.cpu_count() or 1)
     assert len(got) == len(exp)
     assert hashlib.sha256(got).digest() == hashlib.sha256(exp).digest()

@@ -126,3 +126,26 @@ def test_device_against_reference_streams():
         nd = codec.dev_decompress(rp, len(got), out, n + 4096)
         assert nd == n and be.to_host(kout, nd) == src, c["name"]
         codec.close()
+
+
+def test_full_size_reference_vectors():
+    """tests/golden/ref_streams/fullsize_manifest.json: the BASELINE configurations' full-size streams as the reference's Writer writes them (by sha256).
+    Here (CPU suite): the manifest covers configs[1..3], the -l 5 preset and configs[4]'s block shape; the corpus generator still makes the input it
+    was made from; the hand-written oracle writes the same stream for configs[1] (seconds); and, where /root/reference is present, oracle/_ref
+    regenerates that entry bit for bit (the other entries take minutes of one core each: tools/make_ref_fullsize_vectors.py, and the GPU suite compares
+    the device with every one of them)."""
+    import hashlib
+    import bench_corpus
+    import ref_lib as R
+    man = json.load(open(os.path.join(REF_DIR, "fullsize_manifest.json")))
+    cases = {c["name"]: c for c in man["cases"]}
+    assert {(c["transform"], c["entropy"], c["block_size"]) for c in man["cases"]} >= {("NONE", "HUFFMAN", 4 << 20), ("LZ", "ANS0", 4 << 20), ("BWT+RANK+ZRLT", "ANS1", 8 << 20),
+                                                                                       ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0", 4 << 20), ("BWT+RANK+ZRLT", "FPAQ", 32 << 20)}
+    c = cases["config1_huffman_4m"]
+    data = bench_corpus.s_silesia().tobytes()
+    assert len(data) == c["input_bytes"] and hashlib.sha256(data).hexdigest() == c["input_sha256"]
+    got = O.compress(data, c["transform"], c["entropy"], c["block_size"], 0, jobs=os.cpu_count() or 1)
+    assert len(got) == c["stream_bytes"] and hashlib.sha256(got).hexdigest() == c["sha256"], "oracle stream differs from the reference Writer's at full size"
+    if R.can_build():
+        ref = R.compress(data, c["transform"], c["entropy"], c["block_size"], 0, jobs=1)
+        assert len(ref) == c["stream_bytes"] and hashlib.sha256(ref).hexdigest() == c["sha256"], "oracle/_ref no longer writes the committed full-size stream"
