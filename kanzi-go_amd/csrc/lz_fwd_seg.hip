@@ -74,13 +74,15 @@ __device__ __forceinline__ uint32_t knz_lzs_query_logged(uint32_t* qc, uint32_t 
     return wave_uniform(qc[2 * cw + 1] & cb);
 }
 
-// one thread per block: does the block take part, initial entry states
-__global__ __launch_bounds__(64) void knz_lzs_init_kernel(LzSegArgs g) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+// one thread per segment (grid (ceil(segs / 256), nblocks)): does the block take part, initial entry states
+__global__ __launch_bounds__(256) void knz_lzs_init_kernel(LzSegArgs g) {
+    const uint32_t b = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
     const LzArgs& a = g.pa.a;
     if (b >= a.nblocks) return;
-    g.blk_flags[4 * b] = g.blk_flags[4 * b + 1] = g.blk_flags[4 * b + 2] = 0; g.blk_flags[4 * b + 3] = 0xFFFFFFFFu;
-    g.Sp[2 * b] = g.Sp[2 * b + 1] = g.Sn[2 * b] = g.Sn[2 * b + 1] = 0;
+    if (s == 0) {
+        g.blk_flags[4 * b] = g.blk_flags[4 * b + 1] = g.blk_flags[4 * b + 2] = 0; g.blk_flags[4 * b + 3] = 0xFFFFFFFFu;
+        g.Sp[2 * b] = g.Sp[2 * b + 1] = g.Sn[2 * b] = g.Sn[2 * b + 1] = 0;
+    }
     uint8_t st = 3;
     if (a.active[b]) {
         const int count = (int)a.in_len[b];
@@ -89,23 +91,21 @@ __global__ __launch_bounds__(64) void knz_lzs_init_kernel(LzSegArgs g) {
         knz_lzs_geom(a, b, count, srcEnd, maxDist, minMatch, flag, decline);
         // blocks the stage declines before it parses anything (:256-263, :306-308) are answered by the one-wave kernel
         st = (a.out_cap < maxEnc || count < KNZ_LZ_MIN_BLOCK || decline) ? 4 : ((((uintptr_t)a.in_ptr[b]) & 3) != 0 ? 2 : 0);
-        if (st == 0) {
+        if (st == 0 && s < g.segs) {
             const uint32_t ns = srcEnd > 0 ? ((uint32_t)srcEnd + g.seg_size - 1) / g.seg_size : 0;
-            for (uint32_t s = 0; s < g.segs; s++) {
-                const size_t si = (size_t)b * g.segs + s;
-                uint32_t* e = g.entry + 5 * si;
-                // first guess: the state right behind a match that ended `warm` positions in front of the segment, repeat distances unknown: by
-                // the time such a parse crosses into the segment it has usually met the true one (the positions it passes on the way belong to
-                // the segment in front; what it writes there is replaced in the next round, when every segment gets its real entry state)
-                const uint32_t at = s ? s * g.seg_size - min(g.warm, g.seg_size) : 0u;
-                e[0] = at; e[1] = at; e[2] = (uint32_t)count; e[3] = (uint32_t)count; e[4] = s ? 0x80000000u : 0u;
-                g.used[5 * si] = KNZ_LZS_NEVER;
-                g.ntok[si] = 0;
-                g.need[si] = s < ns ? 1 : 0;
-            }
+            const size_t si = (size_t)b * g.segs + s;
+            uint32_t* e = g.entry + 5 * si;
+            // first guess: the state right behind a match that ended `warm` positions in front of the segment, repeat distances unknown: by
+            // the time such a parse crosses into the segment it has usually met the true one (the positions it passes on the way belong to
+            // the segment in front; what it writes there is replaced in the next round, when every segment gets its real entry state)
+            const uint32_t at = s ? s * g.seg_size - min(g.warm, g.seg_size) : 0u;
+            e[0] = at; e[1] = at; e[2] = (uint32_t)count; e[3] = (uint32_t)count; e[4] = s ? 0x80000000u : 0u;
+            g.used[5 * si] = KNZ_LZS_NEVER;
+            g.ntok[si] = 0;
+            g.need[si] = s < ns ? 1 : 0;
         }
     }
-    g.blk_state[b] = st;
+    if (s == 0) g.blk_state[b] = st;
 }
 
 __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
@@ -339,6 +339,187 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
 #undef KNZ_LZS_COUNT
 #undef KNZ_LZS_NOW
 #undef KNZ_LZS_CP
+}
+
+// ---- the same parse, one LANE per segment (round 6) ---------------------------------------------------------------------------------------
+// The wave-per-segment kernel above spends a whole wave on a chain of wave-uniform steps: ~125 instructions per step on the CU's ONE scalar unit,
+// the 64-wide vector units idle (a full round over S-silesia = 156 M steps = 16-17 ms whatever the segment size). Here every lane walks a segment of
+// its own: the step's arithmetic runs on the vector units 64 segments at a time, its reads are per-lane gathers (cand[], cp8[], 4-8 source bytes at
+// the position and at the candidates), lanes that take different paths of the step serialise. Segments are short (KNZ_LZS_LANE_SEG positions)
+// so that a wave's time - its slowest lane's chain - stays small and there are thousands of waves to hide the gathers' latency. The fixed point is the
+// first one of round 3: every live segment of a block with holes runs in every round (all_again: no query log, no carried map stretches), a block has
+// settled when no entry state moved and the maps are equal. Same inputs, same outputs (entry / used / exit states, token descriptors, hole maps) and
+// the same reads of the previous generation as knz_lzs_parse_kernel: the two are interchangeable round by round (KNZ_LZS_WAVES selects the one above).
+#define KNZ_LZS_LANE_SEG 1024u
+
+__device__ __forceinline__ int knz_lz_match_lane(const uint8_t* src, int a, int b, int maxMatch) {     // findMatchLZX (:593-607): 8 bytes per step
+    int n = 0;
+    while (n + 8 <= maxMatch) {
+        const uint64_t d = knz_vle64(src + a + n) ^ knz_vle64(src + b + n);
+        if (d) return n + (int)((__ffsll((unsigned long long)d) - 1) >> 3);
+        n += 8;
+    }
+    return n;
+}
+// bits [lo, hi) of a bit map set with one atomic per word
+__device__ __forceinline__ void knz_lzs_set_bits(uint32_t* map, int lo, int hi) {
+    for (int w = lo >> 5; w <= (hi - 1) >> 5; w++) {
+        uint32_t m = 0xFFFFFFFFu;
+        if (w == (lo >> 5)) m &= 0xFFFFFFFFu << (lo & 31);
+        if (w == ((hi - 1) >> 5)) m &= 0xFFFFFFFFu >> (31 - ((hi - 1) & 31));
+        atomicOr(&map[w], m);
+    }
+}
+
+__global__ __launch_bounds__(64) void knz_lzs_parse_lanes_kernel(LzSegArgs g) {
+    const LzArgs& a = g.pa.a;
+    const uint32_t b = blockIdx.y, s = blockIdx.x * 64 + threadIdx.x;
+    if (g.blk_state[b] != 0) return;
+    if (s >= g.segs) return;
+    const size_t si = (size_t)b * g.segs + s;
+    if (!g.need[si]) return;
+    const int count = (int)a.in_len[b];
+    const uint8_t* src = (const uint8_t*)a.in_ptr[b];
+    int srcEnd, maxDist, minMatch; uint32_t hdrFlag; bool decline;
+    knz_lzs_geom(a, b, count, srcEnd, maxDist, minMatch, hdrFlag, decline);
+    const int segEnd = (int)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
+    const uint32_t* E = g.entry + 5 * si;
+    int srcIdx = (int)E[0], anchor = (int)E[1], repd0 = (int)E[2], repd1 = (int)E[3], srcInc = (int)(E[4] & 0x7FFFFFFFu), repdIdx = (int)(E[4] >> 31);
+    { uint32_t* U = g.used + 5 * si; U[0] = E[0]; U[1] = E[1]; U[2] = E[2]; U[3] = E[3]; U[4] = E[4]; }
+    const int eSrc = srcIdx, eAnchor = anchor;                                // where this segment's own knowledge of the holes begins
+    const uint32_t* cand = g.pa.cand + g.pa.gstart[b];
+    const uint8_t* cp8 = g.pa.cp8 + g.pa.gstart[b];
+    const uint32_t* Jp = g.Jp + (size_t)b * g.map_stride; const uint32_t* Mp = g.Mp + (size_t)b * g.map_stride;
+    uint32_t* Jn = g.Jn + (size_t)b * g.map_stride; uint32_t* Mn = g.Mn + (size_t)b * g.map_stride;
+    const uint32_t* Cp = g.Cp + (size_t)b * KNZ_LZS_COARSE;
+    uint32_t* Cn = g.Cn + (size_t)b * KNZ_LZS_COARSE;
+    unsigned cs = 6;
+    while (((uint32_t)count >> cs) >= 32u * KNZ_LZS_COARSE) cs++;
+    bool anyHoles = g.Sp[2 * b] != 0;
+    int maxHole = -1;                                                         // the largest position this parse jumped over
+    uint32_t ntok = 0;
+    uint4* tokOut = g.tok + si * g.tok_cap;
+    bool overflow = false;
+
+    // the hole bit of position q as knz_lzs_parse_kernel reads it: the previous generation for everything in front of the entry anchor, J of the previous
+    // generation with this trace's own M for the literal run it inherits, its own generation for what it has passed itself. (The coarse map only
+    // filters: a cell without a jumped-over position in the previous generation has no hole to report.)
+    auto is_hole = [&](int q) -> bool {
+        const uint32_t w = (uint32_t)q >> 5, m = 1u << (q & 31);
+        if (q >= eSrc) {
+            if (q > maxHole) return false;
+            const uint32_t j = (uint32_t)knz_agent_load_i32((const int32_t*)Jn + w);
+            if ((j & m) == 0) return false;
+            return ((uint32_t)knz_agent_load_i32((const int32_t*)Mn + w) & m) == 0;
+        }
+        if ((Cp[(uint32_t)q >> (cs + 5)] & (1u << (((uint32_t)q >> cs) & 31))) == 0) return false;
+        if ((Jp[w] & m) == 0) return false;
+        if (q >= eAnchor) return ((uint32_t)knz_agent_load_i32((const int32_t*)Mn + w) & m) == 0;
+        return (Mp[w] & m) == 0;
+    };
+    auto true_cand = [&](int raw) -> int {
+        int q = raw;
+        if (anyHoles) while (q > 0 && is_hole(q)) q = (int)cand[q];
+        return q;
+    };
+    auto len_from_cp = [&](int cp, int maxMatch) -> int { const int whole = maxMatch & ~7; return cp < whole ? cp : whole; };
+
+    for (;;) {
+        { const int stopAt = srcInc < 64 ? segEnd : srcEnd; if (srcIdx >= stopAt) break; }   // hand over only when not skipping
+        int bestLen = 0;
+        const int srcIdx1 = srcIdx + 1;
+        const int nextPos = srcIdx1 + (srcInc >> 6);
+        const int maxMatch = min(srcEnd - srcIdx1, KNZ_LZ_MAX_MATCH);
+        const int minRef = max(srcIdx - maxDist, 0);
+        const int refA = srcIdx1 - (repdIdx ? repd1 : repd0), refB = srcIdx1 - (repdIdx ? repd0 : repd1);
+        const uint64_t p = knz_vle64(src + srcIdx);
+        const int raw0 = (int)cand[srcIdx], cp0 = (int)cp8[srcIdx];
+        const int ref0 = true_cand(raw0);
+        int ref = refB;                                                       // (what the reference leaves in `ref` when neither repeat distance matches)
+        const uint32_t p1 = (uint32_t)(p >> 8);
+        int rep = 0;
+        if (refA > minRef && p1 == knz_vle32(src + refA)) rep = 1;
+        else if (refB > minRef && p1 == knz_vle32(src + refB)) rep = 2;
+        if (rep != 0) {
+            ref = rep == 1 ? refA : refB;
+            bestLen = knz_lz_match_lane(src, srcIdx1, ref, maxMatch);
+        }
+        if (bestLen < minMatch) {
+            ref = ref0;
+            bool found = false;
+            if (ref > minRef) {
+                const int mm = min(srcEnd - srcIdx, KNZ_LZ_MAX_MATCH);
+                if (ref == raw0 && cp0 < 255) { if (cp0 >= 4) { bestLen = len_from_cp(cp0, mm); found = bestLen >= minMatch; } }
+                else if ((uint32_t)p == knz_vle32(src + ref)) { bestLen = knz_lz_match_lane(src, srcIdx, ref, mm); found = bestLen >= minMatch; }
+            }
+            if (!found) {
+                if (nextPos > srcIdx1) {                                      // positions jumped over: not hashed until a match covers them
+                    knz_lzs_set_bits(Jn, srcIdx1, nextPos);
+                    for (uint32_t c = (uint32_t)srcIdx1 >> cs; c <= (uint32_t)(nextPos - 1) >> cs; c++) atomicOr(&Cn[c >> 5], 1u << (c & 31));
+                    atomicOr(&g.Sn[2 * b], 1u); atomicMax(&g.Sn[2 * b + 1], (uint32_t)(nextPos - 1));
+                    anyHoles = true;
+                    maxHole = max(maxHole, nextPos - 1);
+                }
+                srcIdx = nextPos;
+                srcInc++;
+                repdIdx = 0;
+                continue;
+            }
+            if (ref != srcIdx - repd0 && ref != srcIdx - repd1) {             // checkNext (:362-398)
+                {
+                    const int raw1 = (int)cand[srcIdx1], cp1 = (int)cp8[srcIdx1];
+                    const int ref1 = true_cand(raw1);
+                    if (ref1 > minRef + 1 && !(ref1 == raw1 && cp1 < 255 && cp1 < bestLen) &&
+                        knz_vle32(src + srcIdx1 + bestLen - 3) == knz_vle32(src + ref1 + bestLen - 3)) {
+                        const int bestLen1 = (ref1 == raw1 && cp1 < 255) ? len_from_cp(cp1, maxMatch) : knz_lz_match_lane(src, srcIdx1, ref1, maxMatch);
+                        if (bestLen1 >= bestLen) { ref = ref1; bestLen = bestLen1; srcIdx = srcIdx1; }
+                    }
+                }
+                if (a.extra) {
+                    const int srcIdx2 = srcIdx1 + 1;
+                    const int raw2 = (int)cand[srcIdx2], cp2 = (int)cp8[srcIdx2];
+                    const int ref2 = true_cand(raw2);
+                    const int mm2 = min(srcEnd - srcIdx2, KNZ_LZ_MAX_MATCH);
+                    if (ref2 > minRef + 2 && !(ref2 == raw2 && cp2 < 255 && cp2 < bestLen) &&
+                        knz_vle32(src + srcIdx2 + bestLen - 3) == knz_vle32(src + ref2 + bestLen - 3)) {
+                        const int bestLen2 = (ref2 == raw2 && cp2 < 255) ? len_from_cp(cp2, mm2) : knz_lz_match_lane(src, srcIdx2, ref2, mm2);
+                        if (bestLen2 >= bestLen) { ref = ref2; bestLen = bestLen2; srcIdx = srcIdx2; }
+                    }
+                }
+            }
+            {                                                                 // extend backwards (:400-405)
+                int room = min(srcIdx - anchor, ref - minRef);
+                while (room > 0 && src[srcIdx - 1] == src[ref - 1]) { bestLen++; ref--; srcIdx--; room--; }
+            }
+            if (bestLen > KNZ_LZ_MAX_MATCH) {
+                srcIdx += bestLen - KNZ_LZ_MAX_MATCH;
+                ref += bestLen - KNZ_LZ_MAX_MATCH;
+                bestLen = KNZ_LZ_MAX_MATCH;
+            }
+        } else {
+            if ((uint8_t)p == src[ref - 1] && bestLen < KNZ_LZ_MAX_MATCH) { bestLen++; ref--; }
+            else srcIdx++;
+        }
+        srcInc = 0;
+        const int dist = srcIdx - ref;
+        uint32_t tflag;
+        if (dist == repd0) tflag = 0x00;
+        else if (dist == repd1) tflag = 0x04;
+        else tflag = dist >= 65536 ? 0x18 : (dist >= 256 ? 0x10 : 0x08);
+        repd1 = repd0;
+        repd0 = dist;
+        repdIdx = 1;
+        if (ntok < g.tok_cap) { uint4 t; t.x = (uint32_t)anchor; t.y = (uint32_t)(srcIdx - anchor); t.z = (uint32_t)bestLen | (tflag << 24); t.w = (uint32_t)dist; tokOut[ntok] = t; }
+        else overflow = true;
+        ntok++;
+        anchor = srcIdx + bestLen;
+        // the reference hashes every position of the match now (:517-553): jumped-over positions under it are holes no longer
+        if (anyHoles && anchor > srcIdx + 1) knz_lzs_set_bits(Mn, srcIdx + 1, anchor);
+        srcIdx = anchor;
+    }
+    uint32_t* X = g.exit_ + 5 * si;
+    X[0] = (uint32_t)srcIdx; X[1] = (uint32_t)anchor; X[2] = (uint32_t)repd0; X[3] = (uint32_t)repd1; X[4] = (uint32_t)srcInc | ((uint32_t)repdIdx << 31);
+    g.ntok[si] = overflow ? KNZ_LZS_NEVER : ntok;
 }
 
 __device__ __forceinline__ bool knz_lzs_live(const LzSegArgs& g, uint32_t b, uint32_t s, int srcEnd) {

@@ -511,20 +511,22 @@ def check_lz_forward_forms(be, monkeypatch, big=False, segs=(256, 512, 1024)):
     the one-wave table-free parse (lz_par.hip, KNZ_LZ_ONE_WAVE) and the first form (lz.hip, KNZ_LZ_CHAIN): all three == the oracle, and the
     segment-parallel one settles on its own (KNZ_COUNTER_LZ_FWD_SERIAL_BLOCKS == 0)."""
     c = K.Codec("NONE", "NONE", 4 << 20, lib=be.lib)
-    keys = ("KNZ_LZ_SEG", "KNZ_LZ_ONE_WAVE", "KNZ_LZ_CHAIN")
+    keys = ("KNZ_LZ_SEG", "KNZ_LZ_ONE_WAVE", "KNZ_LZ_CHAIN", "KNZ_LZS_WAVES")
     for tname in ("LZ", "LZX"):
         t = K.ByteTransform(c, tname)
         tid = _TID[tname]
         for name, data in lz_forward_inputs(big):
             o = O.transform_forward(tid, data)
-            envs = [("KNZ_LZ_SEG", str(sg)) for sg in segs]
+            # the segment-parallel parse in both of its forms: one lane per segment (default since round 6) and one wave per segment (KNZ_LZS_WAVES)
+            envs = [("KNZ_LZ_SEG", str(sg)) for sg in segs] + [("KNZ_LZ_SEG", str(sg), "KNZ_LZS_WAVES", "1") for sg in segs]
             if big or tname == "LZ":
-                envs += [("KNZ_LZ_SEG", ""), ("KNZ_LZ_ONE_WAVE", "1"), ("KNZ_LZ_CHAIN", "1")]
+                envs += [("KNZ_LZ_SEG", ""), ("KNZ_LZ_SEG", "", "KNZ_LZS_WAVES", "1"), ("KNZ_LZ_ONE_WAVE", "1"), ("KNZ_LZ_CHAIN", "1")]
             for env in envs:
                 for k in keys:
                     monkeypatch.delenv(k, raising=False)
-                if env[1]:
-                    monkeypatch.setenv(*env)
+                for k, v in zip(env[0::2], env[1::2]):
+                    if v:
+                        monkeypatch.setenv(k, v)
                 g = t.forward(data)
                 assert g == o, (tname, name, env)
                 if env[0] == "KNZ_LZ_SEG":
