@@ -162,5 +162,6 @@ __device__ __forceinline__ void knz_histogram_256t_x16(const uint8_t* src, uint3
 // per-lane unaligned 8-byte / 4-byte loads (one global_load_dwordx2 / dword: gfx950 runs with unaligned access enabled)
 struct __attribute__((packed)) KnzPacked64 { uint64_t v; };
 __device__ __forceinline__ uint64_t knz_vle64(const uint8_t* p) { return ((const KnzPacked64*)p)->v; }
+struct __attribute__((packed)) KnzPacked128 { uint32_t x, y, z, w; };
 struct __attribute__((packed)) KnzPacked32 { uint32_t v; };
 __device__ __forceinline__ uint32_t knz_vle32(const uint8_t* p) { return ((const KnzPacked32*)p)->v; }

@@ -74,7 +74,7 @@ struct Handle {
     DevBuf lz_hash, lz_tk, lz_mb, lz_ml;
     DevBuf lz_k0, lz_k1, lz_v0, lz_v1, lz_cand, lz_cp, lz_holes, lz_gstart;     // second form of the LZ forward (lz_par.hip): sort buffers, candidates, common prefixes, hole bitmaps
     DevBuf lzi_geo, lzi_tokbase, lzi_ta, lzi_tb, lzi_tc, lzi_td, lzi_seg, lzi_lxg, lzi_lxc, lzi_ml, lzi_map, lzi_flag, lzi_serial;   // parallel LZ inverse (lz_inv_par.hip)
-    DevBuf lzs_state, lzs_tok, lzs_maps, lzs_misc, lzs_mask, lzs_q;     // segment-parallel LZ forward (lz_fwd_seg.hip): entry / exit states, token descriptors, hole maps, per-block tables
+    DevBuf lzs_state, lzs_tok, lzs_maps, lzs_misc, lzs_mask, lzs_q, lzs_chg;     // segment-parallel LZ forward (lz_fwd_seg.hip): entry / exit states, token descriptors, hole maps, per-block tables
     size_t lzs_n = 0;                 // blocks covered by lzs_misc's state bytes in the last LZ forward stage
     uint32_t lzs_rounds = 0;          // rounds its fixed point took
     size_t lzi_serial_n = 0;          // blocks covered by lzi_serial in the last LZ inverse stage (1 = went to the one-wave kernel)

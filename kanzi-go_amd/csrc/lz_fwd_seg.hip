@@ -53,7 +53,15 @@ struct LzSegArgs {
     uint32_t* cmap;                // [nblocks][KNZ_LZS_COARSE] the coarse cells whose map words differ between the previous round and this one
     uint8_t* qhit;                 // [nblocks][segs] qmap & cmap != 0
     unsigned long long* sprof;     // diagnostics (KNZ_LZS_PROF) or null: [nblocks][segs][4] ticks of all parses, steps / hole-chain steps / ticks of the last one
-    uint32_t all_again;            // (measurements) every live segment of a block with holes runs in every round
+    uint32_t all_again;            // every live segment of a block with holes runs in every round (the lane-per-segment parse; measurements of the other one)
+    uint32_t max_rounds;           // a block that has not settled by then goes to the one-wave kernel
+    // who has to run again when hole bits moved, found from the DATA (lane-per-segment parse; the wave-per-segment one keeps its query log): the words of the
+    // maps that differ between two rounds [knz_lzs_compare_kernel], and for every bit of them the positions that could have asked about it = the next
+    // positions with the same hash, as long as those are holes themselves [knz_lzs_mark_kernel]
+    const uint32_t* skeys; const uint32_t* svals; uint32_t total, hash_log;   // the sorted (block << hash_log | hash, global position) pairs of lz_par.hip
+    uint32_t* chg;                 // [nblocks][chg_cap] map words that moved in this round
+    uint32_t* chg_n;               // [nblocks] their number (may exceed chg_cap: then every live segment of the block runs)
+    uint32_t chg_cap;
 };
 
 __device__ __forceinline__ void knz_lzs_geom(const LzArgs& a, uint32_t b, int count, int& srcEnd, int& maxDist, int& minMatch, uint32_t& flag, bool& decline) {
@@ -344,16 +352,30 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
 // ---- the same parse, one LANE per segment (round 6) ---------------------------------------------------------------------------------------
 // The wave-per-segment kernel above spends a whole wave on a chain of wave-uniform steps: ~125 instructions per step on the CU's ONE scalar unit,
 // the 64-wide vector units idle (a full round over S-silesia = 156 M steps = 16-17 ms whatever the segment size). Here every lane walks a segment of
-// its own: the step's arithmetic runs on the vector units 64 segments at a time, its reads are per-lane gathers (cand[], cp8[], 4-8 source bytes at
-// the position and at the candidates), lanes that take different paths of the step serialise. Segments are short (KNZ_LZS_LANE_SEG positions)
-// so that a wave's time - its slowest lane's chain - stays small and there are thousands of waves to hide the gathers' latency. The fixed point is the
-// first one of round 3: every live segment of a block with holes runs in every round (all_again: no query log, no carried map stretches), a block has
-// settled when no entry state moved and the maps are equal. Same inputs, same outputs (entry / used / exit states, token descriptors, hole maps) and
-// the same reads of the previous generation as knz_lzs_parse_kernel: the two are interchangeable round by round (KNZ_LZS_WAVES selects the one above).
-#define KNZ_LZS_LANE_SEG 1024u
+// its own: the step's arithmetic runs on the vector units 64 segments at a time; what a lane reads at its position and at the two repeat candidates
+// sits in 16-byte register windows (KnzWin16), lanes that take different paths of the step serialise. Segments are short (KNZ_LZS_LANE_SEG positions)
+// so that a wave's time - its slowest lane's chain - stays small and there are thousands of waves. Measured (S-silesia, 51 x 4 MiB): a full round
+// 8-9 ms at 384 .. 2048 positions per segment (bound by vector-instruction issue over the union of the step's paths: neither wider compares nor the
+// register windows moved it), against 16-17 ms for the wave-per-segment kernel.
+// Who runs again: what the wave-per-segment form finds with its query log comes from the DATA here (knz_lzs_mark_kernel: the positions that can have
+// asked about a hole bit that moved are the next positions with its hash), and a moved entry state makes its own segment and the one in front of it
+// run, not the whole block (knz_lzs_walk_run, `guard`); the stretches of everybody else are carried. A block has settled when nobody has to run.
+// S-silesia: 7 rounds, 8.8 + 8.1 + 8.0 + 4.6 + 3.3 + 2.9 + 0.3 ms at 1024 positions, 32 ms at 768; 62 ms (6 rounds) for the wave-per-segment form.
+// Same inputs, same outputs (entry / used / exit states, token descriptors, hole maps) and the same reads of the previous generation as
+// knz_lzs_parse_kernel: the two are interchangeable (KNZ_LZS_WAVES selects the one above, with its query log).
+#define KNZ_LZS_LANE_SEG 768u
 
-__device__ __forceinline__ int knz_lz_match_lane(const uint8_t* src, int a, int b, int maxMatch) {     // findMatchLZX (:593-607): 8 bytes per step
+__device__ __forceinline__ int knz_lz_match_lane(const uint8_t* src, int a, int b, int maxMatch) {     // findMatchLZX (:593-607): 8-byte compares, two per round trip
     int n = 0;
+    while (n + 16 <= maxMatch) {
+        const KnzPacked128* pa = (const KnzPacked128*)(src + a + n);
+        const KnzPacked128* pb = (const KnzPacked128*)(src + b + n);
+        const uint32_t a0 = pa->x, a1 = pa->y, a2 = pa->z, a3 = pa->w, b0 = pb->x, b1 = pb->y, b2 = pb->z, b3 = pb->w;
+        const uint64_t d0 = ((uint64_t)(a1 ^ b1) << 32) | (a0 ^ b0), d1 = ((uint64_t)(a3 ^ b3) << 32) | (a2 ^ b2);
+        if (d0) return n + (int)((__ffsll((unsigned long long)d0) - 1) >> 3);
+        if (d1) return n + 8 + (int)((__ffsll((unsigned long long)d1) - 1) >> 3);
+        n += 16;
+    }
     while (n + 8 <= maxMatch) {
         const uint64_t d = knz_vle64(src + a + n) ^ knz_vle64(src + b + n);
         if (d) return n + (int)((__ffsll((unsigned long long)d) - 1) >> 3);
@@ -361,6 +383,46 @@ __device__ __forceinline__ int knz_lz_match_lane(const uint8_t* src, int a, int 
     }
     return n;
 }
+// 16 bytes of a byte array kept in registers: a lane walks its segment position by position, and what it reads at the position (and at the position
+// minus a repeat distance) moves with it. One 16-byte load serves the next 9-13 steps; a gather per step and array would fetch a whole cache line each
+// time (the lanes of a wave sit a segment apart), and with 200 K lanes in flight those lines do not stay in any cache: the rounds were bound by HBM.
+struct KnzWin16 {
+    uint32_t w0, w1, w2, w3; int base;
+    __device__ __forceinline__ void fill(const uint8_t* a, int pos) {
+        base = pos & ~3;
+        const KnzPacked128* q = (const KnzPacked128*)(a + base);
+        w0 = q->x; w1 = q->y; w2 = q->z; w3 = q->w;
+    }
+    __device__ __forceinline__ uint32_t dw(uint32_t k) const { return k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3)); }
+#ifdef KNZ_LZS_NO_WIN
+    __device__ __forceinline__ uint32_t get32(const uint8_t* a, int pos) { return knz_vle32(a + pos); }
+    __device__ __forceinline__ uint64_t get64(const uint8_t* a, int pos) { return knz_vle64(a + pos); }
+    __device__ __forceinline__ uint32_t get8(const uint8_t* a, int pos) { return a[pos]; }
+#else
+    __device__ __forceinline__ uint32_t get32(const uint8_t* a, int pos) {          // the 4 bytes at pos (little endian)
+        uint32_t rel = (uint32_t)(pos - base);
+        if (rel > 12u) { fill(a, pos); rel = (uint32_t)(pos - base); }
+        const uint32_t k = rel >> 2, sh = (rel & 3u) * 8u;
+        const uint32_t lo = dw(k);
+        if (sh == 0) return lo;
+        return (lo >> sh) | (dw(k + 1) << (32 - sh));
+    }
+    __device__ __forceinline__ uint64_t get64(const uint8_t* a, int pos) {          // the 8 bytes at pos
+        uint32_t rel = (uint32_t)(pos - base);
+        if (rel > 8u) { fill(a, pos); rel = (uint32_t)(pos - base); }
+        const uint32_t k = rel >> 2, sh = (rel & 3u) * 8u;
+        const uint64_t lo = (uint64_t)dw(k) | ((uint64_t)dw(k + 1) << 32);
+        if (sh == 0) return lo;
+        return (lo >> sh) | ((uint64_t)dw(k + 2) << (64 - sh));
+    }
+    __device__ __forceinline__ uint32_t get8(const uint8_t* a, int pos) {
+        uint32_t rel = (uint32_t)(pos - base);
+        if (rel > 15u) { fill(a, pos); rel = (uint32_t)(pos - base); }
+        return (dw(rel >> 2) >> ((rel & 3u) * 8u)) & 0xFFu;
+    }
+#endif
+};
+
 // bits [lo, hi) of a bit map set with one atomic per word
 __device__ __forceinline__ void knz_lzs_set_bits(uint32_t* map, int lo, int hi) {
     for (int w = lo >> 5; w <= (hi - 1) >> 5; w++) {
@@ -372,9 +434,12 @@ __device__ __forceinline__ void knz_lzs_set_bits(uint32_t* map, int lo, int hi) 
 }
 
 __global__ __launch_bounds__(64) void knz_lzs_parse_lanes_kernel(LzSegArgs g) {
+    __shared__ uint32_t s_cp[KNZ_LZS_COARSE];                                  // the block's coarse hole map of the previous generation (all lanes of a workgroup walk segments of ONE block)
     const LzArgs& a = g.pa.a;
     const uint32_t b = blockIdx.y, s = blockIdx.x * 64 + threadIdx.x;
     if (g.blk_state[b] != 0) return;
+    { const uint32_t* Cp = g.Cp + (size_t)b * KNZ_LZS_COARSE; for (uint32_t i = threadIdx.x; i < KNZ_LZS_COARSE; i += 64) s_cp[i] = Cp[i]; }
+    wave_sync();
     if (s >= g.segs) return;
     const size_t si = (size_t)b * g.segs + s;
     if (!g.need[si]) return;
@@ -391,15 +456,23 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_lanes_kernel(LzSegArgs g) {
     const uint8_t* cp8 = g.pa.cp8 + g.pa.gstart[b];
     const uint32_t* Jp = g.Jp + (size_t)b * g.map_stride; const uint32_t* Mp = g.Mp + (size_t)b * g.map_stride;
     uint32_t* Jn = g.Jn + (size_t)b * g.map_stride; uint32_t* Mn = g.Mn + (size_t)b * g.map_stride;
-    const uint32_t* Cp = g.Cp + (size_t)b * KNZ_LZS_COARSE;
     uint32_t* Cn = g.Cn + (size_t)b * KNZ_LZS_COARSE;
     unsigned cs = 6;
     while (((uint32_t)count >> cs) >= 32u * KNZ_LZS_COARSE) cs++;
     bool anyHoles = g.Sp[2 * b] != 0;
     int maxHole = -1;                                                         // the largest position this parse jumped over
+    // which stretches of its own trace hold a jumped-over position: one bit per seg_size / 32 positions behind the entry (everything further out in the
+    // last bit). The trace's own hole bits live in the maps of this generation, which it sets with device-scope atomics and has to read back past the
+    // caches (~1 us per read on this multi-XCD part): the mask answers "no hole there" for almost every question without asking memory.
+    uint64_t ownMask = 0;
+    unsigned os = 0;
+    while ((g.seg_size >> os) > 32u) os++;
     uint32_t ntok = 0;
     uint4* tokOut = g.tok + si * g.tok_cap;
     bool overflow = false;
+    KnzWin16 wS, wC, wP, wA, wB;                                              // source at the position, cand[] and cp8[] at the position, source at the two repeat candidates
+    wS.base = wC.base = wP.base = wA.base = wB.base = -0x40000000;
+    const uint8_t* cand8 = (const uint8_t*)cand;
 
     // the hole bit of position q as knz_lzs_parse_kernel reads it: the previous generation for everything in front of the entry anchor, J of the previous
     // generation with this trace's own M for the literal run it inherits, its own generation for what it has passed itself. (The coarse map only
@@ -408,11 +481,12 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_lanes_kernel(LzSegArgs g) {
         const uint32_t w = (uint32_t)q >> 5, m = 1u << (q & 31);
         if (q >= eSrc) {
             if (q > maxHole) return false;
+            if (((ownMask >> min((uint32_t)(q - eSrc) >> os, 63u)) & 1ull) == 0) return false;
             const uint32_t j = (uint32_t)knz_agent_load_i32((const int32_t*)Jn + w);
             if ((j & m) == 0) return false;
             return ((uint32_t)knz_agent_load_i32((const int32_t*)Mn + w) & m) == 0;
         }
-        if ((Cp[(uint32_t)q >> (cs + 5)] & (1u << (((uint32_t)q >> cs) & 31))) == 0) return false;
+        if ((s_cp[(uint32_t)q >> (cs + 5)] & (1u << (((uint32_t)q >> cs) & 31))) == 0) return false;
         if ((Jp[w] & m) == 0) return false;
         if (q >= eAnchor) return ((uint32_t)knz_agent_load_i32((const int32_t*)Mn + w) & m) == 0;
         return (Mp[w] & m) == 0;
@@ -432,14 +506,14 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_lanes_kernel(LzSegArgs g) {
         const int maxMatch = min(srcEnd - srcIdx1, KNZ_LZ_MAX_MATCH);
         const int minRef = max(srcIdx - maxDist, 0);
         const int refA = srcIdx1 - (repdIdx ? repd1 : repd0), refB = srcIdx1 - (repdIdx ? repd0 : repd1);
-        const uint64_t p = knz_vle64(src + srcIdx);
-        const int raw0 = (int)cand[srcIdx], cp0 = (int)cp8[srcIdx];
+        const uint64_t p = wS.get64(src, srcIdx);
+        const int raw0 = (int)wC.get32(cand8, 4 * srcIdx), cp0 = (int)wP.get8(cp8, srcIdx);
         const int ref0 = true_cand(raw0);
         int ref = refB;                                                       // (what the reference leaves in `ref` when neither repeat distance matches)
         const uint32_t p1 = (uint32_t)(p >> 8);
         int rep = 0;
-        if (refA > minRef && p1 == knz_vle32(src + refA)) rep = 1;
-        else if (refB > minRef && p1 == knz_vle32(src + refB)) rep = 2;
+        if (refA > minRef && p1 == wA.get32(src, refA)) rep = 1;
+        else if (refB > minRef && p1 == wB.get32(src, refB)) rep = 2;
         if (rep != 0) {
             ref = rep == 1 ? refA : refB;
             bestLen = knz_lz_match_lane(src, srcIdx1, ref, maxMatch);
@@ -459,6 +533,7 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_lanes_kernel(LzSegArgs g) {
                     atomicOr(&g.Sn[2 * b], 1u); atomicMax(&g.Sn[2 * b + 1], (uint32_t)(nextPos - 1));
                     anyHoles = true;
                     maxHole = max(maxHole, nextPos - 1);
+                    for (uint32_t c = min((uint32_t)(srcIdx1 - eSrc) >> os, 63u); c <= min((uint32_t)(nextPos - 1 - eSrc) >> os, 63u); c++) ownMask |= 1ull << c;
                 }
                 srcIdx = nextPos;
                 srcInc++;
@@ -467,7 +542,7 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_lanes_kernel(LzSegArgs g) {
             }
             if (ref != srcIdx - repd0 && ref != srcIdx - repd1) {             // checkNext (:362-398)
                 {
-                    const int raw1 = (int)cand[srcIdx1], cp1 = (int)cp8[srcIdx1];
+                    const int raw1 = (int)wC.get32(cand8, 4 * srcIdx1), cp1 = (int)wP.get8(cp8, srcIdx1);
                     const int ref1 = true_cand(raw1);
                     if (ref1 > minRef + 1 && !(ref1 == raw1 && cp1 < 255 && cp1 < bestLen) &&
                         knz_vle32(src + srcIdx1 + bestLen - 3) == knz_vle32(src + ref1 + bestLen - 3)) {
@@ -477,7 +552,7 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_lanes_kernel(LzSegArgs g) {
                 }
                 if (a.extra) {
                     const int srcIdx2 = srcIdx1 + 1;
-                    const int raw2 = (int)cand[srcIdx2], cp2 = (int)cp8[srcIdx2];
+                    const int raw2 = (int)wC.get32(cand8, 4 * srcIdx2), cp2 = (int)wP.get8(cp8, srcIdx2);
                     const int ref2 = true_cand(raw2);
                     const int mm2 = min(srcEnd - srcIdx2, KNZ_LZ_MAX_MATCH);
                     if (ref2 > minRef + 2 && !(ref2 == raw2 && cp2 < 255 && cp2 < bestLen) &&
@@ -487,8 +562,14 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_lanes_kernel(LzSegArgs g) {
                     }
                 }
             }
-            {                                                                 // extend backwards (:400-405)
+            {                                                                 // extend backwards (:400-405): 8 bytes per round trip
                 int room = min(srcIdx - anchor, ref - minRef);
+                while (room > 0 && ref >= 8) {
+                    const uint64_t x = knz_vle64(src + srcIdx - 8) ^ knz_vle64(src + ref - 8);
+                    const int m = min(room, x ? (int)(__clzll((long long)x) >> 3) : 8);
+                    bestLen += m; ref -= m; srcIdx -= m; room -= m;
+                    if (m < 8) { room = 0; break; }
+                }
                 while (room > 0 && src[srcIdx - 1] == src[ref - 1]) { bestLen++; ref--; srcIdx--; room--; }
             }
             if (bestLen > KNZ_LZ_MAX_MATCH) {
@@ -541,10 +622,48 @@ __device__ __forceinline__ bool knz_lzs_live(const LzSegArgs& g, uint32_t b, uin
 // (Round 4: one WAVE per block. The walk over the segments is sequential in the state it hands on, but nothing it reads depends on that state: the
 // (used, exit) pairs of 512 segments are staged in LDS by all lanes, lane 0 walks them there, the new entry states go back in rows, and the
 // "who runs" pass is one segment per lane. One thread per block did the same walk through ~15 dependent global reads per segment: 0.8 ms per round.)
-#define KNZ_LZS_RL_CHUNK 512u
+// (Round 6: with one lane per segment a block has thousands of segments and lane 0's walk was 1.7 ms per round. The walk is sequential only in the
+// state it hands on, and that state is almost always the exit of the segment in front. So every lane walks a run of consecutive segments on its
+// own, from the exit state of the segment in front of its run; lane 0 then goes over the 64 runs in order and walks again those whose real
+// input turned out to be something else (a skipping trace that ran over the border of the run). A run walked from a wrong input may have
+// forgotten traces (`used` reset) and raised `changed` for nothing: both only make segments run that did not have to.)
+// `guard`: with the maps' dependents found from the data (g.chg), a moved entry state no longer makes every live segment of the block run. What it
+// needs instead: where a segment's entry state moved (or a recorded trace died under a parse that ran over it), the maps of this round hold bits of TWO
+// traces around that border - the stale one and the one in front of it. The stale one runs again because its entry is new; the one in front of it
+// (the last live segment before it) is marked to run again as well, so that its stretch of the next generation is written afresh instead of being
+// copied, stale bits and all, from this one. A stretch is carried only when both of its borders matched, i.e. nothing overlapped it.
+struct LzsWalk { uint32_t cur[5]; bool changed, overflow; uint32_t lastLive; bool guardPrev; };
+__device__ __forceinline__ void knz_lzs_walk_run(const LzSegArgs& g, uint32_t b, uint32_t s0, uint32_t s1, int srcEnd, LzsWalk& w) {
+    for (uint32_t s = s0; s < s1; s++) {
+        const size_t si = (size_t)b * g.segs + s;
+        uint32_t* E = g.entry + 5 * si;
+        uint32_t* U = g.used + 5 * si;
+        const uint32_t* X = g.exit_ + 5 * si;
+        const uint32_t u0 = U[0], u1 = U[1], u2 = U[2], u3 = U[3], u4 = U[4];
+        for (int q = 0; q < 5; q++) E[q] = w.cur[q];
+        const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
+        bool border = false;
+        if (w.cur[0] >= segEnd) {                                                 // nothing to parse here: the state passes through
+            // A trace this segment recorded while it still had something to parse is dead now, but its bits may sit in the maps: forget the trace and
+            // have the parse that runs over it (and, without the list of moved words, every live segment) run, so that the next generation of the maps
+            // is written by live traces only.
+            if (u0 != KNZ_LZS_NEVER) { U[0] = KNZ_LZS_NEVER; w.changed = true; border = true; }
+        } else {
+            const bool same = u0 == w.cur[0] && u1 == w.cur[1] && u2 == w.cur[2] && u3 == w.cur[3] && u4 == w.cur[4];
+            if (!same) { w.changed = true; border = true; }
+            else if (g.ntok[si] == KNZ_LZS_NEVER) w.overflow = true;
+            if (u0 != KNZ_LZS_NEVER) for (int q = 0; q < 5; q++) w.cur[q] = X[q]; // exact when `same`, the best guess otherwise
+        }
+        if (border && g.chg) {
+            if (w.lastLive != KNZ_LZS_NEVER) g.qhit[(size_t)b * g.segs + w.lastLive] = 1;
+            else w.guardPrev = true;                                              // (the last live segment lies in front of this run: lane 0 knows it)
+        }
+        if (E[0] < segEnd) w.lastLive = s;
+    }
+}
 __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_t round) {
-    __shared__ uint32_t s_u[KNZ_LZS_RL_CHUNK * 5], s_x[KNZ_LZS_RL_CHUNK * 5], s_e[KNZ_LZS_RL_CHUNK * 5];
-    __shared__ uint32_t s_nt[KNZ_LZS_RL_CHUNK];
+    __shared__ uint32_t s_in[64 * 5], s_out[64 * 5];
+    __shared__ uint32_t s_flag[64], s_last[64];
     __shared__ uint32_t s_res[8];
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
     const LzArgs& a = g.pa.a;
@@ -553,44 +672,52 @@ __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_
     const int srcEnd = count - 18;
     const uint32_t ns = srcEnd > 0 ? ((uint32_t)srcEnd + g.seg_size - 1) / g.seg_size : 0;
     const bool mapsChanged = g.blk_flags[4 * b + 1] != 0;
-    uint32_t cur[5] = {0, 0, (uint32_t)count, (uint32_t)count, 0};
-    bool changed = false, overflow = false;
-    for (uint32_t c0 = 0; c0 < ns; c0 += KNZ_LZS_RL_CHUNK) {
-        const uint32_t cnt = min(KNZ_LZS_RL_CHUNK, ns - c0);
-        const size_t si0 = (size_t)b * g.segs + c0;
-        for (uint32_t i = lane; i < cnt * 5; i += 64) { s_u[i] = g.used[5 * si0 + i]; s_x[i] = g.exit_[5 * si0 + i]; }
-        for (uint32_t i = lane; i < cnt; i += 64) s_nt[i] = g.ntok[si0 + i];
-        wave_sync();
-        if (lane == 0) {
-            for (uint32_t k = 0; k < cnt; k++) {
-                const uint32_t s = c0 + k;
-                uint32_t* E = s_e + 5 * k;
-                const uint32_t* U = s_u + 5 * k;
-                const uint32_t* X = s_x + 5 * k;
-                for (int q = 0; q < 5; q++) E[q] = cur[q];
-                const uint32_t segEnd = (uint32_t)min((uint64_t)(s + 1) * g.seg_size, (uint64_t)srcEnd);
-                if (cur[0] >= segEnd) {                                           // nothing to parse here: the state passes through
-                    // A trace this segment recorded while it still had something to parse is dead now, but its bits may sit in the maps (its stretch was
-                    // carried while it was live, and the stretch of the predecessor that now runs over it is carried from then on): forget the trace and
-                    // have every live segment run, so that the next generation of the maps is written by live traces only.
-                    if (U[0] != KNZ_LZS_NEVER) { s_u[5 * k] = KNZ_LZS_NEVER; changed = true; }
-                    continue;
-                }
-                const bool same = U[0] == cur[0] && U[1] == cur[1] && U[2] == cur[2] && U[3] == cur[3] && U[4] == cur[4];
-                if (!same) changed = true;
-                else if (s_nt[k] == KNZ_LZS_NEVER) overflow = true;
-                if (U[0] != KNZ_LZS_NEVER) for (int q = 0; q < 5; q++) cur[q] = X[q];   // exact when `same`, the best guess otherwise
-            }
+    const uint32_t per = (ns + 63) / 64;                                          // segments per run
+    const uint32_t r0 = min(lane * per, ns), r1 = min(r0 + per, ns);
+    {
+        LzsWalk w;
+        w.changed = false; w.overflow = false; w.lastLive = KNZ_LZS_NEVER; w.guardPrev = false;
+        w.cur[0] = 0; w.cur[1] = 0; w.cur[2] = (uint32_t)count; w.cur[3] = (uint32_t)count; w.cur[4] = 0;
+        if (r0 > 0 && r0 < ns) {                                                  // the guess: what the segment in front of the run left (read before any run is walked)
+            const size_t sp = (size_t)b * g.segs + r0 - 1;
+            if (g.used[5 * sp] != KNZ_LZS_NEVER) for (int q = 0; q < 5; q++) w.cur[q] = g.exit_[5 * sp + q];
+            else w.cur[0] = KNZ_LZS_NEVER;                                        // (no guess: lane 0 walks this run with the real input)
         }
-        wave_sync();
-        for (uint32_t i = lane; i < cnt * 5; i += 64) g.entry[5 * si0 + i] = s_e[i];
-        for (uint32_t i = lane; i < cnt; i += 64) g.used[5 * (si0 + i)] = s_u[5 * i];
-        wave_sync();
+        for (int q = 0; q < 5; q++) s_in[5 * lane + q] = w.cur[q];
+        wave_sync();                                                              // (every guess is read before a walk forgets a trace)
+        if (r0 < r1 && w.cur[0] != KNZ_LZS_NEVER) knz_lzs_walk_run(g, b, r0, r1, srcEnd, w);
+        for (int q = 0; q < 5; q++) s_out[5 * lane + q] = w.cur[q];
+        s_flag[lane] = (w.changed ? 1u : 0u) | (w.overflow ? 2u : 0u) | (w.guardPrev ? 4u : 0u);
+        s_last[lane] = w.lastLive;
     }
-    if (lane == 0) { s_res[0] = changed ? 1u : 0u; s_res[1] = overflow ? 1u : 0u; s_res[2] = cur[1]; }
     __threadfence();
     wave_sync();
-    changed = s_res[0] != 0; overflow = s_res[1] != 0;
+    if (lane == 0) {
+        LzsWalk w;
+        w.changed = false; w.overflow = false; w.lastLive = KNZ_LZS_NEVER; w.guardPrev = false;
+        w.cur[0] = 0; w.cur[1] = 0; w.cur[2] = (uint32_t)count; w.cur[3] = (uint32_t)count; w.cur[4] = 0;
+        for (uint32_t j = 0; j < 64; j++) {
+            const uint32_t q0 = min(j * per, ns), q1 = min(q0 + per, ns);
+            if (q0 >= q1) break;
+            const uint32_t* in = s_in + 5 * j;
+            if (in[0] == w.cur[0] && in[1] == w.cur[1] && in[2] == w.cur[2] && in[3] == w.cur[3] && in[4] == w.cur[4]) {
+                for (int q = 0; q < 5; q++) w.cur[q] = s_out[5 * j + q];
+                w.changed = w.changed || (s_flag[j] & 1u) != 0; w.overflow = w.overflow || (s_flag[j] & 2u) != 0;
+                if ((s_flag[j] & 4u) != 0 && w.lastLive != KNZ_LZS_NEVER) g.qhit[(size_t)b * g.segs + w.lastLive] = 1;
+                if (s_last[j] != KNZ_LZS_NEVER) w.lastLive = s_last[j];
+            } else {
+                if (in[0] != KNZ_LZS_NEVER) {                                      // the run was walked from a state that was not its input: it may have forgotten traces (and its guards are not to be trusted)
+                    w.changed = true;
+                    if (g.chg) g.chg_n[b] = g.chg_cap + 1u;                        // (rare: everybody runs)
+                }
+                knz_lzs_walk_run(g, b, q0, q1, srcEnd, w);
+            }
+        }
+        s_res[0] = w.changed ? 1u : 0u; s_res[1] = w.overflow ? 1u : 0u; s_res[2] = w.cur[1];
+    }
+    __threadfence();
+    wave_sync();
+    const bool changed = s_res[0] != 0, overflow = s_res[1] != 0;
     const uint32_t lastAnchor = s_res[2];
     if (g.rprof && lane == 0) {
         uint32_t firstSeg = ns;
@@ -605,7 +732,8 @@ __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_
         R[0] = firstSeg | (ns << 16); R[1] = g.blk_flags[4 * b + 3];
     }
     const bool holey = (g.Sp[2 * b] | g.Sn[2 * b]) != 0;
-    const bool everyone = holey && (changed || (g.Sp[2 * b] != 0) != (g.Sn[2 * b] != 0) || (g.all_again && mapsChanged));
+    const bool tooMany = g.chg != nullptr && g.chg_n[b] > g.chg_cap;                 // more map words moved than the list holds: nobody is singled out
+    const bool everyone = holey && ((changed && (g.chg == nullptr || tooMany)) || (g.Sp[2 * b] != 0) != (g.Sn[2 * b] != 0) || ((g.all_again || tooMany) && mapsChanged));
     uint32_t nrun = 0;
     for (uint32_t s0 = 0; s0 < ns; s0 += 64) {
         const uint32_t s = s0 + lane;
@@ -629,7 +757,7 @@ __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_
         g.blk_flags[4 * b + 2] = round + 1;
         if (overflow) g.blk_state[b] = 2;
         else if (nrun == 0) g.blk_state[b] = 1;
-        else if (round + 1 >= KNZ_LZS_MAX_ROUNDS) g.blk_state[b] = 2;
+        else if (round + 1 >= g.max_rounds) g.blk_state[b] = 2;
     }
 }
 
@@ -639,11 +767,11 @@ __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_
 // grid (ceil(words / 1024), nblocks); map_stride is a multiple of 4 words
 __global__ __launch_bounds__(256) void knz_lzs_compare_kernel(LzSegArgs g, uint32_t words) {
     __shared__ uint32_t s_c[17];                                              // 1024 words = 32768 positions = at most 512 cells
-    __shared__ uint32_t s_first;
+    __shared__ uint32_t s_first, s_nchg, s_base;
     const uint32_t b = blockIdx.y;
     if (g.blk_state[b] != 0) return;
     if (threadIdx.x < 17) s_c[threadIdx.x] = 0;
-    if (threadIdx.x == 17) s_first = 0xFFFFFFFFu;
+    if (threadIdx.x == 17) { s_first = 0xFFFFFFFFu; s_nchg = 0; s_base = 0; }
     __syncthreads();
     const uint32_t w0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     uint32_t dmask = 0;
@@ -656,12 +784,23 @@ __global__ __launch_bounds__(256) void knz_lzs_compare_kernel(LzSegArgs g, uint3
     unsigned cs = 6;
     while ((g.pa.a.in_len[b] >> cs) >= 32u * KNZ_LZS_COARSE) cs++;
     const uint32_t cw0 = ((blockIdx.x * 1024u * 32u) >> cs) >> 5;            // first word of the coarse map this workgroup can touch
+    uint32_t myOff = 0;
     if (dmask) {
         for (uint32_t k = 0; k < 4u; k++) if (dmask & (1u << k)) {
             const uint32_t cell = ((w0 + k) * 32u) >> cs;                    // a word of 32 positions lies inside one cell (cs >= 6)
             atomicOr(&s_c[(cell >> 5) - cw0], 1u << (cell & 31));
         }
         atomicMin(&s_first, w0 + (uint32_t)__ffs((int)dmask) - 1u);
+        if (g.chg) myOff = atomicAdd(&s_nchg, (uint32_t)__popc(dmask));
+    }
+    __syncthreads();
+    if (g.chg) {                                                             // the moved words of the workgroup go to the block's list in one reservation
+        if (threadIdx.x == 0 && s_nchg) s_base = atomicAdd(&g.chg_n[b], s_nchg);
+        __syncthreads();
+        if (dmask) for (uint32_t k = 0; k < 4u; k++) if (dmask & (1u << k)) {
+            const uint32_t at = s_base + myOff++;
+            if (at < g.chg_cap) g.chg[(size_t)b * g.chg_cap + at] = w0 + k;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 17) { const uint32_t v = s_c[threadIdx.x]; if (v) atomicOr(&g.cmap[(size_t)b * KNZ_LZS_COARSE + cw0 + threadIdx.x], v); }
@@ -682,6 +821,70 @@ __global__ __launch_bounds__(64) void knz_lzs_qhit_kernel(LzSegArgs g) {
     for (uint32_t i = lane; i < KNZ_LZS_COARSE; i += 64) hit |= Q[i] & C[i];
     const uint64_t any = wave_ballot(hit != 0);
     if (lane == 0) g.qhit[si] = any != 0 ? 1 : 0;
+}
+
+// Who asked about a hole bit that moved? A parse reads the bit of position q only on the way down a candidate chain: standing on p (or probing p + 1, p + 2
+// from p) it looks at cand(p), and at cand(cand(p)) if that one is a hole, and so on. Seen from q: the NEXT position with q's hash asks about q, the one
+// after it does if the next one is a hole, ... So for every bit that differs between the two generations the chain of successors is walked while it
+// runs over holes (of either generation), and the traces that stand on a successor s (or on s - 1, s - 2: the probes) are marked to run again. The
+// successor of a position comes from the sorted (block : hash, position) pairs the candidates were made from, by binary search.
+__device__ __forceinline__ uint32_t knz_lzs_successor(const LzSegArgs& g, uint32_t b, const uint8_t* src, uint32_t g0, uint32_t plen, uint32_t q) {
+    // the pairs are sorted by (block : hash, global position); the pairs of block b are [g0, g0 + plen)
+    const uint32_t key = (b << g.hash_log) | knz_lz_hash(knz_vle64(src + q), 64 - g.hash_log);
+    const uint64_t want = ((uint64_t)key << 32) | (g0 + q);
+    uint32_t lo = g0, hi = g0 + plen;                                         // first pair >= want
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const uint64_t v = ((uint64_t)g.skeys[mid] << 32) | g.svals[mid];
+        if (v < want) lo = mid + 1; else hi = mid;
+    }
+    if (lo + 1 >= g0 + plen || g.skeys[lo] != key || g.svals[lo] != g0 + q) return 0;
+    return g.skeys[lo + 1] == key ? g.svals[lo + 1] - g0 : 0;
+}
+__device__ __forceinline__ void knz_lzs_mark_trace(const LzSegArgs& g, uint32_t b, uint32_t ns, uint32_t pos) {
+    uint32_t t = min(pos / g.seg_size, ns - 1);
+    for (;;) {                                                                // the trace that stands on pos: the last one that starts at or in front of it
+        const uint32_t u0 = g.used[5 * ((size_t)b * g.segs + t)];
+        if ((u0 != KNZ_LZS_NEVER && u0 <= pos) || t == 0) break;
+        t--;
+    }
+    g.qhit[(size_t)b * g.segs + t] = 1;
+}
+// grid (ceil(chg_cap / 64), nblocks), one thread per moved word
+__global__ __launch_bounds__(64) void knz_lzs_mark_kernel(LzSegArgs g) {
+    const LzArgs& a = g.pa.a;
+    const uint32_t b = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
+    if (g.blk_state[b] != 0) return;
+    const uint32_t n = g.chg_n[b];
+    if (n > g.chg_cap || i >= n) return;                                      // (too many words moved: relink has every live segment run)
+    const int count = (int)a.in_len[b];
+    const int srcEnd = count - 18;
+    const uint32_t ns = srcEnd > 0 ? ((uint32_t)srcEnd + g.seg_size - 1) / g.seg_size : 0;
+    if (ns == 0) return;
+    const uint8_t* src = (const uint8_t*)a.in_ptr[b];
+    const uint32_t g0 = g.pa.gstart[b], plen = g.pa.gstart[b + 1] - g0;
+    const uint32_t w = g.chg[(size_t)b * g.chg_cap + i];
+    const size_t mi = (size_t)b * g.map_stride;
+    const uint32_t jp = g.Jp[mi + w], jn = g.Jn[mi + w], mp = g.Mp[mi + w], mn = g.Mn[mi + w];
+    // a position counts when it is (or was) jumped over and one of its two bits moved: a parse reads J & ~M of the previous generation, or J alone of
+    // the literal run it inherits (with its own M)
+    uint32_t rel = (jp | jn) & ((jp ^ jn) | (mp ^ mn));
+    while (rel) {
+        const uint32_t q = w * 32u + (uint32_t)(__ffs((int)rel) - 1);
+        rel &= rel - 1;
+        if (q >= plen) continue;
+        uint32_t s = q;
+        for (uint32_t hops = 0; hops < 4096u; hops++) {
+            s = knz_lzs_successor(g, b, src, g0, plen, s);
+            if (s == 0) break;
+            knz_lzs_mark_trace(g, b, ns, s);
+            if (s >= 1) knz_lzs_mark_trace(g, b, ns, s - 1);
+            if (s >= 2) knz_lzs_mark_trace(g, b, ns, s - 2);
+            const uint32_t sw = s >> 5, sm = 1u << (s & 31);
+            if (((g.Jp[mi + sw] | g.Jn[mi + sw]) & sm) == 0) break;           // not a hole in either generation: nobody looks past it
+            if (hops == 4095u) atomicAdd(&g.chg_n[b], g.chg_cap + 1u);        // (a chain of holes this long: give up on being selective, for the next round)
+        }
+    }
 }
 
 // the stretches of the maps that belong to live segments which did not run in this round, copied into this round's generation;

@@ -376,7 +376,7 @@ def test_text_stream_through_foreign_handle(be):
 
 def test_lz_forward_forms(be, monkeypatch):
     """Segment-parallel LZ parse (fixed point over segment entry states and hole maps, lz_fwd_seg.hip) against the two one-wave forms."""
-    P.check_lz_forward_forms(be, monkeypatch, big=True, segs=(512, 1024, 4096))
+    P.check_lz_forward_forms(be, monkeypatch, big=True, segs=(128, 256, 512, 1024, 4096))
 
 
 def test_lz_streams_small_segments(be, monkeypatch):
