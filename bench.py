@@ -12,7 +12,7 @@ N copies of the corpus back to back in ONE stream, split into contiguous balance
 blocks, the compressed segments are gathered to rank 0 over RCCL with their exact sizes (grouped send/recv, no padding) and assembled
 bit-granularly there; the gather stays in flight while each rank decodes its own segment. value = bytes of all ranks / step time (max over
 ranks). This is the mode the path scales in: its time is set by per-block chains whose cost does not depend on how many run side by side
-(the single-GPU saturation curve).
+(DESIGN.md sections 4.9 and 5).
 `--scaling strong`: the SAME job (one S-silesia stream, 26 blocks) split over the ranks (26 blocks over 8 GPUs = 4,4,3,3,3,3,3,3). A rank's step
 is never shorter than its slowest block's chains, so this mode cannot go much above 1x for the chain-bound configurations; it is kept
 for the configurations that are not (--config lz, huffman, ans0).
@@ -869,7 +869,7 @@ def main():
             if fb:
                 out["fallback_counters_last_batch"] = fb
         if entropy == "FPAQ":
-            out["chain_bound"] = True          # one binary arithmetic-coding chain per block by format (DESIGN.md "FPAQ"): flat in the block count
+            out["chain_bound"] = True          # one binary arithmetic-coding chain per block by format: flat in the block count
             if not multi and not emu and not args.no_cpu_baseline:
                 try:
                     out["fpaq_stage"] = fpaq_stage_comparison(base, nblocks, kern_ms.get("knz_fpaq_encode_kernel", 0.0) / K_, kern_ms.get("knz_fpaq_decode_kernel", 0.0) / K_, m_local)

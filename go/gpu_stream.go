@@ -104,7 +104,7 @@ func (this *Writer) enableGPU(devices []int) error {
 // EnableGPUDepth is EnableGPU with a batch depth of its own: `depth` blocks (1..1024) are buffered and handed to the
 // device per batch instead of `jobs` (which the reference caps at 64, _MAX_CONCURRENCY: it is a number of goroutines
 // there; here it is only how many blocks are in flight on the device, and the chains of the BWT pipelines want hundreds:
-// DESIGN.md section 4, saturation curve). To be called before the first Write. The stream written is the same for
+// DESIGN.md section 4.9). To be called before the first Write. The stream written is the same for
 // every depth. Host memory: depth x 2 block buffers, allocated as they fill; device workspace grows with the batch and
 // the library takes a batch in halves when the device cannot hold it.
 func (this *Writer) EnableGPUDepth(depth int) error {

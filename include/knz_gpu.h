@@ -1,11 +1,13 @@
 /*
  * knz_gpu.h — C ABI of the MI355X-native Kanzi block-compression hot path.
  *
- * Drop-in boundary for flanglet/kanzi-go (bitstream v6). Bit-exactness is established against the reference's own code: its .go sources
- * translated mechanically to C++ and compiled (oracle/_ref, tools/go2cpp; the image has no Go toolchain), compared with the device
- * directly and through 387 reference-written stream vectors (tests/test_ref_streams.py), and against the hand-written restatement
- * (oracle/) that _ref pins. A stream from a Go-compiled build would be one more witness (tools/make_ref_vectors.sh). Every entry point names the reference
- * interface it replaces; the cgo stubs a kanzi-go maintainer would add are in INTEGRATION.md.
+ * Drop-in boundary for flanglet/kanzi-go (bitstream v6). Bit-exactness is pinned by a MECHANICAL TRANSLATION of the reference, not yet by a Go-built
+ * binary: the image has no Go toolchain, so kanzi-go's .go sources are translated to C++ by tools/go2cpp and compiled (oracle/_ref); the device is compared
+ * with that build directly, through 387 stream vectors it wrote (tests/test_ref_streams.py), through the full-size BASELINE streams by sha256
+ * (tests/golden/ref_streams/fullsize_manifest.json), and with the hand-written restatement (oracle/) that _ref pins case by case. A misreading of Go shared by
+ * the translator and the restatement would pass all of that; a stream from a Go-compiled build is the missing witness (tools/make_ref_vectors.sh writes the
+ * same manifests on any machine with Go). Every entry point names the reference interface it replaces; the cgo stubs a kanzi-go maintainer would add are
+ * in INTEGRATION.md and go/.
  * Plain pointers and sizes only; the library never keeps a caller pointer after a call returns.
  * Return value: 0 on success, otherwise a kanzi error code (v2/Definitions.go:25-46), except
  * knz_transform_forward() which returns KNZ_SKIP when the transform declines (in kanzi-go a

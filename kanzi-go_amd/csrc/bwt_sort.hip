@@ -21,7 +21,7 @@
 #include "bits.h"
 
 #ifndef KNZ_SS_K0
-#define KNZ_SS_K0 8                       // symbols of the first key (measured on S-silesia, DESIGN.md "Suffix sort": 4, 5, 6, 7, 8)
+#define KNZ_SS_K0 8                       // symbols of the first key (measured on S-silesia, docs/HISTORY.md "Suffix sort": 4, 5, 6, 7, 8)
 #endif
 #define KNZ_SS_MASK 0x3FFFFFFFu           // slot numbers stay below 2^30 (KNZ_BWT_GROUP_BYTES)
 #define KNZ_SS_HEAD 0x80000000u           // list entry: the slot starts a group

@@ -23,7 +23,7 @@
 // 256 bytes at a time. Ranks >= 64 (rare behind a BWT) take the four-register path of the round-1 kernel.
 #pragma once
 
-// FLAGS (variants kept for measurement): bit 0: an isolated rank 0 takes a branch to a shorter step;
+// FLAGS (variants kept for measurement, see docs/HISTORY.md section 4): bit 0: an isolated rank 0 takes a branch to a shorter step;
 // bit 1: lanes above r are kept by a per-lane threshold (v_cmp + v_cndmask) instead of an EXEC mask around the selects
 
 template <int MODE, bool PACKED, int FLAGS>

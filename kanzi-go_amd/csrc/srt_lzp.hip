@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64) void knz_srt_inverse_kernel(XfArgs a) {
         for (int k = 0; k < 4; k++) total += (uint32_t)s_freq[64 * k + lane];
         total = wave_reduce_add(total);
         // a block whose frequencies do not add up to its length is damaged (the reference walks its output buffer to the end
-        // with whatever the buckets hold; the device reports the block instead)
+        // with whatever the buckets hold; the device reports the block instead, docs/HISTORY.md section 2)
         if (total != len) bad = true;
     }
     if (bad) { if (lane == 0) { a.ok[b] = -KNZ_ERR_PROCESS_BLOCK; a.out_len[b] = 0; } return; }

@@ -1544,7 +1544,7 @@ def check_corrupt_streams(be, trials=12):
             # can tell; for the other codecs the two decoders must agree on error-or-bytes
             # A damaged BWT block is a permutation with several cycles: the reference walks whatever cycle the primary index
             # is on and emits it without complaint, the device's chained inverse notices and reports ERR_PROCESS_BLOCK
-            # (deviations).
+            # (docs/HISTORY.md section 2, deviations).
             # (and an SRT block whose header frequencies no longer add up is reported by the device, walked by the reference)
             if entropy.startswith("ANS") or "BWT" in transform or "SRT" in transform:
                 continue

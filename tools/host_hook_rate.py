@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the host-pointer batch hook (knz_encode_blocks / knz_decode_blocks: what the cgo shim of
 Writer.processBlock / Reader.processBlock calls): blocks in pageable host memory in, block-local streams in host memory out.
-Reported in DESIGN.md next to the device-resident rate of bench.py; never bench.py's `value`."""
+Reported in BASELINE.md next to the device-resident rate of bench.py; never bench.py's `value`."""
 import json
 import os
 import sys
