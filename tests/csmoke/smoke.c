@@ -42,6 +42,27 @@ int main(void) {
     if (rc == 0) { fprintf(stderr, "damaged payload was accepted\n"); return 6; }
     printf("damaged block: error %d (%s)\n", rc, knz_last_error(h));
     knz_close(h);
+    /* the same batch through a handle over several lanes (knz_open_devices; here two lanes on device 0): same bytes, block by block */
+    {
+        const int32_t ords[2] = {0, 0};
+        static uint8_t enc2[NB][2 * BS + 262144];
+        knz_block b2[NB];
+        int32_t ldev[2], lblk[2]; float lms[2];
+        void* hm = NULL;
+        enc[1][40] ^= 0x10;
+        if (knz_device_count() < 1) { fprintf(stderr, "knz_device_count: no device\n"); return 7; }
+        rc = knz_open_devices(&cfg, ords, 2, &hm);
+        if (rc) { fprintf(stderr, "knz_open_devices: %d %s\n", rc, knz_last_error(NULL)); return 8; }
+        memset(b2, 0, sizeof b2);
+        for (int b = 0; b < NB; b++) { b2[b].src = src[b]; b2[b].src_len = lens[b]; b2[b].dst = enc2[b]; b2[b].dst_cap = sizeof enc2[b]; }
+        rc = knz_encode_blocks(hm, b2, NB);
+        if (rc) { fprintf(stderr, "knz_encode_blocks (2 lanes): %d %s\n", rc, knz_last_error(hm)); return 9; }
+        for (int b = 0; b < NB; b++)
+            if (b2[b].out_bits != blk[b].out_bits || memcmp(enc2[b], enc[b], (size_t)((blk[b].out_bits + 7) >> 3)) != 0) { fprintf(stderr, "2 lanes: block %d differs\n", b); return 10; }
+        if (knz_lane_count(hm) != 2 || knz_last_lane_times(hm, ldev, lblk, lms, 2) != 2 || lblk[0] + lblk[1] != NB) { fprintf(stderr, "lane bookkeeping\n"); return 11; }
+        printf("two lanes: %d + %d blocks, same streams\n", lblk[0], lblk[1]);
+        knz_close(hm);
+    }
     printf("c smoke ok\n");
     return 0;
 }

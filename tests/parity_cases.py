@@ -229,6 +229,27 @@ def check_alloc_split(be, monkeypatch):
         with pytest_raises_knz_any():
             K.BlockBatch(c).encode(blocks)
         c.close()
+    # the same through a handle over several lanes (knz_open_devices): every lane splits and retries its own range, and a lane that cannot even take one
+    # block fails the call with its error while the handle stays usable
+    monkeypatch.delenv("KNZ_TEST_ALLOC_LIMIT", raising=False)
+    bs, nblocks = 1 << 16, 13
+    blocks = [corpus(bs, 40 + i) for i in range(nblocks - 1)] + [corpus(999, 78)]
+    c = K.Codec("NONE", "HUFFMAN", bs, lib=be.lib)
+    want = K.BlockBatch(c).encode(blocks)
+    c.close()
+    monkeypatch.setenv("KNZ_TEST_ALLOC_LIMIT", "500000")                 # (a lane's 4-5 blocks do not fit, 2-3 do)
+    c = K.Codec("NONE", "HUFFMAN", bs, lib=be.lib, devices=[0, 0, 0])
+    bb = K.BlockBatch(c)
+    got = bb.encode(blocks)
+    assert got == want, "split batches of a multi-lane handle encode differently"
+    assert bb.decode([r[0] for r in got]) == blocks
+    monkeypatch.setenv("KNZ_TEST_ALLOC_LIMIT", "1000")
+    with pytest_raises_knz_any():
+        bb.encode(blocks)
+    monkeypatch.setenv("KNZ_TEST_ALLOC_LIMIT", "500000")
+    assert bb.encode(blocks) == want, "the handle did not recover from a refused batch"
+    c.close()
+    monkeypatch.delenv("KNZ_TEST_ALLOC_LIMIT", raising=False)
     # the order-1 rANS encoder's expanded-step workspace (64 MiB per chunk slot) is halved until the device takes it: 6 slots -> 3 -> 2
     monkeypatch.setenv("KNZ_TEST_ALLOC_LIMIT", "200000000")
     check_stream(be, "NONE", "ANS1", 1 << 16, 6 * (1 << 16) - 77, seed=11)
