@@ -22,6 +22,11 @@ Also on the line (N=1): roofline of the dominant KERNEL (HIP-event time of its l
 present), the PCIe-inclusive rate of the host-pointer batch hook the cgo shim calls (`host_hook_MBps`), and the CPU
 baseline (oracle = C++ restatement of the kanzi-go CPU path, bounded sample).
 
+Other modes (one JSON object instead of the line): `--handles 1,2,4,8` = K host threads x one handle each at the host-pointer boundary; `--in-process-devices 1,2,4,8
+[--depth N]` = ONE handle of knz_open_devices over K lanes (what Writer / Reader.EnableGPUDevices binds: lane i on device i % devices present, so an 8-GPU box measures one
+lane per GPU and a one-GPU box K logical devices); `--copies K` = K corpus copies in one stream (single-GPU saturation). `--corpus PATH` runs the line on a file (the real
+silesia.tar / enwik9 where a driver has them; `data` then says "file").
+
 KNZ_BENCH_EMU=1 is a TEST HARNESS switch (tests/test_bench_ranks.py): the same control flow on CPU tensors with the kernels
 compiled against tests/emu and gloo instead of RCCL, so that the N>1 step can be exercised without GPUs. It is not a
 product path and its JSON says so.
