@@ -353,14 +353,15 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
 // The wave-per-segment kernel above spends a whole wave on a chain of wave-uniform steps: ~125 instructions per step on the CU's ONE scalar unit,
 // the 64-wide vector units idle (a full round over S-silesia = 156 M steps = 16-17 ms whatever the segment size). Here every lane walks a segment of
 // its own: the step's arithmetic runs on the vector units 64 segments at a time; what a lane reads at its position and at the two repeat candidates
-// sits in 16-byte register windows (KnzWin16), lanes that take different paths of the step serialise. Segments are short (KNZ_LZS_LANE_SEG positions)
-// so that a wave's time - its slowest lane's chain - stays small and there are thousands of waves. Measured (S-silesia, 51 x 4 MiB): a full round
-// 8-9 ms at 384 .. 2048 positions per segment (bound by vector-instruction issue over the union of the step's paths: neither wider compares nor the
-// register windows moved it), against 16-17 ms for the wave-per-segment kernel.
+// sits in 16-byte register windows (KnzWin16) and, for cand[], in a 128-byte LDS line per lane; lanes that take different paths of the step serialise.
+// Segments are short (KNZ_LZS_LANE_SEG positions) so that a wave's time - its slowest lane's chain - stays small and there are thousands of waves.
+// Measured (S-silesia, 51 x 4 MiB): a full round 5.2-5.5 ms at 768 positions per segment against 16-17 ms for the wave-per-segment kernel (8-9 ms
+// while the windows were picked apart with a computed register index, which the compiler turned into indexed scratch memory: KnzWin16::at).
 // Who runs again: what the wave-per-segment form finds with its query log comes from the DATA here (knz_lzs_mark_kernel: the positions that can have
 // asked about a hole bit that moved are the next positions with its hash), and a moved entry state makes its own segment and the one in front of it
 // run, not the whole block (knz_lzs_walk_run, `guard`); the stretches of everybody else are carried. A block has settled when nobody has to run.
-// S-silesia: 7 rounds, 8.8 + 8.1 + 8.0 + 4.6 + 3.3 + 2.9 + 0.3 ms at 1024 positions, 32 ms at 768; 62 ms (6 rounds) for the wave-per-segment form.
+// S-silesia: 7 rounds, 5.5 + 5.2 + 5.2 + 2.4 + 2.1 + 1.9 + 0.6 = 23 ms; 62 ms (6 rounds) for the wave-per-segment form. 512 / 768 / 1024 / 2048 positions
+// per segment: 21.5 / 22.6 / 28.1 / 39.9 ms of parse in 8 / 7 / 7 / 6 rounds (the other kernels of the stage grow with the number of segments).
 // Same inputs, same outputs (entry / used / exit states, token descriptors, hole maps) and the same reads of the previous generation as
 // knz_lzs_parse_kernel: the two are interchangeable (KNZ_LZS_WAVES selects the one above, with its query log).
 #define KNZ_LZS_LANE_SEG 768u
@@ -393,34 +394,29 @@ struct KnzWin16 {
         const KnzPacked128* q = (const KnzPacked128*)(a + base);
         w0 = q->x; w1 = q->y; w2 = q->z; w3 = q->w;
     }
-    __device__ __forceinline__ uint32_t dw(uint32_t k) const { return k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3)); }
-#ifdef KNZ_LZS_NO_WIN
-    __device__ __forceinline__ uint32_t get32(const uint8_t* a, int pos) { return knz_vle32(a + pos); }
-    __device__ __forceinline__ uint64_t get64(const uint8_t* a, int pos) { return knz_vle64(a + pos); }
-    __device__ __forceinline__ uint32_t get8(const uint8_t* a, int pos) { return a[pos]; }
-#else
+    // the 64 bits that start `rel` bytes into the window (rel <= 8; rel <= 15 when fewer bits are used): shifts of the two halves, not a choice of
+    // registers - a register picked by a computed index can make the compiler keep the window in scratch memory and index it there
+    __device__ __forceinline__ uint64_t at(uint32_t rel) const {
+        const uint64_t lo = (uint64_t)w0 | ((uint64_t)w1 << 32), hi = (uint64_t)w2 | ((uint64_t)w3 << 32);
+        const uint32_t sh = rel * 8u;
+        if (sh >= 64u) return hi >> (sh - 64u);
+        return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+    }
     __device__ __forceinline__ uint32_t get32(const uint8_t* a, int pos) {          // the 4 bytes at pos (little endian)
         uint32_t rel = (uint32_t)(pos - base);
         if (rel > 12u) { fill(a, pos); rel = (uint32_t)(pos - base); }
-        const uint32_t k = rel >> 2, sh = (rel & 3u) * 8u;
-        const uint32_t lo = dw(k);
-        if (sh == 0) return lo;
-        return (lo >> sh) | (dw(k + 1) << (32 - sh));
+        return (uint32_t)at(rel);
     }
     __device__ __forceinline__ uint64_t get64(const uint8_t* a, int pos) {          // the 8 bytes at pos
         uint32_t rel = (uint32_t)(pos - base);
         if (rel > 8u) { fill(a, pos); rel = (uint32_t)(pos - base); }
-        const uint32_t k = rel >> 2, sh = (rel & 3u) * 8u;
-        const uint64_t lo = (uint64_t)dw(k) | ((uint64_t)dw(k + 1) << 32);
-        if (sh == 0) return lo;
-        return (lo >> sh) | ((uint64_t)dw(k + 2) << (64 - sh));
+        return at(rel);
     }
     __device__ __forceinline__ uint32_t get8(const uint8_t* a, int pos) {
         uint32_t rel = (uint32_t)(pos - base);
         if (rel > 15u) { fill(a, pos); rel = (uint32_t)(pos - base); }
-        return (dw(rel >> 2) >> ((rel & 3u) * 8u)) & 0xFFu;
+        return (uint32_t)at(rel) & 0xFFu;
     }
-#endif
 };
 
 // bits [lo, hi) of a bit map set with one atomic per word
@@ -470,9 +466,32 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_lanes_kernel(LzSegArgs g) {
     uint32_t ntok = 0;
     uint4* tokOut = g.tok + si * g.tok_cap;
     bool overflow = false;
-    KnzWin16 wS, wC, wP, wA, wB;                                              // source at the position, cand[] and cp8[] at the position, source at the two repeat candidates
-    wS.base = wC.base = wP.base = wA.base = wB.base = -0x40000000;
+    KnzWin16 wS, wP, wA, wB;                                                  // source and cp8[] at the position, source at the two repeat candidates
+    wS.base = wP.base = wA.base = wB.base = -0x40000000;
     const uint8_t* cand8 = (const uint8_t*)cand;
+    // cand[] is the widest of the streams a lane walks (4 bytes per position): its current 128-byte line sits in LDS - fetched once, eight 16-byte loads
+    // in flight, read from there for the next 32 positions (a 16-byte register window made every line come from HBM eight times: with it 175x the
+    // algorithmic bytes and 23.7 ms of parse on S-silesia, with the line in LDS 131x and 22.5 ms; the source line in LDS as well: 100x, but 23.3 ms)
+    __shared__ uint32_t s_cl[64 * 33];
+    int clBase = -0x40000000;
+    uint32_t* myCl = s_cl + 33 * threadIdx.x;
+    auto cand_at = [&](int pos) -> int {
+        uint32_t rel = (uint32_t)(pos - clBase);
+        if (rel >= 32u) {
+            const intptr_t a0 = (intptr_t)((uintptr_t)(cand8 + 4 * (size_t)pos) & ~(uintptr_t)127) - (intptr_t)cand8;      // the line the entry lies in
+            clBase = (int)max((intptr_t)0, a0 >> 2);                          // (the workspace behind the last block's entries is readable: DevBuf keeps >= 256 bytes of slack)
+            const KnzPacked128* q = (const KnzPacked128*)(cand8 + 4 * (size_t)clBase);
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const KnzPacked128 a = q[4 * half], b2 = q[4 * half + 1], c2 = q[4 * half + 2], d2 = q[4 * half + 3];
+                uint32_t* o = myCl + 16 * half;
+                o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b2.x; o[5] = b2.y; o[6] = b2.z; o[7] = b2.w;
+                o[8] = c2.x; o[9] = c2.y; o[10] = c2.z; o[11] = c2.w; o[12] = d2.x; o[13] = d2.y; o[14] = d2.z; o[15] = d2.w;
+            }
+            rel = (uint32_t)(pos - clBase);
+        }
+        return (int)myCl[rel];
+    };
 
     // the hole bit of position q as knz_lzs_parse_kernel reads it: the previous generation for everything in front of the entry anchor, J of the previous
     // generation with this trace's own M for the literal run it inherits, its own generation for what it has passed itself. (The coarse map only
@@ -507,7 +526,7 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_lanes_kernel(LzSegArgs g) {
         const int minRef = max(srcIdx - maxDist, 0);
         const int refA = srcIdx1 - (repdIdx ? repd1 : repd0), refB = srcIdx1 - (repdIdx ? repd0 : repd1);
         const uint64_t p = wS.get64(src, srcIdx);
-        const int raw0 = (int)wC.get32(cand8, 4 * srcIdx), cp0 = (int)wP.get8(cp8, srcIdx);
+        const int raw0 = cand_at(srcIdx), cp0 = (int)wP.get8(cp8, srcIdx);
         const int ref0 = true_cand(raw0);
         int ref = refB;                                                       // (what the reference leaves in `ref` when neither repeat distance matches)
         const uint32_t p1 = (uint32_t)(p >> 8);
@@ -542,7 +561,7 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_lanes_kernel(LzSegArgs g) {
             }
             if (ref != srcIdx - repd0 && ref != srcIdx - repd1) {             // checkNext (:362-398)
                 {
-                    const int raw1 = (int)wC.get32(cand8, 4 * srcIdx1), cp1 = (int)wP.get8(cp8, srcIdx1);
+                    const int raw1 = cand_at(srcIdx1), cp1 = (int)wP.get8(cp8, srcIdx1);
                     const int ref1 = true_cand(raw1);
                     if (ref1 > minRef + 1 && !(ref1 == raw1 && cp1 < 255 && cp1 < bestLen) &&
                         knz_vle32(src + srcIdx1 + bestLen - 3) == knz_vle32(src + ref1 + bestLen - 3)) {
@@ -552,7 +571,7 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_lanes_kernel(LzSegArgs g) {
                 }
                 if (a.extra) {
                     const int srcIdx2 = srcIdx1 + 1;
-                    const int raw2 = (int)wC.get32(cand8, 4 * srcIdx2), cp2 = (int)wP.get8(cp8, srcIdx2);
+                    const int raw2 = cand_at(srcIdx2), cp2 = (int)wP.get8(cp8, srcIdx2);
                     const int ref2 = true_cand(raw2);
                     const int mm2 = min(srcEnd - srcIdx2, KNZ_LZ_MAX_MATCH);
                     if (ref2 > minRef + 2 && !(ref2 == raw2 && cp2 < 255 && cp2 < bestLen) &&
