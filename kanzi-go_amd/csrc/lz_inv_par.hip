@@ -375,7 +375,8 @@ __device__ __forceinline__ void knz_lzi_b_tokens(const LziArgs& g, uint32_t b, c
     if (T.n == 0) return;
     const uint64_t w = knz_lzi_load8(src + G[LZI_TK0] + k0, nTok - k0);
     const uint32_t minMatch = G[LZI_MINMATCH];
-    for (uint32_t j = 0; j < T.n; j++) {
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) if (j < T.n) {
         const LziTok k = knz_lzi_token((uint32_t)(w >> (8 * j)) & 0xFFu, k0 + j == nTok - 1);
         const size_t i = tb + k0 + j;
         if (k.lext) { const uint32_t x = g.t_c[i]; uint32_t sz, val; knz_lzi_ext_from_diff(g.lx_c[tb + x + 1] - g.lx_c[tb + x], sz, val); T.lit[j] = 7u + val; }
@@ -406,7 +407,8 @@ __global__ __launch_bounds__(256) void knz_lzi_b_count_kernel(LziArgs g) {
     knz_lzi_b_tokens(g, b, G, s * KNZ_LZI_SEG + tid * 8, T);
     uint32_t len = 0;
     LziRep m; m.c0 = KNZ_LZI_SEL0; m.c1 = KNZ_LZI_SEL1;
-    for (uint32_t j = 0; j < T.n; j++) {
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) if (j < T.n) {
         if (T.lit[j] > 0x3FFFFFFFu || T.mlen[j] > 0x3FFFFFFFu || len > 0x3FFFFFFFu) T.bad = true;
         len += T.lit[j] + T.mlen[j];
         m = knz_lzi_rep_compose(m, knz_lzi_rep_token(T.rep[j], T.dist[j]));
@@ -477,7 +479,8 @@ __global__ __launch_bounds__(256) void knz_lzi_b_apply_kernel(LziArgs g) {
     knz_lzi_b_tokens(g, b, G, k0, T);
     uint32_t len = 0;
     LziRep m; m.c0 = KNZ_LZI_SEL0; m.c1 = KNZ_LZI_SEL1;
-    for (uint32_t j = 0; j < T.n; j++) { len += T.lit[j] + T.mlen[j]; m = knz_lzi_rep_compose(m, knz_lzi_rep_token(T.rep[j], T.dist[j])); }
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) if (j < T.n) { len += T.lit[j] + T.mlen[j]; m = knz_lzi_rep_compose(m, knz_lzi_rep_token(T.rep[j], T.dist[j])); }
     const uint32_t* S = g.seg + ((size_t)b * g.segs + s) * 8;
     uint32_t dpos = S[4] + knz_lzi_wg_scan_excl(len, s_w);                   // (the block total fits 31 bits: checked by the offsets kernel)
     LziRep tot;
@@ -494,7 +497,8 @@ __global__ __launch_bounds__(256) void knz_lzi_b_apply_kernel(LziArgs g) {
     const size_t tb = g.tok_base[b];
     const uint32_t tk0 = G[LZI_TK0], srcEnd = tk0 - 13u, maxDist = G[LZI_MAXDIST];
     const int64_t dstEnd = (int64_t)g.a.out_cap - 16;
-    for (uint32_t j = 0; j < T.n; j++) {
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) if (j < T.n) {
         const size_t i = tb + k0 + j;
         const uint32_t k = k0 + j;
         const bool last = k == nTok - 1;
