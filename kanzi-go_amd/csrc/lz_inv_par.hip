@@ -245,10 +245,19 @@ __global__ __launch_bounds__(64) void knz_lzi_litext_chain_kernel(LziArgs g) {
     for (uint32_t i0 = 0; i0 < E && !bad; i0 += 64) {
         const uint32_t n = min(64u, E - i0);
         uint32_t j = 0;
-        for (; j + 4 <= n; j += 4) {                                           // the g[i] through the scalar cache, four at a time
+        // the g[i] through the scalar cache, sixteen at a time: a scalar load is waited for where it is issued (the compiler drains lgkmcnt in front of
+        // every v_readlane of the walk), so its ~150 ns sit on the chain once per load - once per sixteen steps now, once per four until round 6
+        for (; j + 16 <= n; j += 16) {
             const uint8_t* gp = lg + 4 * (size_t)(i0 + j);
-            const uint32_t g0 = wave_sload_u32(gp), g1 = wave_sload_u32(gp + 4), g2 = wave_sload_u32(gp + 8), g3 = wave_sload_u32(gp + 12);
-            step(g0, j); step(g1, j + 1); step(g2, j + 2); step(g3, j + 3);
+            const knz_u32x4 a = wave_sload_u32x4(gp), b2 = wave_sload_u32x4(gp + 16), c2 = wave_sload_u32x4(gp + 32), d2 = wave_sload_u32x4(gp + 48);
+            step(a.x, j); step(a.y, j + 1); step(a.z, j + 2); step(a.w, j + 3);
+            step(b2.x, j + 4); step(b2.y, j + 5); step(b2.z, j + 6); step(b2.w, j + 7);
+            step(c2.x, j + 8); step(c2.y, j + 9); step(c2.z, j + 10); step(c2.w, j + 11);
+            step(d2.x, j + 12); step(d2.y, j + 13); step(d2.z, j + 14); step(d2.w, j + 15);
+        }
+        for (; j + 4 <= n; j += 4) {
+            const knz_u32x4 a = wave_sload_u32x4(lg + 4 * (size_t)(i0 + j));
+            step(a.x, j); step(a.y, j + 1); step(a.z, j + 2); step(a.w, j + 3);
         }
         for (; j < n; j++) step(wave_sload_u32(lg + 4 * (size_t)(i0 + j)), j);
         if (lane < n) lc[i0 + lane] = hist;
