@@ -869,10 +869,11 @@ __device__ __forceinline__ void knz_lzs_mark_trace(const LzSegArgs& g, uint32_t 
     }
     g.qhit[(size_t)b * g.segs + t] = 1;
 }
-// grid (ceil(chg_cap / 64), nblocks), one thread per moved word
-__global__ __launch_bounds__(64) void knz_lzs_mark_kernel(LzSegArgs g) {
+// grid (ceil(chg_cap / 8), nblocks), 256 threads: one thread per POSITION of a moved word (a walk down the successors is a chain of binary searches,
+// and a word has several positions that count: a thread per word would walk them one after the other)
+__global__ __launch_bounds__(256) void knz_lzs_mark_kernel(LzSegArgs g) {
     const LzArgs& a = g.pa.a;
-    const uint32_t b = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t b = blockIdx.y, i = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (g.blk_state[b] != 0) return;
     const uint32_t n = g.chg_n[b];
     if (n > g.chg_cap || i >= n) return;                                      // (too many words moved: relink has every live segment run)
@@ -887,11 +888,10 @@ __global__ __launch_bounds__(64) void knz_lzs_mark_kernel(LzSegArgs g) {
     const uint32_t jp = g.Jp[mi + w], jn = g.Jn[mi + w], mp = g.Mp[mi + w], mn = g.Mn[mi + w];
     // a position counts when it is (or was) jumped over and one of its two bits moved: a parse reads J & ~M of the previous generation, or J alone of
     // the literal run it inherits (with its own M)
-    uint32_t rel = (jp | jn) & ((jp ^ jn) | (mp ^ mn));
-    while (rel) {
-        const uint32_t q = w * 32u + (uint32_t)(__ffs((int)rel) - 1);
-        rel &= rel - 1;
-        if (q >= plen) continue;
+    const uint32_t rel = (jp | jn) & ((jp ^ jn) | (mp ^ mn));
+    if ((rel >> (threadIdx.x & 31)) & 1u) {
+        const uint32_t q = w * 32u + (threadIdx.x & 31);
+        if (q >= plen) return;
         uint32_t s = q;
         for (uint32_t hops = 0; hops < 4096u; hops++) {
             s = knz_lzs_successor(g, b, src, g0, plen, s);
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(64) void knz_lzs_emit_offsets_kernel(LzSegArgs g, u
 // distance / length bytes by one thread per token and the literals by all threads over the tile's byte range.
 __global__ __launch_bounds__(256) void knz_lzs_emit_write_kernel(LzSegArgs g, const uint32_t* segsum, const uint32_t* blkout) {
     __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_off[257], s_src[256], s_len[256];
+    __shared__ uint32_t s_off[257], s_src[256], s_pre[257];
     const LzArgs& a = g.pa.a;
     const uint32_t b = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     if (g.blk_state[b] != 1) return;
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(256) void knz_lzs_emit_write_kernel(LzSegArgs g, co
         const uint32_t eLit = knz_lzi_wg_scan_excl(z.lit, s_w), eDist = knz_lzi_wg_scan_excl(z.dist, s_w), eMl = knz_lzi_wg_scan_excl(z.ml, s_w);
         const uint32_t litLen = t.y, bestLen = t.z & 0xFFFFFFu, fl = t.z >> 24, dist = t.w;
         const uint32_t extSz = litLen >= 7 ? knz_lzs_len_size(litLen - 7) : 0u;
-        s_off[tid] = litPos + eLit + extSz; s_src[tid] = t.x; s_len[tid] = i < n ? litLen : 0u;
+        s_off[tid] = litPos + eLit + extSz; s_src[tid] = t.x;
         if (i < n) {
             const uint32_t mLen = bestLen - (uint32_t)minMatch, th = fl < 8 ? 3u : 7u;
             const uint32_t token = fl + (mLen >= th ? th : mLen);
@@ -1080,18 +1080,19 @@ __global__ __launch_bounds__(256) void knz_lzs_emit_write_kernel(LzSegArgs g, co
         __shared__ uint32_t s_tot[3];
         if (tid == 255) { s_tot[0] = eLit + z.lit; s_tot[1] = eDist + z.dist; s_tot[2] = eMl + z.ml; }
         __syncthreads();
-        // literals of the tile: every wave takes 64 tokens, its lanes walk their byte range
+        // literals of the tile, one thread per BYTE: the literal runs of a segment are short (2-3 bytes on average), so a wave that walks its 64 tokens one
+        // after the other spends its time on loop overhead; a thread finds the token its byte belongs to by a search over the tile's run starts
         {
-            const uint32_t w = tid >> 6, lane = tid & 63, t0 = w * 64;
-            if (t0 < nt) {
-                const uint32_t tn = min(64u, nt - t0);
-                for (uint32_t k = 0; k < tn; k++) {
-                    const uint32_t len = s_len[t0 + k];
-                    if (len == 0) continue;
-                    const uint8_t* sp = src + s_src[t0 + k];
-                    uint8_t* dp = dst + s_off[t0 + k];
-                    for (uint32_t o = lane; o < len; o += 64) dp[o] = sp[o];
-                }
+            const uint32_t ePlain = knz_lzi_wg_scan_excl(i < n ? litLen : 0u, s_w);       // starts of the runs, counted in literal bytes alone
+            s_pre[tid] = ePlain;
+            if (tid == 255) s_pre[256] = ePlain + (i < n ? litLen : 0u);
+            __syncthreads();
+            const uint32_t total = s_pre[256];
+            for (uint32_t o = tid; o < total; o += 256) {
+                uint32_t lo = 0, hi = nt;                                                    // largest t with s_pre[t] <= o (runs of length 0 share a start: the last one wins)
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= o) lo = mid; else hi = mid; }
+                const uint32_t k = o - s_pre[lo];
+                dst[s_off[lo] + k] = src[s_src[lo] + k];
             }
         }
         litPos += s_tot[0]; mPos += s_tot[1]; mlPos += s_tot[2];
