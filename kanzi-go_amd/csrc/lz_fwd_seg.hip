@@ -869,29 +869,30 @@ __device__ __forceinline__ void knz_lzs_mark_trace(const LzSegArgs& g, uint32_t 
     }
     g.qhit[(size_t)b * g.segs + t] = 1;
 }
-// grid (ceil(chg_cap / 8), nblocks), 256 threads: one thread per POSITION of a moved word (a walk down the successors is a chain of binary searches,
-// and a word has several positions that count: a thread per word would walk them one after the other)
+// grid (up to 256, nblocks), 256 threads: one thread per POSITION of a moved word (a walk down the successors is a chain of binary searches,
+// and a word has several positions that count: a thread per word would walk them one after the other); a workgroup takes 8 words at a time
 __global__ __launch_bounds__(256) void knz_lzs_mark_kernel(LzSegArgs g) {
     const LzArgs& a = g.pa.a;
-    const uint32_t b = blockIdx.y, i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const uint32_t b = blockIdx.y;
     if (g.blk_state[b] != 0) return;
     const uint32_t n = g.chg_n[b];
-    if (n > g.chg_cap || i >= n) return;                                      // (too many words moved: relink has every live segment run)
+    if (n > g.chg_cap) return;                                                // (too many words moved: relink has every live segment run)
     const int count = (int)a.in_len[b];
     const int srcEnd = count - 18;
     const uint32_t ns = srcEnd > 0 ? ((uint32_t)srcEnd + g.seg_size - 1) / g.seg_size : 0;
     if (ns == 0) return;
     const uint8_t* src = (const uint8_t*)a.in_ptr[b];
     const uint32_t g0 = g.pa.gstart[b], plen = g.pa.gstart[b + 1] - g0;
-    const uint32_t w = g.chg[(size_t)b * g.chg_cap + i];
     const size_t mi = (size_t)b * g.map_stride;
-    const uint32_t jp = g.Jp[mi + w], jn = g.Jn[mi + w], mp = g.Mp[mi + w], mn = g.Mn[mi + w];
-    // a position counts when it is (or was) jumped over and one of its two bits moved: a parse reads J & ~M of the previous generation, or J alone of
-    // the literal run it inherits (with its own M)
-    const uint32_t rel = (jp | jn) & ((jp ^ jn) | (mp ^ mn));
-    if ((rel >> (threadIdx.x & 31)) & 1u) {
+    for (uint32_t i = blockIdx.x * 8 + (threadIdx.x >> 5); i < n; i += gridDim.x * 8) {
+        const uint32_t w = g.chg[(size_t)b * g.chg_cap + i];
+        const uint32_t jp = g.Jp[mi + w], jn = g.Jn[mi + w], mp = g.Mp[mi + w], mn = g.Mn[mi + w];
+        // a position counts when it is (or was) jumped over and one of its two bits moved: a parse reads J & ~M of the previous generation, or J alone of
+        // the literal run it inherits (with its own M)
+        const uint32_t rel = (jp | jn) & ((jp ^ jn) | (mp ^ mn));
+        if (((rel >> (threadIdx.x & 31)) & 1u) == 0) continue;
         const uint32_t q = w * 32u + (threadIdx.x & 31);
-        if (q >= plen) return;
+        if (q >= plen) continue;
         uint32_t s = q;
         for (uint32_t hops = 0; hops < 4096u; hops++) {
             s = knz_lzs_successor(g, b, src, g0, plen, s);

@@ -532,7 +532,7 @@ def check_lz_forward_forms(be, monkeypatch, big=False, segs=(256, 512, 1024)):
     the one-wave table-free parse (lz_par.hip, KNZ_LZ_ONE_WAVE) and the first form (lz.hip, KNZ_LZ_CHAIN): all three == the oracle, and the
     segment-parallel one settles on its own (KNZ_COUNTER_LZ_FWD_SERIAL_BLOCKS == 0)."""
     c = K.Codec("NONE", "NONE", 4 << 20, lib=be.lib)
-    keys = ("KNZ_LZ_SEG", "KNZ_LZ_ONE_WAVE", "KNZ_LZ_CHAIN", "KNZ_LZS_WAVES")
+    keys = ("KNZ_LZ_SEG", "KNZ_LZ_ONE_WAVE", "KNZ_LZ_CHAIN", "KNZ_LZS_WAVES", "KNZ_LZS_CHG_CAP")
     for tname in ("LZ", "LZX"):
         t = K.ByteTransform(c, tname)
         tid = _TID[tname]
@@ -540,6 +540,8 @@ def check_lz_forward_forms(be, monkeypatch, big=False, segs=(256, 512, 1024)):
             o = O.transform_forward(tid, data)
             # the segment-parallel parse in both of its forms: one lane per segment (default since round 6) and one wave per segment (KNZ_LZS_WAVES)
             envs = [("KNZ_LZ_SEG", str(sg)) for sg in segs] + [("KNZ_LZ_SEG", str(sg), "KNZ_LZS_WAVES", "1") for sg in segs]
+            # (the list of moved map words holds a block's whole map; a list of 16 words makes "too many moved: everybody runs again" the usual case)
+            envs += [("KNZ_LZ_SEG", str(segs[0]), "KNZ_LZS_CHG_CAP", "16")]
             if big or tname == "LZ":
                 envs += [("KNZ_LZ_SEG", ""), ("KNZ_LZ_SEG", "", "KNZ_LZS_WAVES", "1"), ("KNZ_LZ_ONE_WAVE", "1"), ("KNZ_LZ_CHAIN", "1")]
             for env in envs:
