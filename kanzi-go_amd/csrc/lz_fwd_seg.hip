@@ -643,7 +643,7 @@ __device__ __forceinline__ bool knz_lzs_live(const LzSegArgs& g, uint32_t b, uin
 // "who runs" pass is one segment per lane. One thread per block did the same walk through ~15 dependent global reads per segment: 0.8 ms per round.)
 // (Round 6: with one lane per segment a block has thousands of segments and lane 0's walk was 1.7 ms per round. The walk is sequential only in the
 // state it hands on, and that state is almost always the exit of the segment in front. So every lane walks a run of consecutive segments on its
-// own, from the exit state of the segment in front of its run; lane 0 then goes over the 64 runs in order and walks again those whose real
+// own, from the exit state of the segment in front of its run; lane 0 then goes over the runs (256 of them) in order and walks again those whose real
 // input turned out to be something else (a skipping trace that ran over the border of the run). A run walked from a wrong input may have
 // forgotten traces (`used` reset) and raised `changed` for nothing: both only make segments run that did not have to.)
 // `guard`: with the maps' dependents found from the data (g.chg), a moved entry state no longer makes every live segment of the block run. What it
@@ -680,9 +680,10 @@ __device__ __forceinline__ void knz_lzs_walk_run(const LzSegArgs& g, uint32_t b,
         if (E[0] < segEnd) w.lastLive = s;
     }
 }
-__global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_t round) {
-    __shared__ uint32_t s_in[64 * 5], s_out[64 * 5];
-    __shared__ uint32_t s_flag[64], s_last[64];
+#define KNZ_LZS_RUNS 256u                                                          // runs a block's segments are cut into for the walk (= threads of the kernel)
+__global__ __launch_bounds__(KNZ_LZS_RUNS) void knz_lzs_relink_kernel(LzSegArgs g, uint32_t round) {
+    __shared__ uint32_t s_in[KNZ_LZS_RUNS * 5], s_out[KNZ_LZS_RUNS * 5];
+    __shared__ uint32_t s_flag[KNZ_LZS_RUNS], s_last[KNZ_LZS_RUNS];
     __shared__ uint32_t s_res[8];
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
     const LzArgs& a = g.pa.a;
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_
     const int srcEnd = count - 18;
     const uint32_t ns = srcEnd > 0 ? ((uint32_t)srcEnd + g.seg_size - 1) / g.seg_size : 0;
     const bool mapsChanged = g.blk_flags[4 * b + 1] != 0;
-    const uint32_t per = (ns + 63) / 64;                                          // segments per run
+    const uint32_t per = (ns + KNZ_LZS_RUNS - 1) / KNZ_LZS_RUNS;                      // segments per run
     const uint32_t r0 = min(lane * per, ns), r1 = min(r0 + per, ns);
     {
         LzsWalk w;
@@ -703,19 +704,20 @@ __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_
             else w.cur[0] = KNZ_LZS_NEVER;                                        // (no guess: lane 0 walks this run with the real input)
         }
         for (int q = 0; q < 5; q++) s_in[5 * lane + q] = w.cur[q];
-        wave_sync();                                                              // (every guess is read before a walk forgets a trace)
+        __syncthreads();                                                          // (every guess is read before a walk forgets a trace)
         if (r0 < r1 && w.cur[0] != KNZ_LZS_NEVER) knz_lzs_walk_run(g, b, r0, r1, srcEnd, w);
         for (int q = 0; q < 5; q++) s_out[5 * lane + q] = w.cur[q];
         s_flag[lane] = (w.changed ? 1u : 0u) | (w.overflow ? 2u : 0u) | (w.guardPrev ? 4u : 0u);
         s_last[lane] = w.lastLive;
     }
     __threadfence();
-    wave_sync();
+    __syncthreads();
     if (lane == 0) {
+        s_res[3] = 0;
         LzsWalk w;
         w.changed = false; w.overflow = false; w.lastLive = KNZ_LZS_NEVER; w.guardPrev = false;
         w.cur[0] = 0; w.cur[1] = 0; w.cur[2] = (uint32_t)count; w.cur[3] = (uint32_t)count; w.cur[4] = 0;
-        for (uint32_t j = 0; j < 64; j++) {
+        for (uint32_t j = 0; j < KNZ_LZS_RUNS; j++) {
             const uint32_t q0 = min(j * per, ns), q1 = min(q0 + per, ns);
             if (q0 >= q1) break;
             const uint32_t* in = s_in + 5 * j;
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_
         s_res[0] = w.changed ? 1u : 0u; s_res[1] = w.overflow ? 1u : 0u; s_res[2] = w.cur[1];
     }
     __threadfence();
-    wave_sync();
+    __syncthreads();
     const bool changed = s_res[0] != 0, overflow = s_res[1] != 0;
     const uint32_t lastAnchor = s_res[2];
     if (g.rprof && lane == 0) {
@@ -754,7 +756,7 @@ __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_
     const bool tooMany = g.chg != nullptr && g.chg_n[b] > g.chg_cap;                 // more map words moved than the list holds: nobody is singled out
     const bool everyone = holey && ((changed && (g.chg == nullptr || tooMany)) || (g.Sp[2 * b] != 0) != (g.Sn[2 * b] != 0) || ((g.all_again || tooMany) && mapsChanged));
     uint32_t nrun = 0;
-    for (uint32_t s0 = 0; s0 < ns; s0 += 64) {
+    for (uint32_t s0 = 0; s0 < ns; s0 += KNZ_LZS_RUNS) {
         const uint32_t s = s0 + lane;
         bool run = false;
         if (s < ns) {
@@ -768,6 +770,9 @@ __global__ __launch_bounds__(64) void knz_lzs_relink_kernel(LzSegArgs g, uint32_
         }
         nrun += (uint32_t)__popcll((unsigned long long)wave_ballot(run));
     }
+    if ((lane & 63) == 0 && nrun) atomicAdd(&s_res[3], nrun);
+    __syncthreads();
+    nrun = s_res[3];
     if (lane == 0) {
         if (g.rprof) g.rprof[((size_t)round * a.nblocks + b) * 3 + 2] = nrun;
         g.blk_flags[4 * b + 1] = 0;
