@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64) void knz_lzs_parse_kernel(LzSegArgs g) {
 // Who runs again: what the wave-per-segment form finds with its query log comes from the DATA here (knz_lzs_mark_kernel: the positions that can have
 // asked about a hole bit that moved are the next positions with its hash), and a moved entry state makes its own segment and the one in front of it
 // run, not the whole block (knz_lzs_walk_run, `guard`); the stretches of everybody else are carried. A block has settled when nobody has to run.
-// S-silesia: 7 rounds, 5.5 + 5.2 + 5.2 + 2.4 + 2.1 + 1.9 + 0.6 = 23 ms; 62 ms (6 rounds) for the wave-per-segment form. 512 / 768 / 1024 / 2048 positions
+// S-silesia: 7 rounds, 5.6 + 5.3 + 2.9 + 2.4 + 2.1 + 1.9 + 0.6 = 20.7 ms (23 ms while the list of moved words held 8192 of them: a full third round); 62 ms (6 rounds) for the wave-per-segment form. 512 / 768 / 1024 / 2048 positions
 // per segment: 21.5 / 22.6 / 28.1 / 39.9 ms of parse in 8 / 7 / 7 / 6 rounds (the other kernels of the stage grow with the number of segments).
 // Same inputs, same outputs (entry / used / exit states, token descriptors, hole maps) and the same reads of the previous generation as
 // knz_lzs_parse_kernel: the two are interchangeable (KNZ_LZS_WAVES selects the one above, with its query log).

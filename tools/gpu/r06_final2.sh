@@ -1,4 +1,4 @@
-# round 6, last state of the tree: the whole GPU suite, the LZ line again (the LZ kernels moved after r06_final.sh ran), its trace and its multi-device curve
+# round 6, last state of the tree: the whole GPU suite, the LZ line again (the LZ kernels moved after r06_final.sh ran: emit, mark, the list of moved words, relink), its trace and its multi-device curve
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 O=gpurun_out/r06_final2; mkdir -p $O
 python bench.py --config lz > $O/config_lz_bench.json 2> $O/lz.err
