@@ -46,7 +46,7 @@ struct LziArgs {
     uint32_t* t_c;                 // pass A: literal-length extensions in front of the token ; pass B: its literal length
     uint32_t* t_d;                 // pass A: match-length extensions in front of the token ; pass B: output position of its literals ([nTok] = total)
     uint32_t* seg;                 // [nblocks][segs][8]
-    uint32_t* lx_g;                // per literal-length extension: 13 + t_a of its token
+    uint32_t* lx_g;                // per literal-length extension: 13 + t_a of its token + its ordinal in the block (the "+ 1" of every extension in front of it, taken off the chain)
     uint32_t* lx_c;                // extension bytes + extension values in front of it ([n] = total): size and value of one = the difference
     uint32_t* ml_val;              // values of the match-length extension records, in order
     uint32_t* map; uint64_t map_stride;
@@ -186,13 +186,14 @@ __global__ __launch_bounds__(256) void knz_lzi_a_apply_kernel(LziArgs g) {
         const LziTok k = knz_lzi_token((uint32_t)(w >> (8 * j)) & 0xFFu, k0 + j == nTok - 1);
         const size_t i = tb + k0 + j;
         g.t_a[i] = a; g.t_b[i] = d; g.t_c[i] = c; g.t_d[i] = m;
-        if (k.lext) g.lx_g[tb + c] = 13u + a;
+        if (k.lext) g.lx_g[tb + c] = 13u + a + c;
         a += k.lit; d += k.dbytes; c += k.lext; m += k.mext;
     }
 }
 
 // ---- literal lengths >= 7: the extension sits in the literal stream at the literal cursor (:657-661), so its position depends on
-// every extension in front of it: one wave per block walks them. The chain is  C -> byte at (13 + g[i] + C) -> C + 1 + byte  and it is
+// every extension in front of it: one wave per block walks them. The chain is  C -> byte at (13 + g[i] + C) -> C + 1 + byte  (the 1 per extension is
+// folded into g[i] by the kernel that writes it: the walk carries C minus the number of extensions it has passed, one add less per step) and it is
 // kept on the scalar unit: the g[i] arrive through the scalar cache eight at a time; the literal region is held as two 256-byte
 // windows in two vector registers (lane L = dword L; the window behind the current one is loaded while the current one is walked),
 // so that the byte at the cursor is one v_readlane and three scalar instructions away, with no memory access on the chain at all.
@@ -204,6 +205,7 @@ __device__ __forceinline__ void knz_lzi_ext_from_diff(uint32_t d, uint32_t& sz, 
     val = d - sz;
 }
 __global__ __launch_bounds__(64) void knz_lzi_litext_chain_kernel(LziArgs g) {
+    __shared__ uint32_t s_hist[16 * 64];
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
     uint32_t* G = g.geo + 16 * (size_t)b;
     if (!G[LZI_PAR]) return;
@@ -221,49 +223,71 @@ __global__ __launch_bounds__(64) void knz_lzi_litext_chain_kernel(LziArgs g) {
     // one step. What a damaged stream can do to the walk (a cursor behind the literals, a sum that wraps) is not tested per step: the
     // window loads are bounded by the block, the walk takes exactly E steps, and pass B checks every token's literal range against the
     // end of the literals (a block that fails there goes to the one-wave kernel).
-    auto step = [&](uint32_t gj, uint32_t j) {
-        const uint32_t pos = gj + C;                                           // (g[] holds 13 + the short literal bytes in front)
+    auto window = [&](uint32_t pos) -> uint32_t {                              // the byte at pos, through the windows
         uint32_t o = pos - wlo;
-        if (__builtin_expect(o >= 256, 0)) {                                   // (pos only grows: the cursor never falls in front of the window)
+        if (__builtin_expect(o >= 256, 0)) {                                   // (pos only grows, except when a group of steps is walked again: then it lies in front and both windows are loaded)
             if (o < 512) { w0 = w1; wlo += 256; }
             else { wlo = pos & ~3u; w0 = load_win(wlo); }                      // a jump over the whole next window
             w1 = load_win(wlo + 256);
             o = pos - wlo;
         }
         const uint32_t dw = wave_readlane(w0, o >> 2);
-        const uint32_t b0 = (dw >> (8 * (o & 3))) & 0xFFu;
-        uint32_t d = b0 + 1u;
+        return (dw >> (8 * (o & 3))) & 0xFFu;
+    };
+    auto advance = [&](uint32_t gj) {
+        const uint32_t pos = gj + C;                                           // (g[] holds 13 + the short literal bytes in front + the extensions in front; C their bytes and values minus one each)
+        const uint32_t b0 = window(pos);
+        uint32_t d = b0;                                                       // (bytes + value of this extension, minus one)
         if (__builtin_expect(b0 >= 254, 0)) {                                  // rare: the three / four byte forms, read where they stand
             uint32_t b1 = 0, b2 = 0, b3 = 0;
             if (pos + 4 <= count) { b1 = wave_uniform(src[pos + 1]); b2 = wave_uniform(src[pos + 2]); b3 = wave_uniform(src[pos + 3]); } else bad = true;
-            if (b0 == 254) d = 3u + 254u + (b1 << 8) + b2;
-            else { const uint32_t y = (b1 << 16) + (b2 << 8) + b3; if (y < 65535u) bad = true; d = 4u + 255u + y; }
+            if (b0 == 254) d = 2u + 254u + (b1 << 8) + b2;
+            else { const uint32_t y = (b1 << 16) + (b2 << 8) + b3; if (y < 65535u) bad = true; d = 3u + 255u + y; }
         }
-        hist = lane == j ? C : hist;
         C += d;
     };
+    // the same step taken for a one-byte extension without looking: the largest byte of sixteen steps is looked at once, and if one of them was a three or
+    // four byte form (a literal run of 261 bytes or more) the sixteen are walked again with the step above. A compare and a branch less on the chain per step.
+    uint32_t big = 0;
+    auto advance1 = [&](uint32_t gj) { const uint32_t b0 = window(gj + C); big = max(big, b0); C += b0; };
+    auto step = [&](uint32_t gj, uint32_t j) { hist = lane == j ? C : hist; advance(gj); };
+    // (the C in front of step L goes to lane L of `hist` with one v_writelane_b32; lane == j ? C : hist is a move, a compare and a select per step, a quarter of the walk's instructions)
+#define KNZ_LZI_STEP(G, L) { hist = wave_writelane_at<(L)>(hist, C); advance(G); }
+#define KNZ_LZI_STEP1(G, L) { hist = wave_writelane_at<(L)>(hist, C); advance1(G); }
+#define KNZ_LZI_16(S, Q) \
+        S(a.x, 16 * (Q)) S(a.y, 16 * (Q) + 1) S(a.z, 16 * (Q) + 2) S(a.w, 16 * (Q) + 3) \
+        S(b2.x, 16 * (Q) + 4) S(b2.y, 16 * (Q) + 5) S(b2.z, 16 * (Q) + 6) S(b2.w, 16 * (Q) + 7) \
+        S(c2.x, 16 * (Q) + 8) S(c2.y, 16 * (Q) + 9) S(c2.z, 16 * (Q) + 10) S(c2.w, 16 * (Q) + 11) \
+        S(d2.x, 16 * (Q) + 12) S(d2.y, 16 * (Q) + 13) S(d2.z, 16 * (Q) + 14) S(d2.w, 16 * (Q) + 15)
+#define KNZ_LZI_STEPS16(Q) if (n >= 16u * (Q) + 16u) { \
+        const uint8_t* gp = lg + 4 * (size_t)(i0 + 16u * (Q)); \
+        const knz_u32x4 a = wave_sload_u32x4(gp), b2 = wave_sload_u32x4(gp + 16), c2 = wave_sload_u32x4(gp + 32), d2 = wave_sload_u32x4(gp + 48); \
+        const uint32_t C0 = C; big = 0; \
+        KNZ_LZI_16(KNZ_LZI_STEP1, Q) \
+        if (__builtin_expect(big >= 254u, 0)) { C = C0; KNZ_LZI_16(KNZ_LZI_STEP, Q) } }
     for (uint32_t i0 = 0; i0 < E && !bad; i0 += 64) {
         const uint32_t n = min(64u, E - i0);
-        uint32_t j = 0;
         // the g[i] through the scalar cache, sixteen at a time: a scalar load is waited for where it is issued (the compiler drains lgkmcnt in front of
         // every v_readlane of the walk), so its ~150 ns sit on the chain once per load - once per sixteen steps now, once per four until round 6
-        for (; j + 16 <= n; j += 16) {
-            const uint8_t* gp = lg + 4 * (size_t)(i0 + j);
-            const knz_u32x4 a = wave_sload_u32x4(gp), b2 = wave_sload_u32x4(gp + 16), c2 = wave_sload_u32x4(gp + 32), d2 = wave_sload_u32x4(gp + 48);
-            step(a.x, j); step(a.y, j + 1); step(a.z, j + 2); step(a.w, j + 3);
-            step(b2.x, j + 4); step(b2.y, j + 5); step(b2.z, j + 6); step(b2.w, j + 7);
-            step(c2.x, j + 8); step(c2.y, j + 9); step(c2.z, j + 10); step(c2.w, j + 11);
-            step(d2.x, j + 12); step(d2.y, j + 13); step(d2.z, j + 14); step(d2.w, j + 15);
-        }
+        KNZ_LZI_STEPS16(0) KNZ_LZI_STEPS16(1) KNZ_LZI_STEPS16(2) KNZ_LZI_STEPS16(3)
+        uint32_t j = n & ~15u;
         for (; j + 4 <= n; j += 4) {
             const knz_u32x4 a = wave_sload_u32x4(lg + 4 * (size_t)(i0 + j));
             step(a.x, j); step(a.y, j + 1); step(a.z, j + 2); step(a.w, j + 3);
         }
         for (; j < n; j++) step(wave_sload_u32(lg + 4 * (size_t)(i0 + j)), j);
-        if (lane < n) lc[i0 + lane] = hist;
+        // The 64 cursors of the group wait in LDS and leave for memory sixteen groups at a time: the compiler drains vmcnt in front of every
+        // v_readlane of the walk (the windows are vector loads), so a store to memory is waited for by the very next step - once per 1024 steps this way
+        const uint32_t slot = (i0 >> 6) & 15u;
+        s_hist[slot * 64 + lane] = hist + i0 + lane;                           // (the ones come back here)
+        if (slot == 15u || i0 + 64 >= E) {
+            wave_sync_lds();
+            const uint32_t base = i0 - slot * 64;
+            for (uint32_t k = 0; k <= slot; k++) { const uint32_t i = base + k * 64 + lane; if (i < E) lc[i] = s_hist[k * 64 + lane]; }
+        }
     }
     if (C >= 0x40000000u) bad = true;
-    if (lane == 0) { if (bad) G[LZI_PAR] = 0; else lc[E] = C; }
+    if (lane == 0) { if (bad) G[LZI_PAR] = 0; else lc[E] = C + E; }
 }
 
 // ---- match-length extensions: a stream of records of 1, 3 or 4 bytes (readLengthLZ :214-231) ------------------------------------

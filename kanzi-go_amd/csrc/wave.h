@@ -45,6 +45,13 @@ __device__ __forceinline__ uint32_t wave_writelane0(uint32_t v, uint32_t val) {
     asm("v_writelane_b32 %0, %1, 0" : "+v"(v) : "s"(sv));
     return v;
 }
+// v with lane L (a compile-time constant) replaced by the wave-uniform value `val`. The lane select has to be an inline constant: two scalar registers in
+// one v_writelane_b32 break the constant-bus limit (and the value has to be one)
+template <int L> __device__ __forceinline__ uint32_t wave_writelane_at(uint32_t v, uint32_t val) {
+    const int sv = __builtin_amdgcn_readfirstlane((int)val);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(sv), "n"(L));
+    return v;
+}
 // value of lane-1, lane 0 keeps `old` (DPP wave_shr:1 without bound_ctrl: a lane whose source is out of range is not written)
 __device__ __forceinline__ uint32_t wave_shr1_old(uint32_t v, uint32_t old) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xF, 0xF, false); }
 // value of lane-1 written over `cur` in place: lane 0 keeps what `cur` holds there (one DPP move, no constant to re-materialise)
@@ -243,6 +250,7 @@ inline void wave_sync_lds() { hipemu::wave_barrier(); }
 inline uint32_t wave_shr1(uint32_t v) { const uint32_t r = wave_shfl(v, hipemu::lane() - 1); return hipemu::lane() == 0 ? 0u : r; }
 inline uint32_t wave_ror1(uint32_t v) { return wave_shfl(v, (hipemu::lane() + 63) & 63); }
 inline uint32_t wave_writelane0(uint32_t v, uint32_t val) { return hipemu::lane() == 0 ? val : v; }
+template <int L> inline uint32_t wave_writelane_at(uint32_t v, uint32_t val) { return hipemu::lane() == L ? val : v; }
 inline uint32_t wave_shl1(uint32_t v) { const uint32_t r = wave_shfl(v, hipemu::lane() + 1); return hipemu::lane() == 63 ? 0u : r; }
 inline uint32_t wave_shr1_old(uint32_t v, uint32_t old) { const uint32_t r = wave_shfl(v, hipemu::lane() - 1); return hipemu::lane() == 0 ? old : r; }
 inline uint32_t wave_shr1_keep0(uint32_t cur, uint32_t v) { const uint32_t r = wave_shfl(v, hipemu::lane() - 1); return hipemu::lane() == 0 ? cur : r; }

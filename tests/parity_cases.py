@@ -455,6 +455,14 @@ def lz_inverse_inputs(big=False):
         out += r
     yield "records", bytes(out)
     yield "text", corpus(600000 if big else 90000, seed=5)
+    # long literal runs in the MIDDLE of many short ones: the walk over the literal-length extensions takes sixteen of them as one-byte forms and
+    # walks the sixteen again when one was longer (lz_inv_par.hip), and its cursor windows jump
+    txt = corpus(40000, seed=6)
+    parts = []
+    for i in range(24):
+        parts.append(txt[i * 1500: (i + 1) * 1500])
+        parts.append(rng.integers(0, 256, int(rng.integers(255, 420)) if i != 11 else 66100, dtype=np.uint8).tobytes())
+    yield "lit_mixed", b"".join(parts)
 
 
 def check_lz_inverse_forms(be, monkeypatch, big=False):
