@@ -289,6 +289,10 @@ __global__ __launch_bounds__(64) void knz_lzi_litext_chain_kernel(LziArgs g) {
     if (C >= 0x40000000u) bad = true;
     if (lane == 0) { if (bad) G[LZI_PAR] = 0; else lc[E] = C + E; }
 }
+#undef KNZ_LZI_STEPS16
+#undef KNZ_LZI_16
+#undef KNZ_LZI_STEP1
+#undef KNZ_LZI_STEP
 
 // ---- match-length extensions: a stream of records of 1, 3 or 4 bytes (readLengthLZ :214-231) ------------------------------------
 struct LziRecMap { uint32_t exit; uint64_t cnt; };                      // per entry state s = 0..3: exit state (2 bits each), records started (16 bits each)
