@@ -146,8 +146,11 @@ __global__ __launch_bounds__(256) void knz_bwt_inv_keys_kernel(BwtInvArgs a, uin
     vals[i] = i;
 }
 
+// Distance between the splitters of the inverse's list ranking (below). A PRIME: with a splitter on every 128th slot the walks of record-shaped and
+// executable-like blocks resonated with their power-of-two periods (a walk that advances by multiples of 128 slots meets no splitter: the longest
+// sub-lists set the time of the walk and emit kernels); round 6, S-silesia 26 x 8 MiB: walk 19.7 -> 6.8 ms, emit 6.2 -> 1.9 ms, ranking 2.8 -> 1.7 ms.
 #ifndef KNZ_BWT_SPLIT
-#define KNZ_BWT_SPLIT 128u
+#define KNZ_BWT_SPLIT 191u
 #endif
 
 // LF links (BWT.go:228-247): slot p of the stably sorted order holds symbol v from payload index i; the link is
@@ -243,8 +246,8 @@ __global__ __launch_bounds__(64) void knz_bwt_inv_chains_kernel(BwtInvArgs a, co
 // list of n slots per block; the 8 chunk chains the format allows are still 1 M dependent HBM accesses each at 8 MiB (~430 ns per
 // hop, profiles/r02_lone_wave_latencies.md: 160 ms whatever the GPU does meanwhile). Instead:
 //   1. every KNZ_BWT_SPLIT-th slot (and every chunk start) is a splitter; one THREAD per splitter walks the list to the next
-//      splitter and records (successor, length): ~128 hops each, n / 128 independent walks per block: throughput, not latency;
-//   2. one workgroup per block ranks its splitter list by pointer jumping (Wyllie, log2(n/128) rounds over 64 K entries in L2):
+//      splitter and records (successor, length): ~191 hops each, n / 191 independent walks per block: throughput, not latency;
+//   2. one workgroup per block ranks its splitter list by pointer jumping (Wyllie, log2(n/191) rounds over 44 K entries in L2):
 //      distance of every splitter to the end of the text, hence its text position;
 //   3. one thread per splitter walks its sub-list again, four symbols per hop through the doubled links, and stores the symbols
 //      at the text positions now known.
