@@ -1,4 +1,4 @@
-# round 6 experiment: the splitters of the inverse BWT's list ranking on every 127th / 61st / 257th slot instead of every 128th (do the walks resonate with power-of-two record sizes?)
+# round 6 experiment: the splitters of the inverse BWT's list ranking on every 127th / 61st / 257th slot instead of every 128th (do the walks resonate with power-of-two record sizes?) Variants are built first with: bash tools/gpu/run.sh "lib:split127:-DKNZ_BWT_SPLIT=127u" ... (kanzi-go_amd/variants/, not tracked). Result: profiles/README.md, bwt.hip.
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 O=gpurun_out/r06_split; mkdir -p $O
 for v in base split127 split191 split257 split383 split509 base split257; do
