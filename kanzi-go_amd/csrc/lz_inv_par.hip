@@ -30,7 +30,15 @@
 #define KNZ_LZI_LIT 0x80000000u               // source map: literal byte, low bits = position in the block's input
 #define KNZ_LZI_SEL0 0xFFFFFFFEu              // repeat-distance maps: "the incoming repd0" / "the incoming repd1"
 #define KNZ_LZI_SEL1 0xFFFFFFFFu
-#define KNZ_LZI_HOPS 8
+// The source map is shortened by pointer doubling before the gather follows what is left: passes x hops per pass. Measured on S-silesia (51 x 4 MiB,
+// jump + gather ms): 2 x 8 (rounds 3-5) 4.84 + 0.43, 2 x 4 3.76 + 0.81, 3 x 2 3.19 + 0.81, 4 x 1 2.45 + 1.47, 5 x 1 2.94 + 0.83, none 0 + 22.8
+// (`tools/gpu/r06_jump.sh`). Any choice is exact: the gather follows every path to its literal.
+#ifndef KNZ_LZI_HOPS
+#define KNZ_LZI_HOPS 1
+#endif
+#ifndef KNZ_LZI_JUMP_PASSES
+#define KNZ_LZI_JUMP_PASSES 5
+#endif
 
 // geo[16 b + ..]
 enum { LZI_TK0 = 0, LZI_NTOK = 1, LZI_M0 = 2, LZI_ML0 = 3, LZI_COUNT = 4, LZI_MINMATCH = 5, LZI_MAXDIST = 6, LZI_PAR = 7,
