@@ -546,10 +546,17 @@ __device__ static bool knz_ans1_parse_ctx(R& r, uint16_t* f, uint32_t llr, uint3
         else { count = 256; if (f) for (int i = 0; i < 256; i++) alpha[i] = (uint8_t)i; }
     } else {
         const uint32_t lastMask = r.read(5);
-        for (uint32_t mm = 0; mm <= lastMask; mm++) {
-            const uint32_t mask = r.read(8);
-            if (f) { for (int j = 0; j < 8; j++) if ((mask >> j) & 1) alpha[count++] = (uint8_t)(8 * mm + j); }
-            else count += __popc(mask);                        // position walk only: the symbols themselves are not needed
+        if (f) {
+            for (uint32_t mm = 0; mm <= lastMask; mm++) {
+                const uint32_t mask = r.read(8);
+                for (int j = 0; j < 8; j++) if ((mask >> j) & 1) alpha[count++] = (uint8_t)(8 * mm + j);
+            }
+        } else {                                               // position walk only: the symbols themselves are not needed, four masks per read
+            for (uint32_t bitsLeft = 8 * (lastMask + 1); bitsLeft > 0;) {
+                const uint32_t take = bitsLeft > 32 ? 32 : bitsLeft;
+                count += __popc(r.read(take));
+                bitsLeft -= take;
+            }
         }
     }
     countOut = count;
@@ -560,7 +567,7 @@ __device__ static bool knz_ans1_parse_ctx(R& r, uint16_t* f, uint32_t llr, uint3
         const uint32_t logMax = r.read(llr);
         if ((1u << logMax) > scale) return false;
         const int endj = min(i + chk, count);
-        if (!f) { r.seek(r.tell() + (uint64_t)(endj - i) * logMax); continue; }
+        if (!f) { r.skip_bits((uint32_t)(endj - i) * logMax); continue; }
         for (int j = i; j < endj; j++) {
             uint32_t fr = 1;
             if (logMax > 0) { fr = 1 + r.read(logMax); if (fr >= scale) return false; }

@@ -38,6 +38,7 @@ struct KnzStreamReader {
     __device__ __forceinline__ uint32_t peek(uint32_t n) { refill(); return (uint32_t)(win >> (64 - n)); } // 1..32
     __device__ __forceinline__ void skip(uint32_t n) { refill(); win <<= n; navail -= n; }                 // 0..32
     __device__ __forceinline__ void consume(uint32_t n) { win <<= n; navail -= n; }                        // right after peek(>= n)
+    __device__ __forceinline__ void skip_bits(uint32_t n) { if (n <= 32) skip(n); else seek(tell() + n); }
     __device__ __forceinline__ uint32_t read(uint32_t n) { uint32_t v = peek(n); win <<= n; navail -= n; return v; }
     __device__ __forceinline__ uint64_t tell() const { return (next << 5) - navail; }
     __device__ __forceinline__ void seek(uint64_t bitpos) { init((const uint8_t*)words, nwords << 2, bitpos); }
@@ -85,6 +86,8 @@ struct KnzWaveReader {
     }
     __device__ __forceinline__ uint32_t peek(uint32_t n) { refill(); return (uint32_t)(win >> (64 - n)); }
     __device__ __forceinline__ void skip(uint32_t n) { refill(); win <<= n; navail -= n; }
+    // a jump ahead: inside the window when it is short (the header walks jump over six or eight frequencies at a time; seek() rebuilds the window)
+    __device__ __forceinline__ void skip_bits(uint32_t n) { if (n <= 32) skip(n); else seek(tell() + n); }
     __device__ __forceinline__ uint32_t read(uint32_t n) { uint32_t v = peek(n); win <<= n; navail -= n; return v; }
     __device__ __forceinline__ uint64_t tell() const { return (next << 5) - navail; }
 };
