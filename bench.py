@@ -479,8 +479,9 @@ def pmc_traffic(argv_child, timeout_s=900):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 10; 1 for --config fpaq, whose step takes half a minute): the chains of the default "
+                                                            "configuration move by a few per cent from step to step, three steps were too few for a steady mean")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps in front (default 3; 0 for --config fpaq)")
     ap.add_argument("--config", default="bwt", choices=sorted(CONFIGS))
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N>1: ONE fixed job (the BASELINE corpus) split over the GPUs (strong, default: the figure BASELINE.json's "
                                                                                     "metric and north_star name; the weak figure rides along as roofline.weak_value_MBps) or one corpus copy per GPU in one stream (weak)")
@@ -502,6 +503,10 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--no-host-hook", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 1 if args.config == "fpaq" else 10
+    if args.warmup is None:
+        args.warmup = 0 if args.config == "fpaq" else 3
     if args.handles or args.in_process_devices:
         # several handles = several streams: the HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues and
         # kernels of streams that share a queue run one after the other. libknz_gpu asks for 32 when it is loaded (unless the host chose a value); under
