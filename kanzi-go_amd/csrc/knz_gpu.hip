@@ -231,7 +231,19 @@ extern "C" int knz_open(const knz_cfg* cfg, void** handle) {
     // memory there, so nothing has to be ordered against the NULL stream of whatever else lives in the process
     if (hipStreamCreateWithFlags(&h->hstream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); h->hstream = nullptr; }
     for (int i = 0; i <= KNZ_STAGE_COUNT; i++) hipEventCreate(&h->ev[i]);
-    h->pipe_ready = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking) == hipSuccess;
+    // The two streams of the fused ZRLT / RANK chain (rank_pipe.hip) get priorities of their own: the runtime keeps a pool of hardware queues per priority
+    // level, so the long chains (stream3, highest), the short ones (stream2, lowest) and the caller's stream (the decoder under which they start) can never
+    // share a hardware queue. At one priority the runtime deals its few queues out in turn to every stream the PROCESS creates: where two of the three landed
+    // on one queue the kernels ran one after the other (a decode of configs[3] in 833 ms instead of 525, seen with the handle's own stream in a torch process).
+    {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+        const bool s2 = (least != greatest && hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, least) == hipSuccess) ||
+                        ((void)hipGetLastError(), hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess);
+        const bool s3 = (least != greatest && hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, greatest) == hipSuccess) ||
+                        ((void)hipGetLastError(), hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking) == hipSuccess);
+        h->pipe_ready = s2 && s3;
+    }
     for (int i = 0; i < 3; i++) if (hipEventCreateWithFlags(&h->ev_pipe[i], hipEventDisableTiming) != hipSuccess) h->pipe_ready = false;
     for (int i = 0; i < KNZ_STAGE_COUNT; i++) h->stage_ms[i] = 0.f;
     *handle = h;

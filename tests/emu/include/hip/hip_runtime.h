@@ -56,6 +56,8 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = 0) { me
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 #define hipStreamDefault 0u
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = 0; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 #define hipStreamNonBlocking 1u
 #define hipEventDisableTiming 2u
