@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timeline of the LAST decode of a rocprofv3 kernel trace (rocpd .db) of `bench.py`: every kernel from the decode's block walk on, with its start and end
-relative to the walk's start, and the gaps in which no kernel ran. usage: decode_timeline.py results.db [min_us]"""
+relative to the walk's start, and the gaps in which no kernel ran. usage: decode_timeline.py results.db [min_us] [first kernel of a decode, default knz_dec_walk_blocks_kernel]"""
 import re, sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 200.0
@@ -9,7 +9,8 @@ kd = [t for t in tabs if 'kernel_dispatch' in t][0]; ks = [t for t in tabs if 'k
 cols = [r[1] for r in c.execute(f"pragma table_info({kd})")]
 qcol = "d.queue_id" if "queue_id" in cols else ("d.stream_id" if "stream_id" in cols else "0")
 rows = c.execute(f"select s.kernel_name, d.start, d.end, {qcol} from {kd} d join {ks} s on d.kernel_id=s.id order by d.start").fetchall()
-i0 = [i for i, r in enumerate(rows) if 'knz_dec_walk_blocks_kernel' in r[0]][-1]
+first = sys.argv[3] if len(sys.argv) > 3 else 'knz_dec_walk_blocks_kernel'
+i0 = [i for i, r in enumerate(rows) if first in r[0]][-1]
 t0 = rows[i0][1]
 busy_end = t0
 for name, s, e, q in rows[i0:]:
